@@ -1,0 +1,149 @@
+"""The oracle (oracle/*.py) against the reference's own outputs (tests/golden/*.npz).
+
+These are the pins that make the oracle trustworthy: bit-equality for the Linf index/sign/clamp
+arithmetic and the APGD controller, <=1e-5 relative for the fp32 ViT against HF transformers.
+CPU only.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import attacks_ref as A
+from oracle import losses_ref as Lr
+from oracle import vit_ref as V
+from tests.helpers import (load_golden, weights_digest, cfg_from_array, weights_from_golden,
+                           rel_err, SmallNet, InjectGrad)
+
+torch.set_num_threads(4)
+
+
+@pytest.mark.parametrize("mode", ["max", "min"])
+def test_pgd_linf_elementwise_bit_exact(mode):
+    z = load_golden(f"pgd_linf_elementwise_{mode}.npz")
+    x, d0, grads = z["x"], z["delta0"], z["grads"]
+    eps, step = float(z["eps"]), float(z["stepsize"])
+    delta, vel = d0.copy(), np.zeros_like(d0)
+    for i in range(4):
+        delta, vel = A.pgd_linf_update_ref(x, grads[i], delta, vel, eps, step, 0.9, mode)
+        assert np.array_equal((x + delta).astype(np.float32), z["xadv"][i]), f"step {i}"
+    # and through the full loop restatement with an injected-gradient loss
+    xt = torch.from_numpy(x)
+    it = iter(range(4))
+    out = A.pgd_ref(lambda v, output_normalize=False: v,
+                    lambda o, t: InjectGrad.apply(o, torch.from_numpy(grads[next(it)])),
+                    xt, None, "linf", eps, 4, step, False,
+                    perturbation=torch.from_numpy(d0.copy()), mode=mode)
+    assert np.array_equal(out.numpy(), z["xadv"][3])
+
+
+@pytest.mark.parametrize("n_iter", [10, 50, 100])
+def test_apgd_train_controller_bit_exact(n_iter):
+    z = load_golden(f"apgd_train_smallnet_{n_iter}.npz")
+    net = SmallNet(torch.from_numpy(z["w1"]), torch.from_numpy(z["w2"])).eval()
+    ce = lambda lg, yy: torch.nn.functional.cross_entropy(lg, yy, reduction="none")  # noqa: E731
+    out = A.apgd_train_ref(net, torch.from_numpy(z["x"]), torch.from_numpy(z["y"]), "linf",
+                           float(z["eps"]), n_iter=n_iter, loss_fn=ce)
+    its = np.stack([t.numpy() for t in net.seen])
+    assert its.shape == z["iterates"].shape
+    for i in range(its.shape[0]):
+        assert np.array_equal(its[i], z["iterates"][i]), f"iterate {i} differs"
+    assert np.array_equal(out.numpy(), z["x_best_adv"])
+
+
+def test_apgd_schedule_constants():
+    # n_iter=10 -> (2,1,1); 50 -> (11,3,1); 100 -> (22,6,3)
+    assert A.apgd_schedule(10) == (2, 1, 1)
+    assert A.apgd_schedule(50) == (11, 3, 1)
+    assert A.apgd_schedule(100) == (22, 6, 3)
+
+
+def test_losses_match_reference():
+    z = load_golden("losses.npz")
+    emb, e0, T, y = (torch.from_numpy(z[k]) for k in ("emb", "e0", "T", "y"))
+    for loss in ("l2", "ce"):
+        for red in ("mean", "none"):
+            e = emb.clone().requires_grad_(True)
+            val = Lr.compute_loss_ref(loss, e, y, e0, 100., T, red)
+            (g,) = torch.autograd.grad(val.sum(), e)
+            assert np.array_equal(val.detach().numpy(), z[f"{loss}_{red}"])
+            assert np.array_equal(g.numpy(), z[f"{loss}_{red}_grad"])
+    assert Lr.compute_acc_ref(emb @ (100. * T), y) == float(z["acc"])
+    with pytest.raises(AssertionError):
+        Lr.l2_ref(emb[:1], e0[:1])          # batch size 1 is illegal (…clip.py:513)
+    with pytest.raises(ValueError):
+        Lr.compute_loss_ref("dlr", emb, y, e0, 100., T)
+
+
+@pytest.mark.parametrize("name", ["tiny2", "tiny2gelu", "b32"])
+def test_vit_matches_hf(name):
+    z = load_golden(f"vit_hf_{name}.npz")
+    cfg = cfg_from_array(z["cfg"], str(z["act"]))
+    w = V.init_weights(cfg, seed=int(z["weights_seed"]))
+    assert weights_digest(w) == str(z["weights_sha256"]), "seeded weight generator drifted"
+    x = torch.from_numpy(z["x"])
+    xn = V.normalize_pixels(x).requires_grad_(True)
+    emb = V.vit_forward(cfg, w, xn)
+    (gx,) = torch.autograd.grad((emb * torch.from_numpy(z["cot"])).sum(), xn)
+    assert rel_err(emb.detach().numpy(), z["emb"]) < 1e-5
+    assert rel_err(gx.numpy(), z["grad_xn"]) < 1e-4
+    agree = np.mean(np.sign(gx.numpy()) == np.sign(z["grad_xn"]))
+    assert agree > 0.999
+
+
+def _tiny():
+    z = load_golden("tiny_vit_attacks.npz")
+    cfg = cfg_from_array(z["cfg"])
+    w = weights_from_golden(z)
+    assert weights_digest(w) == str(z["weights_sha256"])
+    w2 = V.init_weights(cfg, seed=int(z["weights_seed"]))
+    assert weights_digest(w2) == str(z["weights_sha256"]), "seeded weight generator drifted"
+    return z, cfg, w
+
+
+@pytest.mark.parametrize("loss_name,on", [("l2", False), ("ce", True)])
+def test_tiny_vit_pgd_end_to_end_bit_exact(loss_name, on):
+    z, cfg, w = _tiny()
+    model = V.ClipVisionModelRef(cfg, w).eval()
+    x, y, T = (torch.from_numpy(z[k]) for k in ("x", "y", "T"))
+    with torch.no_grad():
+        e0 = model(x, on)
+    assert np.array_equal(e0.numpy(), z[f"e0_norm{int(on)}"])
+    wrap = Lr.ComputeLossWrapperRef(e0, T, "mean", loss_name, 100.)
+    out = A.pgd_ref(model, wrap, x, y, "linf", float(z["eps"]), 10, float(z["stepsize"]), on,
+                    perturbation=torch.from_numpy(z["delta0"].copy()), mode="max")
+    assert np.array_equal(out.numpy(), z[f"pgd_{loss_name}_xadv"])
+
+
+@pytest.mark.parametrize("loss_name", ["l2", "ce"])
+def test_tiny_vit_apgd_end_to_end_bit_exact(loss_name):
+    z, cfg, w = _tiny()
+    model = V.ClipVisionModelRef(cfg, w).eval()
+    x, y, T = (torch.from_numpy(z[k]) for k in ("x", "y", "T"))
+    with torch.no_grad():
+        e0 = model(x, True)
+    wrap = Lr.ComputeLossWrapperRef(e0, T, "none", loss_name, 100.)
+    out = A.apgd_train_ref(model, x, y, "linf", float(z["eps"]), n_iter=10, loss_fn=wrap)
+    assert np.array_equal(out.numpy(), z[f"apgd_{loss_name}_xadv"])
+
+
+@pytest.mark.parametrize("r", [1, 2])
+def test_autopgd_bit_exact(r):
+    z = load_golden(f"autopgd_tiny_r{r}.npz")
+    cfg = V.VIT_TINY
+    w = V.init_weights(cfg, seed=int(z["weights_seed"]))
+    assert weights_digest(w) == str(z["weights_sha256"])
+    clf = V.ClassificationModelRef(cfg, w, torch.from_numpy(z["T"]), 100.0).eval()
+    seen = []
+
+    def predict(v):
+        seen.append(v.detach().clone())
+        return clf(v)
+
+    atk = A.APGDAttackRef(predict, n_iter=int(z["n_iter"]), norm="Linf", n_restarts=r,
+                          eps=float(z["eps"]), seed=0, loss="ce", alpha=2.0, use_rs=True)
+    adv = atk.perturb(torch.from_numpy(z["x"]), torch.from_numpy(z["y"]))
+    assert np.array_equal(seen[1].numpy(), z["first_start"])
+    assert len(seen) == int(z["n_model_calls"])
+    assert np.array_equal(adv.numpy(), z["adv"])
+    # never-attacked sample (started misclassified) comes back untouched
+    assert np.array_equal(adv.numpy()[0], z["x"][0])
