@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py - adversarial images/sec of the MI355X-native PGD inner loop (BASELINE.json metric).
+
+One "step" = one complete ``pgd()`` call (10-step L-inf PGD, eps=4/255, step 1/255, FARE l2 loss,
+delta0 ~ U(-eps,eps), mode='max') over one synthetic batch of 128 images 224x224x3 on the CLIP
+ViT-L/14 vision encoder in bf16 (BASELINE config 2; config 4 = the same per GPU on 8 GPUs).
+Weights are seeded random-init of that architecture (no checkpoints offline), inputs are resident in
+HBM before the timed region.  One process per GPU; the attack is per-sample, so ranks shard images
+with NO data-path collective (weak scaling) - torch.distributed (RCCL) only provides the barrier and
+the max-over-ranks time.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     - bf16 MFMA GEMM kernel: algorithmic FLOPs / HIP-event launch time, vs 2.5 PFLOP/s
+  cpu_baseline - the oracle (PyTorch-CPU restatement of the reference path) timed on this host
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+FLOP_PER_IMG_ITER = {"ViT-L-14": 330.545e9, "ViT-B-32": 17.728e9}   # SURVEY.md Appendix C (fwd + input-bwd)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", default="ViT-L-14")
+    ap.add_argument("--batch", type=int, default=128, help="images per GPU per step")
+    ap.add_argument("--iterations", type=int, default=10)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--attack", default="pgd", choices=["pgd", "apgd"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(iterations_full=10):
+    """The reference path's CPU restatement (oracle/) on this host's cores: a bounded sample of the
+    SAME workload (ViT-L/14 fp32, FARE PGD, eps=4/255), scaled to adversarial images/sec."""
+    from oracle import vit_ref as V
+    from oracle.attacks_ref import pgd_ref
+    from oracle.losses_ref import ComputeLossWrapperRef
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = V.VIT_L_14
+    w = V.init_weights(cfg, seed=0)
+    model = V.ClipVisionModelRef(cfg, w).eval()
+    g = torch.Generator().manual_seed(0)
+    B, iters = 2, 2
+    x = torch.rand(B, 3, 224, 224, generator=g)
+    eps = 4 / 255
+    d0 = torch.zeros_like(x).uniform_(-eps, eps, generator=g)
+    with torch.no_grad():
+        e0 = model(x, False)
+    wrap = ComputeLossWrapperRef(e0, None, "mean", "l2", 100.)
+    t0 = time.time()
+    pgd_ref(model, wrap, x, None, "linf", eps, iters, 1 / 255, False, perturbation=d0, mode="max")
+    dt = time.time() - t0
+    per_call_full = dt * iterations_full / iters
+    return {"value": B / per_call_full, "unit": "adversarial images/sec", "cores": cores, "kind": "port",
+            "sample": f"oracle pgd_ref (torch {torch.__version__} CPU fp32, {cores} threads): ViT-L/14, batch {B}, "
+                      f"{iters} of {iterations_full} PGD iterations timed ({dt:.1f} s) and scaled x{iterations_full // iters}"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+
+    import robustvlm_amd as R
+    cfg = R.CONFIGS[args.model]
+    sd = R.random_state_dict(cfg, seed=0, device=dev)           # same weights on every rank
+    eng = R.VitEngine(cfg, sd, precision=args.precision, max_batch=args.batch, device=dev)
+    del sd
+    model = R.ClipVisionModel(eng).eval()
+    B = args.batch
+    g = torch.Generator(device=dev).manual_seed(1000 + rank)   # each rank its own shard of images
+    x = torch.rand(B, 3, cfg.image_size, cfg.image_size, generator=g, device=dev)
+    eps, stepsize = 4 / 255, 1 / 255
+    d0 = (torch.rand(x.shape, generator=g, device=dev) * 2 - 1) * eps
+    y = torch.randint(0, 1000, (B,), generator=g, device=dev)
+    e0 = model(x, args.attack == "apgd")                        # embedding_orig (…clip.py:296-297)
+    if args.attack == "pgd":
+        wrap = R.ComputeLossWrapper(e0, None, "mean", "l2", 100.)
+
+        def step():
+            return R.pgd(model, wrap, x, y, "linf", eps, args.iterations, stepsize, False,
+                         perturbation=d0, mode="max")
+    else:
+        T = torch.randn(cfg.out_dim, 1000, generator=g, device=dev)
+        T = T / T.norm(dim=0, keepdim=True)
+        wrap = R.ComputeLossWrapper(e0, T, "none", "ce", 100.)
+
+        def step():
+            return R.apgd_train(model, x, y, "linf", eps, n_iter=args.iterations, loss_fn=wrap)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    barrier()
+    assert float((out - x).abs().max()) <= 4 / 255 + 1e-6
+
+    res = None
+    if rank == 0:
+        value = world * B * args.steps / el
+        res = {
+            "metric": "adversarial images/sec (ViT-L/14, 10-step PGD eps=4/255)" if args.model == "ViT-L-14"
+                      else f"adversarial images/sec ({args.model}, {args.iterations}-step {args.attack})",
+            "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"FARE {args.attack.upper()} {args.iterations}-step eps=4/255 on {args.model} "
+                                   f"{args.precision}, batch={B} per GPU, 224x224x3 synthetic, seeded random-init weights "
+                                   f"(BASELINE configs[{1 if world == 1 else 3}])",
+                       "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world} (no data-path collective)",
+                       "loss": "l2/mean" if args.attack == "pgd" else "ce/none"},
+            "whole_loop_tflops_per_gpu": value / world * FLOP_PER_IMG_ITER.get(args.model, 0) * args.iterations / 1e12,
+        }
+        res["whole_loop_frac_of_peak"] = res["whole_loop_tflops_per_gpu"] / PEAK_BF16_TFLOPS
+
+    # ---- roofline of the dominant kernel (bf16 MFMA GEMM), HIP events on the engine's stream ------
+    if rank == 0 and not args.no_roofline:
+        eng.set_profiling(True)
+        eng.reset_profile()
+        step()
+        prof = eng.get_profile()
+        eng.set_profiling(False)
+        gemm = {k: v for k, v in prof.items() if k.startswith("gemm_") and "patch" not in k}
+        gflops = sum(v["flops"] for v in gemm.values())
+        gms = sum(v["ms"] for v in gemm.values())
+        glaunch = sum(v["launches"] for v in gemm.values())
+        attn_gemm = {k: v for k, v in prof.items() if k in ("gemm_qkv_fwd", "gemm_out_fwd", "gemm_qkv_bwd",
+                                                            "gemm_out_bwd", "attn_fwd", "attn_bwd")}
+        achieved = gflops / (gms * 1e-3) / 1e12 if gms > 0 else 0.0
+        res["roofline"] = {
+            "bound": "mfma", "kernel": "gemm_bf16_nt_kernel (QKV/out-proj/fc1/fc2, fwd + dgrad)",
+            "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
+            "traffic": None,
+            "flops_per_launch": gflops / max(glaunch, 1), "avg_launch_ms": gms / max(glaunch, 1),
+            "launches": glaunch,
+            "attention_gemm_subset": {
+                "tflops": sum(v["flops"] for v in attn_gemm.values()) / max(sum(v["ms"] for v in attn_gemm.values()), 1e-9) / 1e9,
+                "frac": sum(v["flops"] for v in attn_gemm.values()) / max(sum(v["ms"] for v in attn_gemm.values()), 1e-9) / 1e9 / PEAK_BF16_TFLOPS},
+            "per_class": {k: {"ms": round(v["ms"], 3), "launches": v["launches"],
+                              "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 and v["flops"] > 0 else None,
+                              "gbps": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 and v["bytes"] > 0 else None}
+                          for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
+        }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(args.iterations)
+    if rank == 0:
+        print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

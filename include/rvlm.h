@@ -1,0 +1,221 @@
+/* rvlm.h - C ABI of librvlm.so, the MI355X (gfx950) adversarial inner loop for RobustVLM.
+ *
+ * Drop-in boundary.  Everything the reference's Python hot path does on
+ * the device goes through these entry points; the Python shim in robustvlm_amd/ binds them with
+ * ctypes (INTEGRATION.md shows the stub a reference maintainer would add).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch / C++ types.
+ *   - every pointer is a DEVICE pointer owned by the caller unless the name ends in _host.
+ *   - every function takes the hipStream_t to enqueue on (as void*), never synchronises the device
+ *     (except *_create / *_destroy / *_get_profile), starts no threads and allocates nothing after
+ *     rvlm_vit_create.
+ *   - return value: 0 = RVLM_OK, otherwise an rvlm_status; rvlm_last_error() gives the message of
+ *     the last failure on the calling thread.  No exceptions cross the ABI.
+ *   - images are NCHW fp32 in [0,1] (un-normalised: the CLIP mean/std Normalize lives inside the
+ *     encoder, train/adversarial_training_clip.py:105-108,254), targets are int64.
+ */
+#ifndef RVLM_H
+#define RVLM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RVLM_VERSION 100
+
+typedef void* rvlm_stream_t; /* hipStream_t */
+typedef struct rvlm_vit rvlm_vit;
+
+typedef enum {
+    RVLM_OK = 0,
+    RVLM_ERR_ARG = 1,         /* bad argument (null pointer, shape out of range, unknown enum) */
+    RVLM_ERR_HIP = 2,         /* a HIP runtime call failed */
+    RVLM_ERR_STATE = 3,       /* call order violated (e.g. backward without a saved forward) */
+    RVLM_ERR_UNSUPPORTED = 4  /* configuration the kernels do not cover */
+} rvlm_status;
+
+enum { RVLM_PREC_F32 = 0, RVLM_PREC_BF16 = 1 };       /* GEMM/attention operand precision */
+enum { RVLM_ACT_QUICK_GELU = 0, RVLM_ACT_GELU = 1 };  /* open_clip QuickGELU / exact erf GELU */
+enum { RVLM_LOSS_L2 = 0, RVLM_LOSS_CE = 1 };          /* FARE l2 / TeCoA ce (…clip.py:495-528) */
+enum { RVLM_RED_MEAN = 0, RVLM_RED_NONE = 1 };        /* reduction='mean' | 'none' (grad of sum) */
+
+/* bits of the device-side flag word written by the attack kernels (replaces the reference's
+ * per-iteration host asserts, train/pgd_train.py:24,40,60-63) */
+enum {
+    RVLM_FLAG_INPUT_RANGE = 1, /* data_clean outside [0,1] (+-1e-6)          pgd_train.py:24    */
+    RVLM_FLAG_NAN_GRAD = 2,    /* NaN in the gradient (zeroed, not an error) pgd_train.py:40-42 */
+    RVLM_FLAG_NAN_DELTA = 4,   /* NaN in the perturbation                    pgd_train.py:60    */
+    RVLM_FLAG_ADV_RANGE = 8    /* x+delta left [0,1] (+-1e-6)                pgd_train.py:61-63 */
+};
+
+/* ---------------------------------------------------------------------------------------------
+ * Encoder: open_clip VisionTransformer forward + input-gradient.
+ * Replaces `ClipVisionModel.forward` (train/adversarial_training_clip.py:253-257) and the autograd
+ * backward `torch.autograd.grad(loss, perturbation)` (train/pgd_train.py:38, apgd_train.py:185,295).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t image_size; /* 224 */
+    int32_t patch;      /* 14 (ViT-L/14), 32 (ViT-B/32) */
+    int32_t width;      /* 1024 / 768; heads * 64 */
+    int32_t layers;     /* 24 / 12 */
+    int32_t heads;      /* 16 / 12 (head_dim must be 64) */
+    int32_t out_dim;    /* 768 / 512 */
+    int32_t act;        /* RVLM_ACT_* */
+    int32_t precision;  /* RVLM_PREC_* */
+    int32_t max_batch;  /* workspace is sized for this many images */
+    float mean[3];      /* Normalize constants, …clip.py:116 */
+    float std[3];
+} rvlm_vit_config;
+
+/* fp32 device pointers in `visual.state_dict()` layout (…clip.py:239,470; Appendix B key list). */
+typedef struct {
+    const float* ln_1_weight;          /* [W]      */
+    const float* ln_1_bias;            /* [W]      */
+    const float* attn_in_proj_weight;  /* [3W, W]  */
+    const float* attn_in_proj_bias;    /* [3W]     */
+    const float* attn_out_proj_weight; /* [W, W]   */
+    const float* attn_out_proj_bias;   /* [W]      */
+    const float* ln_2_weight;          /* [W]      */
+    const float* ln_2_bias;            /* [W]      */
+    const float* mlp_c_fc_weight;      /* [4W, W]  */
+    const float* mlp_c_fc_bias;        /* [4W]     */
+    const float* mlp_c_proj_weight;    /* [W, 4W]  */
+    const float* mlp_c_proj_bias;      /* [W]      */
+} rvlm_vit_block_weights;
+
+typedef struct {
+    const float* class_embedding;      /* [W]            */
+    const float* positional_embedding; /* [tokens, W]    */
+    const float* proj;                 /* [W, out_dim]   */
+    const float* conv1_weight;         /* [W, 3, P, P]   */
+    const float* ln_pre_weight;        /* [W] */
+    const float* ln_pre_bias;
+    const float* ln_post_weight;
+    const float* ln_post_bias;
+    const rvlm_vit_block_weights* blocks_host; /* HOST array of `layers` structs of device ptrs */
+} rvlm_vit_weights;
+
+/* Allocates the workspace, converts/transposes the weights into the engine's layout. */
+int rvlm_vit_create(const rvlm_vit_config* cfg, const rvlm_vit_weights* weights,
+                    rvlm_stream_t stream, rvlm_vit** out);
+int rvlm_vit_destroy(rvlm_vit* h);
+/* Re-import weights (after an optimizer step of the outer trainer). */
+int rvlm_vit_load_weights(rvlm_vit* h, const rvlm_vit_weights* weights, rvlm_stream_t stream);
+/* Bytes of device memory the handle owns. */
+size_t rvlm_vit_workspace_bytes(const rvlm_vit* h);
+
+/* emb[B,out_dim] = visual(Normalize(x + delta)) (delta may be NULL), L2-normalised iff
+ * output_normalize.  save_for_backward != 0 keeps the activations rvlm_vit_backward_input needs. */
+int rvlm_vit_forward(rvlm_vit* h, const float* x, const float* delta, int B, int output_normalize,
+                     int save_for_backward, float* out_emb, rvlm_stream_t stream);
+/* grad_x[B,3,H,W] = d<d_emb, emb>/d(x+delta) for the last saved forward (dgrad only, no wgrad). */
+int rvlm_vit_backward_input(rvlm_vit* h, const float* d_emb, int B, float* grad_x,
+                            rvlm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Losses (replace compute_loss / l2 / ce, …clip.py:495-528) - loss value and d loss / d emb.
+ *   L2:  ref = embedding_orig [B,D];  per_sample = sum_d (emb-ref)^2
+ *   CE:  ref = text head T [D,C] (column-normalised); logits = emb @ (logit_scale*T)
+ * reduction MEAN: *loss_scalar = mean_b, d_emb carries the 1/B; NONE: d_emb = grad of the sum.
+ * pred_eq (optional, u8[B]) = argmax_c(logits) == targets (CE only).  scratch: CE needs
+ * B*C + D*C floats (may be NULL for L2).
+ * ------------------------------------------------------------------------------------------- */
+int rvlm_loss_grad(int loss_kind, int reduction, const float* emb, const float* ref,
+                   const int64_t* targets, int B, int D, int C, float logit_scale,
+                   float* loss_per_sample, float* loss_scalar, float* d_emb, uint8_t* pred_eq,
+                   float* scratch, rvlm_stream_t stream);
+/* out[b] = (argmax_j logits[b,j] == targets[b]); ties -> first index (…clip.py:490,
+ * apgd_train.py:192,301). */
+int rvlm_argmax_eq(const float* logits, const int64_t* targets, int B, int C, uint8_t* out,
+                   rvlm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * L-inf attack arithmetic (bit-exact with the reference).
+ * ------------------------------------------------------------------------------------------- */
+/* flags |= RVLM_FLAG_INPUT_RANGE if any x outside (-1e-6, 1+1e-6)   (pgd_train.py:24) */
+int rvlm_check_image_range(const float* x, size_t n, int32_t* flags, rvlm_stream_t stream);
+/* One PGD step (pgd_train.py:38-63 + vlm_eval/attacks/utils.py:10,21), in place on delta/velocity:
+ *   g=NaN->0; v=sign(mom*v+sign(g)); delta=clamp(delta +/- step*v, +-eps);
+ *   delta=clamp(x+delta,0,1)-x.   x_adv_out (optional) = x + delta. */
+int rvlm_pgd_linf_update(const float* x, const float* grad, float* delta, float* velocity,
+                         size_t n, float eps, float stepsize, float momentum, int mode_max,
+                         float* x_adv_out, int32_t* flags, rvlm_stream_t stream);
+/* One APGD step (apgd_train.py:205-229 == autopgd_base.py:328-341); step is per-sample [B]. */
+int rvlm_apgd_linf_step(const float* x, float* x_adv, float* x_adv_old, const float* grad,
+                        const float* step, float a, float eps, size_t n_per_sample, int B,
+                        rvlm_stream_t stream);
+/* Per-sample APGD bookkeeping for iteration i (apgd_train.py:301-305,320-355): k and do_check
+ * follow the data-independent checkpoint schedule kept by the host. */
+int rvlm_apgd_controller(int i, int B, int n_iter, int k, int do_check, const float* loss_i,
+                         const uint8_t* pred, float* loss_steps, float* loss_best,
+                         float* loss_best_last_check, float* reduced_last_check, float* step,
+                         uint8_t* acc, uint8_t* f_notpred, uint8_t* f_improved,
+                         uint8_t* f_reduced, rvlm_stream_t stream);
+/* The index assignments of the same lines as one pass over the image tensors. */
+int rvlm_apgd_select(float* x_adv, float* grad, float* x_best, float* grad_best,
+                     float* x_best_adv, const uint8_t* f_notpred, const uint8_t* f_improved,
+                     const uint8_t* f_reduced, size_t n_per_sample, int B, rvlm_stream_t stream);
+/* APGDAttack random start (autopgd_base.py:210-214,180-183): x + eps * t / (max_b|t| + 1e-12). */
+int rvlm_linf_random_start(const float* x, const float* t, float eps, size_t n_per_sample, int B,
+                           float* x_adv, rvlm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Whole loops, device resident (no host sync inside): replace
+ *   pgd()        train/pgd_train.py:5-68          -> rvlm_pgd_run
+ *   apgd_train() train/apgd_train.py:125-373      -> rvlm_apgd_run (train_variant = 1)
+ *   APGDAttack.attack_single_run autopgd_base.py:205-451 -> rvlm_apgd_run (train_variant = 0)
+ * with the FARE / TeCoA losses bound (ComputeLossWrapper, …clip.py:260-274).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t loss_kind;        /* RVLM_LOSS_* */
+    int32_t reduction;        /* pgd: MEAN (trainer) ; apgd: NONE */
+    int32_t output_normalize; /* F.normalize the embedding */
+    int32_t n_classes;        /* C for CE (columns of ref) */
+    float logit_scale;        /* 100. */
+    const float* ref;         /* L2: embedding_orig [B,D];  CE: T [D,C] */
+    const int64_t* targets;   /* [B] (CE, and the argmax test of apgd); may be NULL for pgd+L2 */
+} rvlm_loss_spec;
+
+/* x_adv_out = pgd(...) ; delta0 may be NULL (zeros).  flags: see RVLM_FLAG_*.
+ * loss_trace (optional, [iterations]) receives the scalar loss of every iteration. */
+int rvlm_pgd_run(rvlm_vit* h, const float* x, const float* delta0, int B,
+                 const rvlm_loss_spec* loss, float eps, int iterations, float stepsize,
+                 float momentum, int mode_max, float* x_adv_out, float* loss_trace,
+                 int32_t* flags, rvlm_stream_t stream);
+
+/* APGD L-inf.  x_init: NULL -> start from clamp(x,0,1) (apgd_train) or the caller-provided random
+ * start (APGDAttack).  logits_from_head: 0 -> the `argmax(model output)==y` test runs on the
+ * embedding (apgd_train quirk); 1 -> on emb @ (logit_scale*T) logits
+ * (ClassificationModel, CLIP_eval/clip_robustbench.py:50-69).
+ * Outputs (each optional): x_best_adv, x_best, loss_best [B], acc u8[B]. */
+int rvlm_apgd_run(rvlm_vit* h, const float* x, const float* x_init, int B,
+                  const rvlm_loss_spec* loss, float eps, int n_iter, float alpha,
+                  int train_variant, int logits_from_head, float* x_best_adv, float* x_best,
+                  float* loss_best, uint8_t* acc, rvlm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Measurement support: per-kernel-class HIP-event timing on the engine's stream.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    char name[48];
+    double total_ms;  /* sum of launch durations */
+    double flops;     /* algorithmic FLOPs of those launches (2/MAC, GEMM-shaped work only) */
+    double bytes;     /* algorithmic bytes (HBM-bound kernels) */
+    int64_t launches;
+} rvlm_profile_entry;
+int rvlm_vit_set_profiling(rvlm_vit* h, int enabled);
+/* Synchronises the device; writes up to *n entries, sets *n to the count. */
+int rvlm_vit_get_profile(rvlm_vit* h, rvlm_profile_entry* out, int* n);
+int rvlm_vit_reset_profile(rvlm_vit* h);
+
+const char* rvlm_last_error(void);
+int rvlm_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RVLM_H */

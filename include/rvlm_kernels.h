@@ -1,0 +1,43 @@
+/* rvlm_kernels.h - kernel-level entry points of librvlm.so (unit-test / benchmarking surface).
+ *
+ * Not part of the drop-in boundary (that is rvlm.h); these expose the individual HIP kernels the
+ * encoder is built from so tests/ can check each one against the oracle in isolation.
+ * bf16 buffers are passed as uint16_t* (raw bfloat16 bits).  All pointers are device pointers.
+ */
+#ifndef RVLM_KERNELS_H
+#define RVLM_KERNELS_H
+#include "rvlm.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* C[M,N] = epi(A[M,K] @ Bw[N,K]^T): epi 0 bf16 out(+bias); 1 f32 out(+bias)(+residual f32);
+ * 2 out_pre=bf16(acc+bias), out=bf16 act(.); 3 out=bf16 acc*act'(h_pre); 4 f32 out(+bias).
+ * A must be readable for round_up(M,128) rows. */
+int rvlm_k_gemm_bf16_nt(const uint16_t* A, long lda, const uint16_t* Bw, long ldb, int M, int N, int K,
+                        int a_rows, int epi, const float* bias, void* out, long ldo, uint16_t* out_pre,
+                        const uint16_t* h_pre, const float* residual, int act, rvlm_stream_t stream);
+/* generic strided batched fp32 GEMM (see robustvlm_amd/csrc/kernels.h: GemmF32) */
+int rvlm_k_gemm_f32(const float* A, long sam, long sak, const float* B, long sbn, long sbk, float* C,
+                    long scm, long scn, int M, int N, int K, float alpha, const float* bias,
+                    rvlm_stream_t stream);
+/* bf16 flash attention on packed qkv [B*S, 3W] (head_dim 64); lse2 [B*H*round_up(S,32)] */
+int rvlm_k_attn_fwd_bf16(const uint16_t* qkv, uint16_t* o, float* lse2, int B, int H, int S,
+                         rvlm_stream_t stream);
+int rvlm_k_attn_bwd_bf16(const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o, const float* lse2,
+                         float* dsum_scratch, uint16_t* dqkv, int B, int H, int S, rvlm_stream_t stream);
+/* 1: ds_read_b64_tr_b16 transposed fragments (default); 0: scalar-LDS-read validation variant */
+int rvlm_k_attn_set_use_tr(int on);
+int rvlm_k_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y,
+                             float* mean, float* rstd, int M, int W, rvlm_stream_t stream);
+int rvlm_k_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean,
+                             const float* rstd, float* dres, int accumulate, int M, int W,
+                             rvlm_stream_t stream);
+/* micro-probe of ds_read_b64_tr_b16: out[lane*4+j] for a 64-lane wave reading the bf16 buffer `src`
+ * (>= 2048 elements, copied to LDS) at per-lane byte offsets `offs[64]`. */
+int rvlm_k_probe_tr16(const uint16_t* src, const int32_t* offs, uint16_t* out, rvlm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,138 @@
+"""Drop-in ``APGDAttack`` (autoattack/autopgd_base.py:89-582) for BASELINE config 5:
+L-inf, CE loss, random start, restarts over still-correct points.
+
+Native routes as in apgd_train.py: fused (predict is a :class:`ClassificationModel` over the
+engine -> rvlm_apgd_run with the zero-shot head on the device) or generic (any ``predict``).
+Branches the repo's configs never select (DLR / targeted / L1 / L2 / TF adapters /
+use_largereps) raise NotImplementedError.
+"""
+from __future__ import annotations
+
+import time
+
+import torch
+
+from . import _lib as L
+from .apgd_train import _apgd_linf_generic, apgd_schedule
+from .clip_model import ClassificationModel
+from .engine import _require_cuda, _f32c
+
+
+class APGDAttack():
+    """AutoPGD https://arxiv.org/abs/2003.01690 (constructor of autopgd_base.py:105-124)."""
+
+    def __init__(self, predict, n_iter=100, norm='Linf', n_restarts=1, eps=None, seed=0, loss='ce',
+                 eot_iter=1, rho=.75, topk=None, verbose=False, device=None, use_largereps=False,
+                 is_tf_model=False, logger=None, alpha=None, use_rs=True):
+        self.model = predict
+        self.n_iter = n_iter
+        self.eps = eps
+        self.norm = norm
+        self.n_restarts = n_restarts
+        self.seed = seed
+        self.loss = loss
+        self.eot_iter = eot_iter
+        self.thr_decr = rho
+        self.topk = topk
+        self.verbose = verbose
+        self.device = device
+        self.use_rs = use_rs
+        self.use_largereps = use_largereps
+        self.n_iter_orig = n_iter + 0
+        assert self.norm in ['Linf', 'L2', 'L1']
+        assert not self.eps is None
+        self.eps_orig = eps + 0.
+        self.is_tf_model = is_tf_model
+        self.y_target = None
+        self.logger = logger
+        self.alpha = alpha
+        self.n_iter_2, self.n_iter_min, self.size_decr = apgd_schedule(self.n_iter)
+        if norm != 'Linf' or is_tf_model or use_largereps or eot_iter != 1 or rho != .75:
+            raise NotImplementedError("native APGDAttack covers norm='Linf', eot_iter=1, rho=0.75, torch models")
+
+    def init_hyperparam(self, x):
+        if self.device is None:
+            self.device = x.device
+        self.orig_dim = list(x.shape[1:])
+        self.ndims = len(self.orig_dim)
+        if self.seed is None:
+            self.seed = time.time()
+
+    def _random_start(self, x):
+        """x + eps * t / max|t|, t ~ U(-1,1) drawn on the CPU generator like the reference
+        (autopgd_base.py:210-214 does torch.rand(x.shape).to(device)), normalised on the device."""
+        lib = L.load()
+        t = (2 * torch.rand(x.shape).to(x.device).detach() - 1).contiguous()
+        out = torch.empty_like(x)
+        B = x.shape[0]
+        with torch.cuda.device(x.device):
+            L.check(lib.rvlm_linf_random_start(x.data_ptr(), t.data_ptr(), float(self.eps), x[0].numel(), B,
+                                               out.data_ptr(), L.stream_ptr()))
+        return out
+
+    def attack_single_run(self, x, y, x_init=None):
+        """Returns (x_best, acc, loss_best, x_best_adv) like autopgd_base.py:205-451."""
+        if self.loss != 'ce':
+            raise NotImplementedError(f"native APGDAttack covers loss='ce' (got {self.loss})")
+        x = _f32c(x)
+        start = self._random_start(x) if self.use_rs else None
+        if x_init is not None:
+            start = _f32c(x_init)
+        alpha = 2. if self.alpha is None else self.alpha                    # :296-299
+        step0 = alpha * self.eps
+        m = self.model
+        if isinstance(m, ClassificationModel) and x.shape[0] > 1 and m.logit_scale \
+                and m.resizer.__class__.__name__ == "function":
+            x_best_adv, x_best, loss_best, acc = m.model.apgd_run(
+                x, start, "ce", m.text_embedding, y, True, self.eps, self.n_iter, step0,
+                train_variant=False, logits_from_head=True, logit_scale=m.logit_scale_value, want_extra=True)
+            return x_best, acc.bool(), loss_best, x_best_adv
+        ce = lambda lg, yy: torch.nn.functional.cross_entropy(lg, yy, reduction='none')   # noqa: E731
+        return _apgd_linf_generic(self.model, ce, x, y, self.eps, self.n_iter, step0, False, x_init=start)
+
+    def perturb(self, x, y=None, best_loss=False, x_init=None):
+        """:param best_loss: if True the points attaining highest loss are returned, otherwise
+        adversarial examples (autopgd_base.py:453-548)."""
+        assert self.loss in ['ce', 'dlr']
+        _require_cuda(x, "x")
+        if y is not None and len(y.shape) == 0:
+            x.unsqueeze_(0)
+            y.unsqueeze_(0)
+        self.init_hyperparam(x)
+        x = x.detach().clone().float().to(self.device)
+        with torch.no_grad():
+            y_pred = self.model(x).max(1)[1]
+        y = y_pred.detach().clone().long().to(self.device) if y is None \
+            else y.detach().clone().long().to(self.device)
+        adv = x.clone()
+        acc = y_pred == y
+        if self.verbose:
+            print('-------------------------- ', 'running {}-attack with epsilon {:.5f}'.format(
+                self.norm, self.eps), '--------------------------')
+            print('initial accuracy: {:.2%}'.format(acc.float().mean()))
+        startt = time.time()
+        if not best_loss:
+            torch.random.manual_seed(self.seed)
+            torch.cuda.random.manual_seed(self.seed)
+            for counter in range(self.n_restarts):
+                ind_to_fool = acc.nonzero().squeeze(1)
+                if ind_to_fool.numel() != 0:
+                    x_to_fool, y_to_fool = x[ind_to_fool].clone(), y[ind_to_fool].clone()
+                    _, acc_curr, _, adv_curr = self.attack_single_run(x_to_fool, y_to_fool)
+                    ind_curr = (acc_curr == 0).nonzero().squeeze(1)
+                    acc[ind_to_fool[ind_curr]] = 0
+                    adv[ind_to_fool[ind_curr]] = adv_curr[ind_curr].clone()
+                    if self.verbose:
+                        print('restart {} - robust accuracy: {:.2%}'.format(counter, acc.float().mean()),
+                              '- cum. time: {:.1f} s'.format(time.time() - startt))
+            return adv
+        adv_best = x.detach().clone()
+        loss_best = torch.ones([x.shape[0]]).to(self.device) * (-float('inf'))
+        for counter in range(self.n_restarts):
+            best_curr, _, loss_curr, _ = self.attack_single_run(x, y)
+            ind_curr = (loss_curr > loss_best).nonzero().squeeze(1)
+            adv_best[ind_curr] = best_curr[ind_curr] + 0.
+            loss_best[ind_curr] = loss_curr[ind_curr] + 0.
+            if self.verbose:
+                print('restart {} - loss: {:.5f}'.format(counter, loss_best.sum()))
+        return adv_best

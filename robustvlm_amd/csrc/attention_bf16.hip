@@ -1,0 +1,430 @@
+// bf16 flash attention forward / backward for CLIP ViTs on gfx950 (head_dim = 64, no mask, no
+// dropout, S = 50 / 257 / 577 tokens), v_mfma_f32_32x32x16_bf16 throughout.
+//
+// One workgroup per (image, head).  A whole head's K and V (S x 64 bf16 = 32 KiB each at S = 257)
+// are LDS-resident, so there is no K/V streaming loop over HBM: every wave owns 32-row tiles and
+// walks the LDS-resident operand in 32-row tiles with an online (running max / sum) softmax.
+//
+// Layout tricks
+//  * LDS tiles are [rows][64] bf16 (128-B rows), 16-B chunk index XOR ((row>>1)&7): ds_read_b128
+//    fragment reads are bank-conflict free.
+//  * "Swapped" products: S^T = K.Q^T puts one query per lane (lane&31), so softmax row statistics are
+//    per-lane scalars and P^T / dS^T are already in the B-operand register layout of the next MFMA
+//    (the k index is permuted identically on both operands, so no cross-lane exchange is needed).
+//  * The operand that needs a transpose (V^T in fwd, K^T / Q^T / dO^T in bwd) comes from the same
+//    row-major LDS tile through ds_read_b64_tr_b16 (hardware transpose read, 4 rows x 16 cols per
+//    16-lane group).  USE_TR=false builds the same fragment with scalar LDS reads (validation).
+//
+// Forward also stores lse2[b,h,q] = m + log2(sum) in the log2 domain of (scale*log2e)*q.k for the
+// backward.  Backward = prep (D = rowsum(dO*O)) + dQ kernel (K,V in LDS) + dK/dV kernel (Q,dO in LDS)
+// = 7 tile GEMMs instead of the minimal 5; the attention core is ~8 % of the backward FLOPs.
+#include "kernels.h"
+
+namespace rvlm {
+
+typedef __attribute__((address_space(3))) char lds_char;
+
+__device__ __forceinline__ int swz_off(int row, int chunk) {  // byte offset inside a [rows][64] bf16 tile
+    return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+// cooperative stage of rows [0,Sp) x 64 bf16 from global (row stride ld elements) into a swizzled tile;
+// rows >= S are zero-filled.
+__device__ __forceinline__ void stage_tile(char* tile, const bf16_t* src, long ld, int S, int Sp,
+                                           int tid, int nthreads) {
+    for (int idx = tid; idx < Sp * 8; idx += nthreads) {
+        const int r = idx >> 3, c = idx & 7;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r < S) v = *(const uint4*)(src + (long)r * ld + c * 8);
+        *(uint4*)(tile + swz_off(r, c)) = v;
+    }
+}
+
+// A/B operand fragment with k along the 64-wide (contiguous) dim: row = row0 + lane&31, k-chunk kk
+__device__ __forceinline__ bf16x8 frag_rowmajor(const char* tile, int row0, int kk, int lane) {
+    const int row = row0 + (lane & 31);
+    return *(const bf16x8*)(tile + swz_off(row, kk * 2 + (lane >> 5)));
+}
+__device__ __forceinline__ bf16x8 frag_global(const bf16_t* src, long ld, int row, int kk, int lane) {
+    return *(const bf16x8*)(src + (long)row * ld + (kk * 2 + (lane >> 5)) * 8);
+}
+
+// Transposed fragment X^T: MFMA row index = column (dt*32 + lane&31) of the LDS tile, k index t'
+// (0..7) <-> tile row  rowbase + 4*hi + (t'&3) + 8*(t'>>2)   (the permutation pack_b() uses).
+template <bool USE_TR>
+__device__ __forceinline__ bf16x8 frag_transposed(const char* tile, int rowbase, int dt, int lane) {
+    const int hi = lane >> 5;
+    bf16x8 out;
+    if (USE_TR) {
+        const int i = lane & 15, dblk = (lane >> 4) & 1;
+        const int chunk = dt * 4 + dblk * 2 + ((i & 3) >> 1);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int row = rowbase + 4 * hi + 8 * r + (i >> 2);
+            const int off = swz_off(row, chunk) + (i & 1) * 8;
+            bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                (__attribute__((address_space(3))) bf16x4*)((lds_char*)tile + off));
+            out[4 * r + 0] = v[0]; out[4 * r + 1] = v[1]; out[4 * r + 2] = v[2]; out[4 * r + 3] = v[3];
+        }
+    } else {
+        const int col = dt * 32 + (lane & 31);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int row = rowbase + 4 * hi + (t & 3) + 8 * (t >> 2);
+            out[t] = *(const bf16_t*)(tile + swz_off(row, col >> 3) + (col & 7) * 2);
+        }
+    }
+    return out;
+}
+
+// accumulator (D layout: row = (reg&3)+8*(reg>>2)+4*hi) -> B operand for k-slice ks (16 rows)
+__device__ __forceinline__ bf16x8 pack_b(const f32x16& p, int ks) {
+    bf16x8 o;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        o[t] = (bf16_t)p[(2 * ks) * 4 + t];
+        o[4 + t] = (bf16_t)p[(2 * ks + 1) * 4 + t];
+    }
+    return o;
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) z[e] = 0.0f;
+    return z;
+}
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+
+// =============================================================================================
+// forward
+// =============================================================================================
+template <bool USE_TR>
+__global__ void __launch_bounds__(256)
+attn_fwd_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict__ o, long ldo,
+                float* __restrict__ lse2, int H, int S, int Sp, int W, float scale_log2) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Kt = smem;
+    char* Vt = smem + (size_t)Sp * 128;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const bf16_t* base = qkv + (long)b * S * ld + h * 64;
+    stage_tile(Kt, base + W, ld, S, Sp, tid, blockDim.x);
+    stage_tile(Vt, base + 2 * W, ld, S, Sp, tid, blockDim.x);
+    __syncthreads();
+
+    const int ntiles = Sp / 32;
+    for (int qt = w; qt < ntiles; qt += nw) {
+        const int q = qt * 32 + l31;
+        const int qc = min(q, S - 1);
+        bf16x8 qf[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) qf[kk] = frag_global(base, ld, qc, kk, lane);
+        f32x16 oacc[2] = {zero16(), zero16()};
+        float m = -INFINITY, l = 0.0f;
+        for (int kt = 0; kt < ntiles; ++kt) {
+            f32x16 s = zero16();
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) s = MFMA(frag_rowmajor(Kt, kt * 32, kk, lane), qf[kk], s);
+            const bool tail = (kt * 32 + 32 > S);
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float t = s[r] * scale_log2;
+                if (tail) {
+                    const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (key >= S) t = -INFINITY;
+                }
+                s[r] = t;
+                tmax = fmaxf(tmax, t);
+            }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float mnew = fmaxf(m, tmax);
+            const float alpha = exp2f(m - mnew);
+            float psum = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = exp2f(s[r] - mnew); psum += s[r]; }
+            l = l * alpha + psum;
+            m = mnew;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 pb = pack_b(s, ks);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+                    oacc[dt] = MFMA(frag_transposed<USE_TR>(Vt, kt * 32 + ks * 16, dt, lane), pb, oacc[dt]);
+            }
+        }
+        const float ltot = l + __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / ltot;
+        if (q < S) {
+            bf16_t* orow = o + ((long)b * S + q) * ldo + h * 64;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bf16x4 ov;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ov[e] = (bf16_t)(oacc[dt][g * 4 + e] * inv);
+                    *(bf16x4*)(orow + dt * 32 + 8 * g + 4 * hi) = ov;
+                }
+            if (hi == 0 && lse2) lse2[((long)b * H + h) * Sp + q] = m + log2f(ltot);
+        }
+    }
+}
+
+// =============================================================================================
+// backward prep: D[b,h,q] = sum_d dO[q,d] * O[q,d]
+// =============================================================================================
+__global__ void __launch_bounds__(256)
+attn_bwd_prep_kernel(const bf16_t* __restrict__ o, long ldo, const bf16_t* __restrict__ d_o, long lddo,
+                     float* __restrict__ dsum, int H, int S, int Sp) {
+    const long tok = blockIdx.x;  // b*S + q
+    const int b = (int)(tok / S), q = (int)(tok % S);
+    const int lane = threadIdx.x & 63;
+    for (int h = threadIdx.x >> 6; h < H; h += 4) {
+        const float a = (float)o[tok * ldo + h * 64 + lane];
+        const float g = (float)d_o[tok * lddo + h * 64 + lane];
+        const float v = wave_sum(a * g);
+        if (lane == 0) dsum[((long)b * H + h) * Sp + q] = v;
+    }
+}
+
+// =============================================================================================
+// backward dQ: wave owns a query tile, K and V LDS-resident
+// =============================================================================================
+template <bool USE_TR>
+__global__ void __launch_bounds__(256)
+attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __restrict__ d_o, long lddo,
+                   const float* __restrict__ lse2, const float* __restrict__ dsum,
+                   bf16_t* __restrict__ dqkv, long lddq, int H, int S, int Sp, int W, float scale,
+                   float scale_log2) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Kt = smem;
+    char* Vt = smem + (size_t)Sp * 128;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const bf16_t* base = qkv + (long)b * S * ld + h * 64;
+    stage_tile(Kt, base + W, ld, S, Sp, tid, blockDim.x);
+    stage_tile(Vt, base + 2 * W, ld, S, Sp, tid, blockDim.x);
+    __syncthreads();
+
+    const int ntiles = Sp / 32;
+    for (int qt = w; qt < ntiles; qt += nw) {
+        const int q = qt * 32 + l31;
+        const int qc = min(q, S - 1);
+        bf16x8 qf[4], dof[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            qf[kk] = frag_global(base, ld, qc, kk, lane);
+            dof[kk] = frag_global(d_o + (long)b * S * lddo + h * 64, lddo, qc, kk, lane);
+        }
+        const float lq = lse2[((long)b * H + h) * Sp + qc];
+        const float dq_sum = dsum[((long)b * H + h) * Sp + qc];
+        f32x16 acc[2] = {zero16(), zero16()};
+        for (int kt = 0; kt < ntiles; ++kt) {
+            f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                s = MFMA(frag_rowmajor(Kt, kt * 32, kk, lane), qf[kk], s);
+                dp = MFMA(frag_rowmajor(Vt, kt * 32, kk, lane), dof[kk], dp);
+            }
+            const bool tail = (kt * 32 + 32 > S);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float p = exp2f(s[r] * scale_log2 - lq);
+                if (tail) {
+                    const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (key >= S) p = 0.0f;
+                }
+                s[r] = p * (dp[r] - dq_sum);   // dS^T
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 db = pack_b(s, ks);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+                    acc[dt] = MFMA(frag_transposed<USE_TR>(Kt, kt * 32 + ks * 16, dt, lane), db, acc[dt]);
+            }
+        }
+        if (q < S) {
+            bf16_t* drow = dqkv + ((long)b * S + q) * lddq + h * 64;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bf16x4 ov;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ov[e] = (bf16_t)(acc[dt][g * 4 + e] * scale);
+                    *(bf16x4*)(drow + dt * 32 + 8 * g + 4 * hi) = ov;
+                }
+        }
+    }
+}
+
+// =============================================================================================
+// backward dK, dV: wave owns a key tile, Q and dO LDS-resident
+// =============================================================================================
+template <bool USE_TR>
+__global__ void __launch_bounds__(256)
+attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __restrict__ d_o, long lddo,
+                    const float* __restrict__ lse2, const float* __restrict__ dsum,
+                    bf16_t* __restrict__ dqkv, long lddq, int H, int S, int Sp, int W, float scale,
+                    float scale_log2) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Qt = smem;
+    char* Dt = smem + (size_t)Sp * 128;
+    float* Ls = (float*)(smem + (size_t)Sp * 256);
+    float* Ds = Ls + Sp;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const bf16_t* base = qkv + (long)b * S * ld + h * 64;
+    stage_tile(Qt, base, ld, S, Sp, tid, blockDim.x);
+    stage_tile(Dt, d_o + (long)b * S * lddo + h * 64, lddo, S, Sp, tid, blockDim.x);
+    for (int i = tid; i < Sp; i += blockDim.x) {
+        Ls[i] = (i < S) ? lse2[((long)b * H + h) * Sp + i] : INFINITY;   // pad rows -> p = 0
+        Ds[i] = (i < S) ? dsum[((long)b * H + h) * Sp + i] : 0.0f;
+    }
+    __syncthreads();
+
+    const int ntiles = Sp / 32;
+    for (int kt = w; kt < ntiles; kt += nw) {
+        const int key = kt * 32 + l31;
+        const int kc = min(key, S - 1);
+        bf16x8 kf[4], vf[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            kf[kk] = frag_global(base + W, ld, kc, kk, lane);
+            vf[kk] = frag_global(base + 2 * W, ld, kc, kk, lane);
+        }
+        f32x16 dk[2] = {zero16(), zero16()}, dv[2] = {zero16(), zero16()};
+        for (int qt = 0; qt < ntiles; ++qt) {
+            f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                s = MFMA(frag_rowmajor(Qt, qt * 32, kk, lane), kf[kk], s);     // S[q][key]
+                dp = MFMA(frag_rowmajor(Dt, qt * 32, kk, lane), vf[kk], dp);   // dP[q][key]
+            }
+            f32x16 ds;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 lq = *(const float4*)(Ls + qt * 32 + 8 * g + 4 * hi);
+                const float4 dq = *(const float4*)(Ds + qt * 32 + 8 * g + 4 * hi);
+                const float lqa[4] = {lq.x, lq.y, lq.z, lq.w};
+                const float dqa[4] = {dq.x, dq.y, dq.z, dq.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float p = exp2f(s[g * 4 + e] * scale_log2 - lqa[e]);
+                    s[g * 4 + e] = p;
+                    ds[g * 4 + e] = p * (dp[g * 4 + e] - dqa[e]);
+                }
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 pb = pack_b(s, ks), db = pack_b(ds, ks);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    dv[dt] = MFMA(frag_transposed<USE_TR>(Dt, qt * 32 + ks * 16, dt, lane), pb, dv[dt]);
+                    dk[dt] = MFMA(frag_transposed<USE_TR>(Qt, qt * 32 + ks * 16, dt, lane), db, dk[dt]);
+                }
+            }
+        }
+        if (key < S) {
+            bf16_t* krow = dqkv + ((long)b * S + key) * lddq + W + h * 64;
+            bf16_t* vrow = krow + W;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bf16x4 ok, ov;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        ok[e] = (bf16_t)(dk[dt][g * 4 + e] * scale);
+                        ov[e] = (bf16_t)dv[dt][g * 4 + e];
+                    }
+                    *(bf16x4*)(krow + dt * 32 + 8 * g + 4 * hi) = ok;
+                    *(bf16x4*)(vrow + dt * 32 + 8 * g + 4 * hi) = ov;
+                }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+static bool g_use_tr = true;
+void attn_set_use_tr(int on) { g_use_tr = on != 0; }
+
+static int attn_block_threads(int ntiles) {
+    // 9 tiles (S=257) split evenly over 3 waves; otherwise up to 4 waves
+    if (ntiles % 3 == 0) return 192;
+    if (ntiles >= 4) return 256;
+    return ntiles * 64;
+}
+
+template <typename K>
+static int set_lds(K kernel, size_t bytes) {
+    if (bytes > 160 * 1024) return fail(RVLM_ERR_UNSUPPORTED, "attention: sequence too long for LDS-resident K/V");
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return fail(RVLM_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
+    return RVLM_OK;
+}
+
+int attn_fwd_bf16(const bf16_t* qkv, long ldqkv, bf16_t* o, long ldo, float* lse, int B, int H,
+                  int S, hipStream_t s) {
+    const int Sp = (int)round_up(S, 32), W = H * 64;
+    const size_t lds_bytes = (size_t)Sp * 256;
+    const float sl2 = 0.125f * 1.4426950408889634f;
+    const int nt = attn_block_threads(Sp / 32);
+    int rc;
+    if (g_use_tr) {
+        if ((rc = set_lds(attn_fwd_kernel<true>, lds_bytes))) return rc;
+        hipLaunchKernelGGL((attn_fwd_kernel<true>), dim3(B * H), dim3(nt), lds_bytes, s, qkv, ldqkv, o,
+                           ldo, lse, H, S, Sp, W, sl2);
+    } else {
+        if ((rc = set_lds(attn_fwd_kernel<false>, lds_bytes))) return rc;
+        hipLaunchKernelGGL((attn_fwd_kernel<false>), dim3(B * H), dim3(nt), lds_bytes, s, qkv, ldqkv, o,
+                           ldo, lse, H, S, Sp, W, sl2);
+    }
+    RVLM_CHECK_LAUNCH();
+    return RVLM_OK;
+}
+
+int attn_bwd_bf16(const bf16_t* qkv, long ldqkv, const bf16_t* o, long ldo, const bf16_t* d_o,
+                  long lddo, const float* lse, float* dsum_scratch, bf16_t* dqkv, long lddqkv,
+                  int B, int H, int S, hipStream_t s) {
+    const int Sp = (int)round_up(S, 32), W = H * 64;
+    const float scale = 0.125f, sl2 = 0.125f * 1.4426950408889634f;
+    const int nt = attn_block_threads(Sp / 32);
+    hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(B * S), dim3(256), 0, s, o, ldo, d_o, lddo,
+                       dsum_scratch, H, S, Sp);
+    RVLM_CHECK_LAUNCH();
+    const size_t lds_q = (size_t)Sp * 256, lds_kv = (size_t)Sp * 256 + (size_t)Sp * 8;
+    int rc;
+    if (g_use_tr) {
+        if ((rc = set_lds(attn_bwd_dq_kernel<true>, lds_q))) return rc;
+        if ((rc = set_lds(attn_bwd_dkv_kernel<true>, lds_kv))) return rc;
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<true>), dim3(B * H), dim3(nt), lds_q, s, qkv, ldqkv, d_o,
+                           lddo, lse, dsum_scratch, dqkv, lddqkv, H, S, Sp, W, scale, sl2);
+        RVLM_CHECK_LAUNCH();
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<true>), dim3(B * H), dim3(nt), lds_kv, s, qkv, ldqkv, d_o,
+                           lddo, lse, dsum_scratch, dqkv, lddqkv, H, S, Sp, W, scale, sl2);
+    } else {
+        if ((rc = set_lds(attn_bwd_dq_kernel<false>, lds_q))) return rc;
+        if ((rc = set_lds(attn_bwd_dkv_kernel<false>, lds_kv))) return rc;
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<false>), dim3(B * H), dim3(nt), lds_q, s, qkv, ldqkv, d_o,
+                           lddo, lse, dsum_scratch, dqkv, lddqkv, H, S, Sp, W, scale, sl2);
+        RVLM_CHECK_LAUNCH();
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<false>), dim3(B * H), dim3(nt), lds_kv, s, qkv, ldqkv, d_o,
+                           lddo, lse, dsum_scratch, dqkv, lddqkv, H, S, Sp, W, scale, sl2);
+    }
+    RVLM_CHECK_LAUNCH();
+    return RVLM_OK;
+}
+
+}  // namespace rvlm

@@ -1,0 +1,778 @@
+// The fixed-function "ViT forward + input-gradient" engine and the device-resident PGD / APGD loops.
+//
+// Not an autograd graph: one handle owns the converted weights and a workspace sized for max_batch
+// (MI355X has 288 GB of HBM3E, so every activation the dgrad chain needs is simply kept resident:
+// ~19 GB at ViT-L/14, B=128, bf16), and forward / backward are fixed launch sequences on the caller's
+// stream with no host synchronisation.  Only the INPUT gradient is produced (no wgrad, no saved
+// linear inputs), exactly what torch.autograd.grad(loss, perturbation) asks for in
+// train/pgd_train.py:38 and train/apgd_train.py:185,295.
+#include <vector>
+#include <cstring>
+#include <map>
+
+#include "kernels.h"
+
+namespace rvlm {
+void attn_set_use_tr(int on);
+
+struct Layer {
+    float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *b_in, *b_out, *b_fc, *b_proj;
+    float *w_in, *w_out, *w_fc, *w_proj;                          // fp32 mode (reference layout)
+    bf16_t *w_in_nk, *w_in_t, *w_out_nk, *w_out_t, *w_fc_nk, *w_fc_t, *w_proj_nk, *w_proj_t;  // bf16
+};
+
+struct ProfRec { int cls; hipEvent_t a, b; };
+struct ProfAcc { double ms = 0, flops = 0, bytes = 0; int64_t n = 0; };
+
+}  // namespace rvlm
+
+using namespace rvlm;
+
+struct rvlm_vit {
+    rvlm_vit_config cfg;
+    int S, G, W, L, H, D, P, img, Kp, Kpad, maxB, Mp, Mp0;
+    bool bf16;
+    size_t esz;  // activation element size
+    std::vector<Layer> layers;
+    float *cls, *pos, *proj, *lnpre_w, *lnpre_b, *lnpost_w, *lnpost_b, *conv_f32;
+    bf16_t *conv_nk, *conv_t;
+    // activations
+    void* A0;            // [Mp0, Kpad] T
+    float* patch_out;    // [Mp0, W] f32
+    std::vector<float*> xs;      // 2L+1 x [Mp, W] f32 residual stream
+    float *st_mean, *st_rstd;    // [(2L+2) * Mp]
+    void* ln_out;        // [Mp, W] T
+    std::vector<void*> qkv;      // L x [Mp, 3W] T
+    std::vector<void*> attn_o;   // L x [Mp, W] T
+    std::vector<float*> lse;     // L x [B*H*Sp]
+    std::vector<void*> h_pre;    // L x [Mp, 4W] T
+    void* g_act;         // [Mp, 4W] T
+    float *pooled, *emb_raw, *inv_norm;   // [maxB, W], [maxB, D], [maxB]
+    // backward scratch
+    float* dres;  void* dres_lp;  void* d_o;  void* dqkv;  void* dh;  void* d_ln;  void* d_patch;
+    float* dA0;   float* dsum;   float *d_raw, *d_pooled;
+    float *scores, *dscores;   // fp32 mode [B,H,S,S]
+    // attack state
+    float* img_buf[5];         // [maxB*3*img*img]
+    float *emb, *d_emb, *loss_ps, *loss_scalar, *loss_scratch;
+    float *ap_loss_steps, *ap_loss_best, *ap_loss_best_lc, *ap_reduced_lc, *ap_step;
+    uint8_t *ap_acc, *ap_pred, *ap_f0, *ap_f1, *ap_f2;
+    size_t loss_scratch_floats;
+    // bookkeeping
+    std::vector<void*> allocs;
+    size_t bytes = 0;
+    int saved_B = 0;
+    bool saved_norm = false;
+    // profiling
+    bool prof = false;
+    std::vector<ProfRec> recs;
+    std::vector<std::string> cls_names;
+    std::vector<ProfAcc> accs;
+    std::vector<double> cls_flops, cls_bytes;
+
+    float* mean_at(int i) { return st_mean + (size_t)i * Mp; }
+    float* rstd_at(int i) { return st_rstd + (size_t)i * Mp; }
+};
+
+namespace rvlm {
+
+static int dev_alloc(rvlm_vit* h, void** p, size_t bytes, bool zero = true) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) return fail(RVLM_ERR_HIP, std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e));
+    if (zero) {
+        e = hipMemset(*p, 0, bytes);
+        if (e != hipSuccess) return fail(RVLM_ERR_HIP, std::string("hipMemset: ") + hipGetErrorString(e));
+    }
+    h->allocs.push_back(*p);
+    h->bytes += bytes;
+    return RVLM_OK;
+}
+#define ALLOC(ptr, bytes)                                              \
+    do { int _rc = dev_alloc(h, (void**)&(ptr), (bytes)); if (_rc) return _rc; } while (0)
+
+// ---- profiling ------------------------------------------------------------------------------
+static int prof_class(rvlm_vit* h, const char* name) {
+    for (size_t i = 0; i < h->cls_names.size(); ++i) if (h->cls_names[i] == name) return (int)i;
+    h->cls_names.push_back(name);
+    h->accs.emplace_back();
+    return (int)h->cls_names.size() - 1;
+}
+struct ProfScope {
+    rvlm_vit* h; hipStream_t s; int idx = -1;
+    ProfScope(rvlm_vit* h_, hipStream_t s_, const char* name, double flops, double bytes) : h(h_), s(s_) {
+        if (!h->prof) return;
+        ProfRec r;
+        r.cls = prof_class(h, name);
+        hipEventCreate(&r.a); hipEventCreate(&r.b);
+        hipEventRecord(r.a, s);
+        h->recs.push_back(r);
+        idx = (int)h->recs.size() - 1;
+        h->accs[r.cls].flops += flops;
+        h->accs[r.cls].bytes += bytes;
+        h->accs[r.cls].n += 1;
+    }
+    ~ProfScope() { if (idx >= 0) hipEventRecord(h->recs[idx].b, s); }
+};
+#define PROF(name, flops, bytes) ProfScope _ps(h, s, name, (double)(flops), (double)(bytes))
+
+// ---- weights --------------------------------------------------------------------------------
+static int copy_f32(rvlm_vit* h, float** dst, const float* src, size_t n, hipStream_t s, bool alloc) {
+    if (!src) return fail(RVLM_ERR_ARG, "rvlm_vit: null weight pointer");
+    if (alloc) { int rc = dev_alloc(h, (void**)dst, n * 4, false); if (rc) return rc; }
+    RVLM_HIP(hipMemcpyAsync(*dst, src, n * 4, hipMemcpyDeviceToDevice, s));
+    return RVLM_OK;
+}
+// nk: [rows, cols] bf16 (ld = cols_pad) ; t: [cols, rows] bf16
+static int conv_w(rvlm_vit* h, bf16_t** nk, bf16_t** t, const float* src, int rows, int cols, int cols_pad,
+                  hipStream_t s, bool alloc) {
+    if (!src) return fail(RVLM_ERR_ARG, "rvlm_vit: null weight pointer");
+    if (alloc) {
+        int rc = dev_alloc(h, (void**)nk, (size_t)rows * cols_pad * 2); if (rc) return rc;
+        rc = dev_alloc(h, (void**)t, (size_t)cols_pad * rows * 2); if (rc) return rc;
+    }
+    int rc = convert_f32_to_bf16(src, cols, *nk, cols_pad, rows, cols, 0, s); if (rc) return rc;
+    return convert_f32_to_bf16(src, cols, *t, rows, rows, cols, 1, s);
+}
+
+static int load_weights(rvlm_vit* h, const rvlm_vit_weights* w, hipStream_t s, bool alloc) {
+    const int W = h->W, L = h->L;
+    int rc;
+#define CP(dst, src, n) if ((rc = copy_f32(h, &(dst), (src), (n), s, alloc))) return rc
+    CP(h->cls, w->class_embedding, W);
+    CP(h->pos, w->positional_embedding, (size_t)h->S * W);
+    CP(h->proj, w->proj, (size_t)W * h->D);
+    CP(h->lnpre_w, w->ln_pre_weight, W); CP(h->lnpre_b, w->ln_pre_bias, W);
+    CP(h->lnpost_w, w->ln_post_weight, W); CP(h->lnpost_b, w->ln_post_bias, W);
+    if (h->bf16) {
+        if ((rc = conv_w(h, &h->conv_nk, &h->conv_t, w->conv1_weight, W, h->Kp, h->Kpad, s, alloc))) return rc;
+    } else {
+        CP(h->conv_f32, w->conv1_weight, (size_t)W * h->Kp);
+    }
+    if (!w->blocks_host) return fail(RVLM_ERR_ARG, "rvlm_vit: blocks_host is null");
+    for (int l = 0; l < L; ++l) {
+        const rvlm_vit_block_weights& b = w->blocks_host[l];
+        Layer& y = h->layers[l];
+        CP(y.ln1_w, b.ln_1_weight, W); CP(y.ln1_b, b.ln_1_bias, W);
+        CP(y.ln2_w, b.ln_2_weight, W); CP(y.ln2_b, b.ln_2_bias, W);
+        CP(y.b_in, b.attn_in_proj_bias, 3 * W); CP(y.b_out, b.attn_out_proj_bias, W);
+        CP(y.b_fc, b.mlp_c_fc_bias, 4 * W); CP(y.b_proj, b.mlp_c_proj_bias, W);
+        if (h->bf16) {
+            if ((rc = conv_w(h, &y.w_in_nk, &y.w_in_t, b.attn_in_proj_weight, 3 * W, W, W, s, alloc))) return rc;
+            if ((rc = conv_w(h, &y.w_out_nk, &y.w_out_t, b.attn_out_proj_weight, W, W, W, s, alloc))) return rc;
+            if ((rc = conv_w(h, &y.w_fc_nk, &y.w_fc_t, b.mlp_c_fc_weight, 4 * W, W, W, s, alloc))) return rc;
+            if ((rc = conv_w(h, &y.w_proj_nk, &y.w_proj_t, b.mlp_c_proj_weight, W, 4 * W, 4 * W, s, alloc))) return rc;
+        } else {
+            CP(y.w_in, b.attn_in_proj_weight, (size_t)3 * W * W);
+            CP(y.w_out, b.attn_out_proj_weight, (size_t)W * W);
+            CP(y.w_fc, b.mlp_c_fc_weight, (size_t)4 * W * W);
+            CP(y.w_proj, b.mlp_c_proj_weight, (size_t)4 * W * W);
+        }
+    }
+#undef CP
+    return RVLM_OK;
+}
+
+// ---- linear layers (dispatch on precision) ---------------------------------------------------
+// forward: out[M,N] = epi(A[M,K] @ Wt[N,K]^T + bias)
+template <typename T>
+static int linear_fwd(rvlm_vit* h, hipStream_t s, const void* A, long lda, int M, int N, int K,
+                      const float* w_f32, const bf16_t* w_nk, const float* bias, int epi, void* out, long ldo,
+                      void* out_pre, const float* residual);
+template <>
+int linear_fwd<bf16_t>(rvlm_vit* h, hipStream_t s, const void* A, long lda, int M, int N, int K,
+                       const float*, const bf16_t* w_nk, const float* bias, int epi, void* out, long ldo,
+                       void* out_pre, const float* residual) {
+    GemmBf16 g;
+    g.A = (const bf16_t*)A; g.lda = lda; g.Bw = w_nk; g.ldb = K; g.M = M; g.N = N; g.K = K;
+    g.a_rows = (int)round_up(M, 128); g.epi = epi; g.bias = bias; g.out = out; g.ldo = ldo;
+    g.out_pre = (bf16_t*)out_pre; g.residual = residual; g.act = h->cfg.act;
+    return gemm_bf16_nt(g, s);
+}
+template <>
+int linear_fwd<float>(rvlm_vit* h, hipStream_t s, const void* A, long lda, int M, int N, int K,
+                      const float* w_f32, const bf16_t*, const float* bias, int epi, void* out, long ldo,
+                      void* out_pre, const float* residual) {
+    GemmF32 g;
+    g.A = (const float*)A; g.sam = lda; g.sak = 1;
+    g.B = w_f32; g.sbn = K; g.sbk = 1;
+    g.C = (float*)out; g.scm = ldo; g.scn = 1;
+    g.M = M; g.N = N; g.K = K; g.bias = bias; g.residual = residual;
+    if (epi == EPI_BF16_ACT) { g.act = h->cfg.act; g.C_pre = (float*)out_pre; }
+    return gemm_f32(g, s);
+}
+// dgrad: out[M,K] = epi(dY[M,N] @ W[N,K])   (w_t = W^T stored [K,N] for the bf16 path)
+template <typename T>
+static int linear_dgrad(rvlm_vit* h, hipStream_t s, const void* dY, long lddy, int M, int N, int K,
+                        const float* w_f32, long ldw, const bf16_t* w_t, int epi, void* out, long ldo,
+                        const void* h_pre);
+template <>
+int linear_dgrad<bf16_t>(rvlm_vit* h, hipStream_t s, const void* dY, long lddy, int M, int N, int K,
+                         const float*, long, const bf16_t* w_t, int epi, void* out, long ldo,
+                         const void* h_pre) {
+    GemmBf16 g;
+    g.A = (const bf16_t*)dY; g.lda = lddy; g.Bw = w_t; g.ldb = N; g.M = M; g.N = K; g.K = N;
+    g.a_rows = (int)round_up(M, 128); g.epi = epi; g.out = out; g.ldo = ldo;
+    g.h_pre = (const bf16_t*)h_pre; g.act = h->cfg.act;
+    return gemm_bf16_nt(g, s);
+}
+template <>
+int linear_dgrad<float>(rvlm_vit* h, hipStream_t s, const void* dY, long lddy, int M, int N, int K,
+                        const float* w_f32, long ldw, const bf16_t*, int epi, void* out, long ldo,
+                        const void* h_pre) {
+    GemmF32 g;
+    g.A = (const float*)dY; g.sam = lddy; g.sak = 1;
+    g.B = w_f32; g.sbn = 1; g.sbk = ldw;          // (n = k_out, k = n_in) at n_in*ldw + k_out
+    g.C = (float*)out; g.scm = ldo; g.scn = 1;
+    g.M = M; g.N = K; g.K = N;
+    if (epi == EPI_BF16_DACT) { g.dact_h = (const float*)h_pre; g.dact_kind = h->cfg.act; }
+    return gemm_f32(g, s);
+}
+
+// ---- attention (dispatch on precision) -------------------------------------------------------
+template <typename T>
+static int attention_fwd(rvlm_vit* h, hipStream_t s, const void* qkv, void* o, float* lse, int B);
+template <>
+int attention_fwd<bf16_t>(rvlm_vit* h, hipStream_t s, const void* qkv, void* o, float* lse, int B) {
+    return attn_fwd_bf16((const bf16_t*)qkv, 3 * h->W, (bf16_t*)o, h->W, lse, B, h->H, h->S, s);
+}
+static int attn_scores_f32(rvlm_vit* h, hipStream_t s, const float* qkv, int B) {
+    const int S = h->S, W = h->W, H = h->H;
+    GemmF32 g;  // scores = 0.125 * Q K^T
+    g.A = qkv; g.sam = 3 * W; g.sak = 1; g.sab1 = (long)S * 3 * W; g.sab2 = 64;
+    g.B = qkv + W; g.sbn = 3 * W; g.sbk = 1; g.sbb1 = (long)S * 3 * W; g.sbb2 = 64;
+    g.C = h->scores; g.scm = S; g.scn = 1; g.scb1 = (long)H * S * S; g.scb2 = (long)S * S;
+    g.M = S; g.N = S; g.K = 64; g.nb1 = B; g.nb2 = H; g.alpha = 0.125f;
+    int rc = gemm_f32(g, s); if (rc) return rc;
+    return softmax_rows_fwd(h->scores, (long)B * H * S, S, s);
+}
+template <>
+int attention_fwd<float>(rvlm_vit* h, hipStream_t s, const void* qkv_, void* o, float*, int B) {
+    const int S = h->S, W = h->W, H = h->H;
+    const float* qkv = (const float*)qkv_;
+    int rc = attn_scores_f32(h, s, qkv, B); if (rc) return rc;
+    GemmF32 g;  // O = P V
+    g.A = h->scores; g.sam = S; g.sak = 1; g.sab1 = (long)H * S * S; g.sab2 = (long)S * S;
+    g.B = qkv + 2 * W; g.sbn = 1; g.sbk = 3 * W; g.sbb1 = (long)S * 3 * W; g.sbb2 = 64;
+    g.C = (float*)o; g.scm = W; g.scn = 1; g.scb1 = (long)S * W; g.scb2 = 64;
+    g.M = S; g.N = 64; g.K = S; g.nb1 = B; g.nb2 = H;
+    return gemm_f32(g, s);
+}
+template <typename T>
+static int attention_bwd(rvlm_vit* h, hipStream_t s, const void* qkv, const void* o, const void* d_o,
+                         const float* lse, void* dqkv, int B);
+template <>
+int attention_bwd<bf16_t>(rvlm_vit* h, hipStream_t s, const void* qkv, const void* o, const void* d_o,
+                          const float* lse, void* dqkv, int B) {
+    return attn_bwd_bf16((const bf16_t*)qkv, 3 * h->W, (const bf16_t*)o, h->W, (const bf16_t*)d_o, h->W,
+                         lse, h->dsum, (bf16_t*)dqkv, 3 * h->W, B, h->H, h->S, s);
+}
+template <>
+int attention_bwd<float>(rvlm_vit* h, hipStream_t s, const void* qkv_, const void*, const void* d_o_,
+                         const float*, void* dqkv_, int B) {
+    const int S = h->S, W = h->W, H = h->H;
+    const float* qkv = (const float*)qkv_;
+    const float* d_o = (const float*)d_o_;
+    float* dqkv = (float*)dqkv_;
+    int rc = attn_scores_f32(h, s, qkv, B); if (rc) return rc;  // recompute P
+    const long bs1 = (long)H * S * S, bs2 = (long)S * S, qs1 = (long)S * 3 * W, os1 = (long)S * W;
+    GemmF32 g;  // dP = dO V^T
+    g.A = d_o; g.sam = W; g.sak = 1; g.sab1 = os1; g.sab2 = 64;
+    g.B = qkv + 2 * W; g.sbn = 3 * W; g.sbk = 1; g.sbb1 = qs1; g.sbb2 = 64;
+    g.C = h->dscores; g.scm = S; g.scn = 1; g.scb1 = bs1; g.scb2 = bs2;
+    g.M = S; g.N = S; g.K = 64; g.nb1 = B; g.nb2 = H;
+    if ((rc = gemm_f32(g, s))) return rc;
+    if ((rc = softmax_rows_bwd(h->scores, h->dscores, (long)B * H * S, S, 0.125f, s))) return rc;
+    GemmF32 q;  // dQ = dS K
+    q.A = h->dscores; q.sam = S; q.sak = 1; q.sab1 = bs1; q.sab2 = bs2;
+    q.B = qkv + W; q.sbn = 1; q.sbk = 3 * W; q.sbb1 = qs1; q.sbb2 = 64;
+    q.C = dqkv; q.scm = 3 * W; q.scn = 1; q.scb1 = qs1; q.scb2 = 64;
+    q.M = S; q.N = 64; q.K = S; q.nb1 = B; q.nb2 = H;
+    if ((rc = gemm_f32(q, s))) return rc;
+    GemmF32 k;  // dK = dS^T Q
+    k.A = h->dscores; k.sam = 1; k.sak = S; k.sab1 = bs1; k.sab2 = bs2;
+    k.B = qkv; k.sbn = 1; k.sbk = 3 * W; k.sbb1 = qs1; k.sbb2 = 64;
+    k.C = dqkv + W; k.scm = 3 * W; k.scn = 1; k.scb1 = qs1; k.scb2 = 64;
+    k.M = S; k.N = 64; k.K = S; k.nb1 = B; k.nb2 = H;
+    if ((rc = gemm_f32(k, s))) return rc;
+    GemmF32 v;  // dV = P^T dO
+    v.A = h->scores; v.sam = 1; v.sak = S; v.sab1 = bs1; v.sab2 = bs2;
+    v.B = d_o; v.sbn = 1; v.sbk = W; v.sbb1 = os1; v.sbb2 = 64;
+    v.C = dqkv + 2 * W; v.scm = 3 * W; v.scn = 1; v.scb1 = qs1; v.scb2 = 64;
+    v.M = S; v.N = 64; v.K = S; v.nb1 = B; v.nb2 = H;
+    return gemm_f32(v, s);
+}
+
+// ---- forward -----------------------------------------------------------------------------------
+template <typename T>
+static int forward_impl(rvlm_vit* h, const float* x, const float* delta, int B, int normalize, int save,
+                        float* out_emb, hipStream_t s) {
+    const int S = h->S, W = h->W, L = h->L, D = h->D, M = B * S, M0 = B * h->G * h->G;
+    const double attn_flops = 4.0 * B * h->H * (double)S * S * 64;
+    int rc;
+    {
+        PROF("patch_im2col", 0, (double)B * 3 * h->img * h->img * (delta ? 8 : 4) + (double)M0 * h->Kpad * sizeof(T));
+        if ((rc = im2col_normalize<T>(x, delta, B, h->img, h->P, h->cfg.mean, h->cfg.std, (T*)h->A0, h->Kpad, h->Kpad, s))) return rc;
+    }
+    {
+        PROF("gemm_patch_fwd", 2.0 * M0 * W * h->Kp, 0);
+        if (h->bf16) {
+            GemmBf16 g;
+            g.A = (const bf16_t*)h->A0; g.lda = h->Kpad; g.Bw = h->conv_nk; g.ldb = h->Kpad;
+            g.M = M0; g.N = W; g.K = h->Kpad; g.a_rows = h->Mp0; g.epi = EPI_F32; g.out = h->patch_out; g.ldo = W;
+            rc = gemm_bf16_nt(g, s);
+        } else {
+            rc = linear_fwd<float>(h, s, h->A0, h->Kpad, M0, W, h->Kp, h->conv_f32, nullptr, nullptr, EPI_F32,
+                                   h->patch_out, W, nullptr, nullptr);
+        }
+        if (rc) return rc;
+    }
+    auto XS = [&](int i) { return h->xs[save ? i : 0]; };
+    {
+        PROF("embed_lnpre_fwd", 0, (double)M * W * 8);
+        if ((rc = embed_lnpre_fwd<float>(h->patch_out, W, h->cls, h->pos, h->lnpre_w, h->lnpre_b, XS(0), W,
+                                         h->mean_at(0), h->rstd_at(0), B, S, W, s))) return rc;
+    }
+    for (int l = 0; l < L; ++l) {
+        Layer& y = h->layers[l];
+        const int sl = save ? l : 0;
+        float* x_in = XS(2 * l); float* x_mid = XS(2 * l + 1); float* x_out = XS(2 * l + 2);
+        {
+            PROF("layernorm_fwd", 0, (double)M * W * (4 + sizeof(T)));
+            if ((rc = layernorm_fwd<T>(x_in, W, y.ln1_w, y.ln1_b, (T*)h->ln_out, W, h->mean_at(1 + 2 * l),
+                                       h->rstd_at(1 + 2 * l), M, W, s))) return rc;
+        }
+        {
+            PROF("gemm_qkv_fwd", 2.0 * M * W * 3 * W, 0);
+            if ((rc = linear_fwd<T>(h, s, h->ln_out, W, M, 3 * W, W, y.w_in, y.w_in_nk, y.b_in, EPI_BF16,
+                                    h->qkv[sl], 3 * W, nullptr, nullptr))) return rc;
+        }
+        {
+            PROF("attn_fwd", attn_flops, 0);
+            if ((rc = attention_fwd<T>(h, s, h->qkv[sl], h->attn_o[sl], h->lse[sl], B))) return rc;
+        }
+        {
+            PROF("gemm_out_fwd", 2.0 * M * W * W, 0);
+            if ((rc = linear_fwd<T>(h, s, h->attn_o[sl], W, M, W, W, y.w_out, y.w_out_nk, y.b_out, EPI_F32_RESID,
+                                    x_mid, W, nullptr, x_in))) return rc;
+        }
+        {
+            PROF("layernorm_fwd", 0, (double)M * W * (4 + sizeof(T)));
+            if ((rc = layernorm_fwd<T>(x_mid, W, y.ln2_w, y.ln2_b, (T*)h->ln_out, W, h->mean_at(2 + 2 * l),
+                                       h->rstd_at(2 + 2 * l), M, W, s))) return rc;
+        }
+        {
+            PROF("gemm_fc1_fwd", 2.0 * M * W * 4 * W, 0);
+            if ((rc = linear_fwd<T>(h, s, h->ln_out, W, M, 4 * W, W, y.w_fc, y.w_fc_nk, y.b_fc, EPI_BF16_ACT,
+                                    h->g_act, 4 * W, h->h_pre[sl], nullptr))) return rc;
+        }
+        {
+            PROF("gemm_fc2_fwd", 2.0 * M * W * 4 * W, 0);
+            if ((rc = linear_fwd<T>(h, s, h->g_act, 4 * W, M, W, 4 * W, y.w_proj, y.w_proj_nk, y.b_proj,
+                                    EPI_F32_RESID, x_out, W, nullptr, x_mid))) return rc;
+        }
+    }
+    {
+        PROF("head_fwd", 2.0 * B * W * D, 0);
+        float* xf = XS(2 * L);
+        if ((rc = layernorm_fwd<float>(xf, (long)S * W, h->lnpost_w, h->lnpost_b, h->pooled, W,
+                                       h->mean_at(2 * L + 1), h->rstd_at(2 * L + 1), B, W, s))) return rc;
+        GemmF32 g;
+        g.A = h->pooled; g.sam = W; g.sak = 1;
+        g.B = h->proj; g.sbn = 1; g.sbk = D;
+        g.C = normalize ? h->emb_raw : out_emb; g.scm = D; g.scn = 1;
+        g.M = B; g.N = D; g.K = W;
+        if ((rc = gemm_f32(g, s))) return rc;
+        if (normalize) {
+            if ((rc = l2_normalize_fwd(h->emb_raw, out_emb, h->inv_norm, B, D, s))) return rc;
+        }
+    }
+    if (save) { h->saved_B = B; h->saved_norm = normalize != 0; }
+    return RVLM_OK;
+}
+
+// ---- backward (input gradient only) --------------------------------------------------------------
+template <typename T>
+static int backward_impl(rvlm_vit* h, const float* d_emb, int B, float* grad_x, hipStream_t s) {
+    const int S = h->S, W = h->W, L = h->L, D = h->D, M = B * S, M0 = B * h->G * h->G;
+    const double attn_flops = 8.0 * B * h->H * (double)S * S * 64;
+    constexpr bool LP = !std::is_same<T, float>::value;
+    int rc;
+    {
+        PROF("head_bwd", 2.0 * B * W * D, 0);
+        const float* d_raw = d_emb;
+        if (h->saved_norm) {
+            if ((rc = l2_normalize_bwd(d_emb, h->emb_raw, h->inv_norm, h->d_raw, B, D, s))) return rc;
+            d_raw = h->d_raw;
+        }
+        GemmF32 g;  // d_pooled = d_raw @ proj^T
+        g.A = d_raw; g.sam = D; g.sak = 1;
+        g.B = h->proj; g.sbn = D; g.sbk = 1;
+        g.C = h->d_pooled; g.scm = W; g.scn = 1;
+        g.M = B; g.N = W; g.K = D;
+        if ((rc = gemm_f32(g, s))) return rc;
+        RVLM_HIP(hipMemsetAsync(h->dres, 0, (size_t)h->Mp * W * 4, s));
+        if (LP) RVLM_HIP(hipMemsetAsync(h->dres_lp, 0, (size_t)h->Mp * W * sizeof(T), s));
+        if ((rc = layernorm_bwd<float, T>(h->d_pooled, W, h->xs[2 * L], (long)S * W, h->lnpost_w,
+                                          h->mean_at(2 * L + 1), h->rstd_at(2 * L + 1), h->dres, (long)S * W,
+                                          LP ? (T*)h->dres_lp : nullptr, (long)S * W, 0, B, W, s))) return rc;
+    }
+    const void* dres_A = LP ? (const void*)h->dres_lp : (const void*)h->dres;
+    for (int l = L - 1; l >= 0; --l) {
+        Layer& y = h->layers[l];
+        {
+            PROF("gemm_fc2_bwd", 2.0 * M * W * 4 * W, 0);
+            if ((rc = linear_dgrad<T>(h, s, dres_A, W, M, W, 4 * W, y.w_proj, 4 * W, y.w_proj_t, EPI_BF16_DACT,
+                                      h->dh, 4 * W, h->h_pre[l]))) return rc;
+        }
+        {
+            PROF("gemm_fc1_bwd", 2.0 * M * W * 4 * W, 0);
+            if ((rc = linear_dgrad<T>(h, s, h->dh, 4 * W, M, 4 * W, W, y.w_fc, W, y.w_fc_t, EPI_BF16, h->d_ln, W,
+                                      nullptr))) return rc;
+        }
+        {
+            PROF("layernorm_bwd", 0, (double)M * W * (12 + 2 * sizeof(T)));
+            if ((rc = layernorm_bwd<T, T>((const T*)h->d_ln, W, h->xs[2 * l + 1], W, y.ln2_w, h->mean_at(2 + 2 * l),
+                                          h->rstd_at(2 + 2 * l), h->dres, W, LP ? (T*)h->dres_lp : nullptr, W, 1,
+                                          M, W, s))) return rc;
+        }
+        {
+            PROF("gemm_out_bwd", 2.0 * M * W * W, 0);
+            if ((rc = linear_dgrad<T>(h, s, dres_A, W, M, W, W, y.w_out, W, y.w_out_t, EPI_BF16, h->d_o, W,
+                                      nullptr))) return rc;
+        }
+        {
+            PROF("attn_bwd", attn_flops, 0);
+            if ((rc = attention_bwd<T>(h, s, h->qkv[l], h->attn_o[l], h->d_o, h->lse[l], h->dqkv, B))) return rc;
+        }
+        {
+            PROF("gemm_qkv_bwd", 2.0 * M * W * 3 * W, 0);
+            if ((rc = linear_dgrad<T>(h, s, h->dqkv, 3 * W, M, 3 * W, W, y.w_in, W, y.w_in_t, EPI_BF16, h->d_ln, W,
+                                      nullptr))) return rc;
+        }
+        {
+            PROF("layernorm_bwd", 0, (double)M * W * (12 + 2 * sizeof(T)));
+            if ((rc = layernorm_bwd<T, T>((const T*)h->d_ln, W, h->xs[2 * l], W, y.ln1_w, h->mean_at(1 + 2 * l),
+                                          h->rstd_at(1 + 2 * l), h->dres, W, LP ? (T*)h->dres_lp : nullptr, W, 1,
+                                          M, W, s))) return rc;
+        }
+    }
+    {
+        PROF("embed_lnpre_bwd", 0, (double)M * W * 8);
+        if ((rc = embed_lnpre_bwd<T>(h->dres, W, h->patch_out, W, h->cls, h->pos, h->lnpre_w, h->mean_at(0),
+                                     h->rstd_at(0), (T*)h->d_patch, W, B, S, W, s))) return rc;
+    }
+    {
+        PROF("gemm_patch_bwd", 2.0 * M0 * W * h->Kp, 0);
+        if (h->bf16) {
+            GemmBf16 g;
+            g.A = (const bf16_t*)h->d_patch; g.lda = W; g.Bw = h->conv_t; g.ldb = W;
+            g.M = M0; g.N = h->Kpad; g.K = W; g.a_rows = h->Mp0; g.epi = EPI_F32; g.out = h->dA0; g.ldo = h->Kpad;
+            rc = gemm_bf16_nt(g, s);
+        } else {
+            GemmF32 g;
+            g.A = (const float*)h->d_patch; g.sam = W; g.sak = 1;
+            g.B = h->conv_f32; g.sbn = 1; g.sbk = h->Kp;
+            g.C = h->dA0; g.scm = h->Kpad; g.scn = 1;
+            g.M = M0; g.N = h->Kp; g.K = W;
+            rc = gemm_f32(g, s);
+        }
+        if (rc) return rc;
+    }
+    {
+        PROF("patch_col2im", 0, (double)B * 3 * h->img * h->img * 8);
+        if ((rc = col2im_grad<float>(h->dA0, h->Kpad, B, h->img, h->P, h->cfg.std, grad_x, s))) return rc;
+    }
+    return RVLM_OK;
+}
+
+static int vit_forward(rvlm_vit* h, const float* x, const float* delta, int B, int normalize, int save,
+                       float* out_emb, hipStream_t s) {
+    return h->bf16 ? forward_impl<bf16_t>(h, x, delta, B, normalize, save, out_emb, s)
+                   : forward_impl<float>(h, x, delta, B, normalize, save, out_emb, s);
+}
+static int vit_backward(rvlm_vit* h, const float* d_emb, int B, float* grad_x, hipStream_t s) {
+    return h->bf16 ? backward_impl<bf16_t>(h, d_emb, B, grad_x, s) : backward_impl<float>(h, d_emb, B, grad_x, s);
+}
+
+__global__ void __launch_bounds__(256)
+add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = a[i] + (b ? b[i] : 0.0f);
+}
+__global__ void __launch_bounds__(256)
+clamp01_kernel(const float* __restrict__ a, float* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = fminf(fmaxf(a[i], 0.0f), 1.0f);
+}
+__global__ void init_apgd_state_kernel(int B, const float* loss0, const uint8_t* pred0, float step0,
+                                       float* loss_best, float* loss_best_lc, float* reduced_lc, float* step,
+                                       uint8_t* acc) {
+    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
+        loss_best[b] = loss0[b]; loss_best_lc[b] = loss0[b]; reduced_lc[b] = 1.0f; step[b] = step0;
+        acc[b] = pred0[b];
+    }
+}
+static int ew_blocks(size_t n) { size_t b = (n + 1023) / 1024; if (b > 2048) b = 2048; if (b < 1) b = 1; return (int)b; }
+
+}  // namespace rvlm
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" int rvlm_vit_create(const rvlm_vit_config* cfg, const rvlm_vit_weights* weights,
+                               rvlm_stream_t stream, rvlm_vit** out) {
+    RVLM_REQUIRE(cfg && weights && out, "rvlm_vit_create: null argument");
+    RVLM_REQUIRE(cfg->patch > 0 && cfg->image_size % cfg->patch == 0, "rvlm_vit_create: image_size % patch");
+    RVLM_REQUIRE(cfg->heads > 0 && cfg->width == cfg->heads * 64, "rvlm_vit_create: head_dim must be 64");
+    RVLM_REQUIRE(cfg->layers > 0 && cfg->out_dim > 0 && cfg->max_batch > 0, "rvlm_vit_create: sizes");
+    RVLM_REQUIRE(cfg->precision == RVLM_PREC_F32 || cfg->precision == RVLM_PREC_BF16, "rvlm_vit_create: precision");
+    RVLM_REQUIRE(cfg->act == RVLM_ACT_QUICK_GELU || cfg->act == RVLM_ACT_GELU, "rvlm_vit_create: act");
+    RVLM_REQUIRE(cfg->width <= 2048, "rvlm_vit_create: width > 2048 unsupported");
+    hipStream_t s = (hipStream_t)stream;
+    rvlm_vit* h = new rvlm_vit();
+    h->cfg = *cfg;
+    h->bf16 = cfg->precision == RVLM_PREC_BF16;
+    h->esz = h->bf16 ? 2 : 4;
+    h->img = cfg->image_size; h->P = cfg->patch; h->G = h->img / h->P; h->S = h->G * h->G + 1;
+    h->W = cfg->width; h->L = cfg->layers; h->H = cfg->heads; h->D = cfg->out_dim;
+    h->Kp = 3 * h->P * h->P; h->Kpad = (int)round_up(h->Kp, 64);
+    h->maxB = cfg->max_batch;
+    h->Mp = (int)round_up((long)h->maxB * h->S, 256);
+    h->Mp0 = (int)round_up((long)h->maxB * h->G * h->G, 256);
+    h->layers.resize(h->L);
+    const int W = h->W, L = h->L, S = h->S, B = h->maxB, D = h->D;
+    const size_t Mp = h->Mp, Mp0 = h->Mp0, e = h->esz;
+    int rc = load_weights(h, weights, s, true);
+    if (rc) { rvlm_vit_destroy(h); return rc; }
+#define ALLOC_OR_DIE(ptr, bytes) do { rc = dev_alloc(h, (void**)&(ptr), (bytes)); if (rc) { rvlm_vit_destroy(h); return rc; } } while (0)
+    ALLOC_OR_DIE(h->A0, Mp0 * h->Kpad * e);
+    ALLOC_OR_DIE(h->patch_out, Mp0 * W * 4);
+    h->xs.resize(2 * L + 1);
+    for (auto& p : h->xs) ALLOC_OR_DIE(p, Mp * W * 4);
+    ALLOC_OR_DIE(h->st_mean, (size_t)(2 * L + 2) * Mp * 4);
+    ALLOC_OR_DIE(h->st_rstd, (size_t)(2 * L + 2) * Mp * 4);
+    ALLOC_OR_DIE(h->ln_out, Mp * W * e);
+    h->qkv.resize(L); h->attn_o.resize(L); h->lse.resize(L); h->h_pre.resize(L);
+    const size_t Sp = round_up(S, 32);
+    for (int l = 0; l < L; ++l) {
+        ALLOC_OR_DIE(h->qkv[l], Mp * 3 * W * e);
+        ALLOC_OR_DIE(h->attn_o[l], Mp * W * e);
+        ALLOC_OR_DIE(h->lse[l], (size_t)B * h->H * Sp * 4);
+        ALLOC_OR_DIE(h->h_pre[l], Mp * 4 * W * e);
+    }
+    ALLOC_OR_DIE(h->g_act, Mp * 4 * W * e);
+    ALLOC_OR_DIE(h->pooled, (size_t)B * W * 4);
+    ALLOC_OR_DIE(h->emb_raw, (size_t)B * D * 4);
+    ALLOC_OR_DIE(h->inv_norm, (size_t)B * 4);
+    ALLOC_OR_DIE(h->dres, Mp * W * 4);
+    ALLOC_OR_DIE(h->dres_lp, Mp * W * e);
+    ALLOC_OR_DIE(h->d_o, Mp * W * e);
+    ALLOC_OR_DIE(h->dqkv, Mp * 3 * W * e);
+    ALLOC_OR_DIE(h->dh, Mp * 4 * W * e);
+    ALLOC_OR_DIE(h->d_ln, Mp * W * e);
+    ALLOC_OR_DIE(h->d_patch, Mp0 * W * e);
+    ALLOC_OR_DIE(h->dA0, Mp0 * h->Kpad * 4);
+    ALLOC_OR_DIE(h->dsum, (size_t)B * h->H * Sp * 4);
+    ALLOC_OR_DIE(h->d_raw, (size_t)B * D * 4);
+    ALLOC_OR_DIE(h->d_pooled, (size_t)B * W * 4);
+    if (!h->bf16) {
+        ALLOC_OR_DIE(h->scores, (size_t)B * h->H * S * S * 4);
+        ALLOC_OR_DIE(h->dscores, (size_t)B * h->H * S * S * 4);
+    } else { h->scores = h->dscores = nullptr; }
+    const size_t npix = (size_t)B * 3 * h->img * h->img;
+    for (int i = 0; i < 5; ++i) ALLOC_OR_DIE(h->img_buf[i], npix * 4);
+    ALLOC_OR_DIE(h->emb, (size_t)B * D * 4);
+    ALLOC_OR_DIE(h->d_emb, (size_t)B * D * 4);
+    ALLOC_OR_DIE(h->loss_ps, (size_t)B * 4);
+    ALLOC_OR_DIE(h->loss_scalar, 4096 * 4);
+    h->loss_scratch_floats = (size_t)B * 1024 + (size_t)D * 1024;   // CE head with up to 1024 classes
+    ALLOC_OR_DIE(h->loss_scratch, h->loss_scratch_floats * 4);
+    ALLOC_OR_DIE(h->ap_loss_steps, (size_t)1024 * B * 4);
+    ALLOC_OR_DIE(h->ap_loss_best, (size_t)B * 4);
+    ALLOC_OR_DIE(h->ap_loss_best_lc, (size_t)B * 4);
+    ALLOC_OR_DIE(h->ap_reduced_lc, (size_t)B * 4);
+    ALLOC_OR_DIE(h->ap_step, (size_t)B * 4);
+    ALLOC_OR_DIE(h->ap_acc, B); ALLOC_OR_DIE(h->ap_pred, B);
+    ALLOC_OR_DIE(h->ap_f0, B); ALLOC_OR_DIE(h->ap_f1, B); ALLOC_OR_DIE(h->ap_f2, B);
+#undef ALLOC_OR_DIE
+    hipError_t he = hipStreamSynchronize(s);
+    if (he != hipSuccess) { rvlm_vit_destroy(h); return fail(RVLM_ERR_HIP, std::string("create sync: ") + hipGetErrorString(he)); }
+    *out = h;
+    return RVLM_OK;
+}
+
+extern "C" int rvlm_vit_destroy(rvlm_vit* h) {
+    if (!h) return RVLM_OK;
+    hipDeviceSynchronize();
+    for (auto& r : h->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    for (void* p : h->allocs) hipFree(p);
+    delete h;
+    return RVLM_OK;
+}
+
+extern "C" int rvlm_vit_load_weights(rvlm_vit* h, const rvlm_vit_weights* weights, rvlm_stream_t stream) {
+    RVLM_REQUIRE(h && weights, "rvlm_vit_load_weights: null argument");
+    return load_weights(h, weights, (hipStream_t)stream, false);
+}
+
+extern "C" size_t rvlm_vit_workspace_bytes(const rvlm_vit* h) { return h ? h->bytes : 0; }
+
+extern "C" int rvlm_vit_forward(rvlm_vit* h, const float* x, const float* delta, int B, int output_normalize,
+                                int save_for_backward, float* out_emb, rvlm_stream_t stream) {
+    RVLM_REQUIRE(h && x && out_emb, "rvlm_vit_forward: null argument");
+    RVLM_REQUIRE(B > 0 && B <= h->maxB, "rvlm_vit_forward: batch exceeds max_batch");
+    return vit_forward(h, x, delta, B, output_normalize, save_for_backward, out_emb, (hipStream_t)stream);
+}
+
+extern "C" int rvlm_vit_backward_input(rvlm_vit* h, const float* d_emb, int B, float* grad_x,
+                                       rvlm_stream_t stream) {
+    RVLM_REQUIRE(h && d_emb && grad_x, "rvlm_vit_backward_input: null argument");
+    if (h->saved_B != B || B <= 0)
+        return fail(RVLM_ERR_STATE, "rvlm_vit_backward_input: no saved forward for this batch size");
+    return vit_backward(h, d_emb, B, grad_x, (hipStream_t)stream);
+}
+
+static int loss_step(rvlm_vit* h, const rvlm_loss_spec* ls, int B, int reduction, float* loss_scalar,
+                     uint8_t* pred_eq, hipStream_t s) {
+    if (ls->loss_kind == RVLM_LOSS_CE) {
+        RVLM_REQUIRE(ls->n_classes > 0 && ls->n_classes <= 1024, "loss: n_classes must be in 1..1024");
+        RVLM_REQUIRE(ls->targets, "loss: ce needs targets");
+    }
+    PROF("loss", 0, 0);
+    return rvlm_loss_grad(ls->loss_kind, reduction, h->emb, ls->ref, ls->targets, B, h->D, ls->n_classes,
+                          ls->logit_scale, h->loss_ps, loss_scalar, h->d_emb, pred_eq, h->loss_scratch, s);
+}
+
+extern "C" int rvlm_pgd_run(rvlm_vit* h, const float* x, const float* delta0, int B,
+                            const rvlm_loss_spec* loss, float eps, int iterations, float stepsize,
+                            float momentum, int mode_max, float* x_adv_out, float* loss_trace,
+                            int32_t* flags, rvlm_stream_t stream) {
+    RVLM_REQUIRE(h && x && loss && x_adv_out && loss->ref, "rvlm_pgd_run: null argument");
+    RVLM_REQUIRE(B > 1 && B <= h->maxB, "rvlm_pgd_run: need 1 < B <= max_batch");
+    RVLM_REQUIRE(iterations >= 0 && iterations <= 4096, "rvlm_pgd_run: iterations");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = (size_t)B * 3 * h->img * h->img;
+    float *delta = h->img_buf[0], *vel = h->img_buf[1], *grad = h->img_buf[2];
+    int rc;
+    if (flags && (rc = rvlm_check_image_range(x, n, flags, s))) return rc;
+    if (delta0) RVLM_HIP(hipMemcpyAsync(delta, delta0, n * 4, hipMemcpyDeviceToDevice, s));
+    else RVLM_HIP(hipMemsetAsync(delta, 0, n * 4, s));
+    RVLM_HIP(hipMemsetAsync(vel, 0, n * 4, s));
+    if (iterations == 0) {
+        hipLaunchKernelGGL(add_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, x, (const float*)delta, x_adv_out, n);
+        RVLM_CHECK_LAUNCH();
+    }
+    for (int it = 0; it < iterations; ++it) {
+        if ((rc = vit_forward(h, x, delta, B, loss->output_normalize, 1, h->emb, s))) return rc;
+        float* lsc = loss_trace ? loss_trace + it : (it < 4096 ? h->loss_scalar + it : nullptr);
+        if ((rc = loss_step(h, loss, B, loss->reduction, lsc, nullptr, s))) return rc;
+        if ((rc = vit_backward(h, h->d_emb, B, grad, s))) return rc;
+        {
+            PROF("linf_update", 0, (double)n * 28);
+            if ((rc = rvlm_pgd_linf_update(x, grad, delta, vel, n, eps, stepsize, momentum, mode_max,
+                                           it == iterations - 1 ? x_adv_out : nullptr, flags, s))) return rc;
+        }
+    }
+    return RVLM_OK;
+}
+
+extern "C" int rvlm_apgd_run(rvlm_vit* h, const float* x, const float* x_init, int B,
+                             const rvlm_loss_spec* loss, float eps, int n_iter, float step0,
+                             int train_variant, int logits_from_head, float* x_best_adv, float* x_best_out,
+                             float* loss_best_out, uint8_t* acc_out, rvlm_stream_t stream) {
+    RVLM_REQUIRE(h && x && loss && loss->ref && loss->targets, "rvlm_apgd_run: null argument");
+    RVLM_REQUIRE(x_best_adv, "rvlm_apgd_run: x_best_adv output required");
+    RVLM_REQUIRE(B > 1 && B <= h->maxB, "rvlm_apgd_run: need 1 < B <= max_batch");
+    RVLM_REQUIRE(n_iter >= 1 && n_iter <= 1024, "rvlm_apgd_run: n_iter must be in 1..1024");
+    RVLM_REQUIRE(!logits_from_head || loss->loss_kind == RVLM_LOSS_CE, "rvlm_apgd_run: head logits need the ce loss");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t npix = (size_t)3 * h->img * h->img, n = npix * B;
+    float *x_adv = h->img_buf[0], *x_adv_old = h->img_buf[1], *x_best = h->img_buf[2], *grad = h->img_buf[3],
+          *grad_best = h->img_buf[4];
+    int rc;
+    // schedule (apgd_train.py:153-156)
+    int k = std::max((int)(0.22 * n_iter), 1);
+    const int n_iter_min = std::max((int)(0.06 * n_iter), 1), size_decr = std::max((int)(0.03 * n_iter), 1);
+    int counter3 = 0;
+    hipLaunchKernelGGL(clamp01_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, x_init ? x_init : x, x_adv, n);
+    RVLM_CHECK_LAUNCH();
+    RVLM_HIP(hipMemcpyAsync(x_best, x_adv, n * 4, hipMemcpyDeviceToDevice, s));
+    RVLM_HIP(hipMemcpyAsync(x_best_adv, x_adv, n * 4, hipMemcpyDeviceToDevice, s));
+    RVLM_HIP(hipMemcpyAsync(x_adv_old, x_adv, n * 4, hipMemcpyDeviceToDevice, s));
+    RVLM_HIP(hipMemsetAsync(h->ap_loss_steps, 0, (size_t)n_iter * B * 4, s));
+
+    auto eval = [&](bool need_grad) -> int {
+        int r;
+        if ((r = vit_forward(h, x_adv, nullptr, B, loss->output_normalize, need_grad ? 1 : 0, h->emb, s))) return r;
+        if ((r = loss_step(h, loss, B, RVLM_RED_NONE, nullptr, logits_from_head ? h->ap_pred : nullptr, s))) return r;
+        if (!logits_from_head) {   // apgd_train.py:192,301: argmax over the model output (the embedding)
+            if ((r = rvlm_argmax_eq(h->emb, loss->targets, B, h->D, h->ap_pred, s))) return r;
+        }
+        if (need_grad) { if ((r = vit_backward(h, h->d_emb, B, grad, s))) return r; }
+        return RVLM_OK;
+    };
+    if ((rc = eval(true))) return rc;
+    RVLM_HIP(hipMemcpyAsync(grad_best, grad, n * 4, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(init_apgd_state_kernel, dim3(cdiv(B, 256)), dim3(256), 0, s, B, h->loss_ps, h->ap_pred, step0,
+                       h->ap_loss_best, h->ap_loss_best_lc, h->ap_reduced_lc, h->ap_step, h->ap_acc);
+    RVLM_CHECK_LAUNCH();
+    for (int i = 0; i < n_iter; ++i) {
+        const float a = i > 0 ? 0.75f : 1.0f;
+        {
+            PROF("linf_update", 0, (double)n * 24);
+            if ((rc = rvlm_apgd_linf_step(x, x_adv, x_adv_old, grad, h->ap_step, a, eps, npix, B, s))) return rc;
+        }
+        const bool need_grad = !(train_variant && i == n_iter - 1);   // apgd_train.py:293-295
+        if ((rc = eval(need_grad))) return rc;
+        counter3 += 1;
+        const int do_check = counter3 == k;
+        if ((rc = rvlm_apgd_controller(i, B, n_iter, k, do_check, h->loss_ps, h->ap_pred, h->ap_loss_steps,
+                                       h->ap_loss_best, h->ap_loss_best_lc, h->ap_reduced_lc, h->ap_step,
+                                       h->ap_acc, h->ap_f0, h->ap_f1, h->ap_f2, s))) return rc;
+        {
+            PROF("linf_update", 0, (double)n * 8);
+            if ((rc = rvlm_apgd_select(x_adv, grad, x_best, grad_best, x_best_adv, h->ap_f0, h->ap_f1, h->ap_f2,
+                                       npix, B, s))) return rc;
+        }
+        if (do_check) { counter3 = 0; k = std::max(k - size_decr, n_iter_min); }
+    }
+    if (x_best_out) RVLM_HIP(hipMemcpyAsync(x_best_out, x_best, n * 4, hipMemcpyDeviceToDevice, s));
+    if (loss_best_out) RVLM_HIP(hipMemcpyAsync(loss_best_out, h->ap_loss_best, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+    if (acc_out) RVLM_HIP(hipMemcpyAsync(acc_out, h->ap_acc, (size_t)B, hipMemcpyDeviceToDevice, s));
+    return RVLM_OK;
+}
+
+extern "C" int rvlm_vit_set_profiling(rvlm_vit* h, int enabled) {
+    RVLM_REQUIRE(h, "rvlm_vit_set_profiling: null handle");
+    h->prof = enabled != 0;
+    return RVLM_OK;
+}
+extern "C" int rvlm_vit_reset_profile(rvlm_vit* h) {
+    RVLM_REQUIRE(h, "rvlm_vit_reset_profile: null handle");
+    hipDeviceSynchronize();
+    for (auto& r : h->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    h->recs.clear();
+    for (auto& a : h->accs) a = ProfAcc();
+    return RVLM_OK;
+}
+extern "C" int rvlm_vit_get_profile(rvlm_vit* h, rvlm_profile_entry* out, int* n) {
+    RVLM_REQUIRE(h && out && n, "rvlm_vit_get_profile: null argument");
+    RVLM_HIP(hipDeviceSynchronize());
+    for (auto& a : h->accs) a.ms = 0;
+    for (auto& r : h->recs) {
+        float ms = 0.0f;
+        hipError_t e = hipEventElapsedTime(&ms, r.a, r.b);
+        if (e == hipSuccess) h->accs[r.cls].ms += ms;
+    }
+    int cnt = 0;
+    for (size_t i = 0; i < h->cls_names.size() && cnt < *n; ++i) {
+        if (h->accs[i].n == 0) continue;
+        rvlm_profile_entry& e = out[cnt++];
+        memset(&e, 0, sizeof(e));
+        strncpy(e.name, h->cls_names[i].c_str(), sizeof(e.name) - 1);
+        e.total_ms = h->accs[i].ms; e.flops = h->accs[i].flops; e.bytes = h->accs[i].bytes; e.launches = h->accs[i].n;
+    }
+    *n = cnt;
+    return RVLM_OK;
+}

@@ -1,0 +1,198 @@
+// bf16 MFMA GEMM for gfx950, NT form: C[M,N] = A[M,K] x Bw[N,K]^T, fp32 accumulate, fused epilogues.
+//
+// All the dense work of the encoder (QKV / out-proj / fc1 / fc2 / patch-embed, forward and dgrad)
+// runs through this kernel: dgrad uses the same NT form on the pre-transposed weight copy.
+//
+// Structure (v1):  128x128 block tile, BK = 64, 4 waves (2x2), each wave a 64x64 sub-tile as 2x2
+// v_mfma_f32_32x32x16_bf16; operands staged HBM -> LDS with global_load_lds_dwordx4 (16 B/lane,
+// no VGPR round trip), double-buffered, one barrier per K-step; LDS rows are 128 B (= BK bf16) with
+// the 16-B chunk index XOR-swizzled by ((row>>1)&7) so the ds_read_b128 fragment reads are
+// bank-conflict free (the swizzle is applied on the per-lane GLOBAL source address because the DMA
+// writes LDS lane-linearly).  The MFMA is issued as mfma(Bfrag, Afrag) so every lane ends up with 4
+// consecutive output columns of one row -> 8/16-byte epilogue accesses.  Workgroup ids are remapped
+// XCD-aware (each XCD's L2 sees a contiguous group of tiles) with GROUP_M=8 tile grouping.
+#include "kernels.h"
+
+namespace rvlm {
+
+constexpr int GB_M = 128, GB_N = 128, GB_K = 64;
+constexpr int GB_TILE_BYTES = GB_M * GB_K * 2;  // 16 KiB per operand per buffer
+
+__device__ __forceinline__ void glds16(const void* gptr, void* lds_ptr) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                     (__attribute__((address_space(3))) void*)lds_ptr, 16, 0, 0);
+}
+
+template <int EPI>
+__global__ void __launch_bounds__(256)
+gemm_bf16_nt_kernel(GemmBf16 p, int tiles_m, int tiles_n, int a_rows) {
+    __shared__ __attribute__((aligned(16))) char lds[4 * GB_TILE_BYTES];
+
+    // ---- XCD-aware, grouped tile order ----------------------------------------------------
+    const int nwg = gridDim.x, pid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = pid & 7, loc = pid >> 3;
+    const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+    const int group_size = 8 * tiles_n;
+    const int first_m = (t / group_size) * 8;
+    const int gm = min(tiles_m - first_m, 8);
+    const int tm = first_m + (t % group_size) % gm;
+    const int tn = (t % group_size) / gm;
+    const int m0 = tm * GB_M, n0 = tn * GB_N;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 1, wn = w & 1;
+
+    // ---- staging: wave w loads rows [32w, 32w+32) of both operand tiles, 8 rows per DMA ----
+    const int srow = lane >> 3, cphys = lane & 7;
+    const bf16_t* a_src[4];
+    const bf16_t* b_src[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = w * 32 + j * 8 + srow;
+        const int clog = cphys ^ ((r >> 1) & 7);
+        const int ar = min(m0 + r, a_rows - 1);
+        const int br = min(n0 + r, p.N - 1);
+        a_src[j] = p.A + (long)ar * p.lda + clog * 8;
+        b_src[j] = p.Bw + (long)br * p.ldb + clog * 8;
+    }
+    char* const stage_base = lds + (w * 32) * 128;
+
+    // ---- fragment read offsets (bytes inside an operand tile) ------------------------------
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int swz = (l31 >> 1) & 7;
+    int koff[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) koff[kk] = ((kk * 2 + hi) ^ swz) << 4;
+    const int a_row_off = (wm * 64 + l31) * 128;
+    const int b_row_off = (wn * 64 + l31) * 128;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int nk = p.K / GB_K;
+    // prologue: stage tile 0 into buffer 0
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        glds16(a_src[j], stage_base + j * 1024);
+        glds16(b_src[j], stage_base + GB_TILE_BYTES + j * 1024);
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        __syncthreads();  // drains this wave's DMA (vmcnt(0)) and orders LDS reuse
+        if (kt + 1 < nk) {
+            char* dst = stage_base + (buf ^ 1) * 2 * GB_TILE_BYTES;
+            const int ko = (kt + 1) * GB_K;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                glds16(a_src[j] + ko, dst + j * 1024);
+                glds16(b_src[j] + ko, dst + GB_TILE_BYTES + j * 1024);
+            }
+        }
+        const char* At = lds + buf * 2 * GB_TILE_BYTES;
+        const char* Bt = At + GB_TILE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 a0 = *(const bf16x8*)(At + a_row_off + koff[kk]);
+            bf16x8 a1 = *(const bf16x8*)(At + a_row_off + 32 * 128 + koff[kk]);
+            bf16x8 b0 = *(const bf16x8*)(Bt + b_row_off + koff[kk]);
+            bf16x8 b1 = *(const bf16x8*)(Bt + b_row_off + 32 * 128 + koff[kk]);
+            // swapped operands: D[n][m] -> lane holds 4 consecutive n for m = lane&31
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a0, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a1, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a1, acc[1][1], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int m = m0 + wm * 64 + mi * 32 + l31;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wn * 64 + ni * 32 + 8 * g + 4 * hi;
+                if (n >= p.N) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][g * 4 + e];
+                if (p.bias) {
+                    const float4 bv = *(const float4*)(p.bias + n);
+                    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+                }
+                const long o = (long)m * p.ldo + n;
+                if (EPI == EPI_BF16) {
+                    bf16x4 ov;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ov[e] = (bf16_t)v[e];
+                    *(bf16x4*)((bf16_t*)p.out + o) = ov;
+                } else if (EPI == EPI_F32_RESID) {
+                    if (p.residual) {
+                        const float4 rv = *(const float4*)(p.residual + o);
+                        v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+                    }
+                    *(float4*)((float*)p.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+                } else if (EPI == EPI_BF16_ACT) {
+                    bf16x4 pv, ov;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        pv[e] = (bf16_t)v[e];
+                        ov[e] = (bf16_t)act_fwd(v[e], p.act);
+                    }
+                    *(bf16x4*)(p.out_pre + o) = pv;
+                    *(bf16x4*)((bf16_t*)p.out + o) = ov;
+                } else if (EPI == EPI_BF16_DACT) {
+                    const bf16x4 hv = *(const bf16x4*)(p.h_pre + o);
+                    bf16x4 ov;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ov[e] = (bf16_t)(v[e] * act_bwd((float)hv[e], p.act));
+                    *(bf16x4*)((bf16_t*)p.out + o) = ov;
+                } else {  // EPI_F32
+                    *(float4*)((float*)p.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+    }
+}
+
+int gemm_bf16_nt(const GemmBf16& p, hipStream_t s) {
+    if (!p.A || !p.Bw || !p.out || p.M <= 0 || p.N <= 0 || p.K <= 0)
+        return fail(RVLM_ERR_ARG, "gemm_bf16_nt: bad arguments");
+    if (p.K % GB_K != 0 || p.N % 4 != 0 || p.lda % 8 != 0 || p.ldb % 8 != 0 || p.ldo % 4 != 0)
+        return fail(RVLM_ERR_UNSUPPORTED, "gemm_bf16_nt: need K%64==0, N%4==0, lda/ldb%8==0, ldo%4==0");
+    if (p.epi == EPI_BF16_ACT && !p.out_pre) return fail(RVLM_ERR_ARG, "gemm_bf16_nt: out_pre");
+    if (p.epi == EPI_BF16_DACT && !p.h_pre) return fail(RVLM_ERR_ARG, "gemm_bf16_nt: h_pre");
+    const int tiles_m = cdiv(p.M, GB_M), tiles_n = cdiv(p.N, GB_N);
+    const int a_rows = p.a_rows > 0 ? p.a_rows : p.M;
+    dim3 grid(tiles_m * tiles_n), block(256);
+    switch (p.epi) {
+        case EPI_BF16:
+            hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI_BF16>), grid, block, 0, s, p, tiles_m, tiles_n, a_rows);
+            break;
+        case EPI_F32_RESID:
+            hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI_F32_RESID>), grid, block, 0, s, p, tiles_m, tiles_n, a_rows);
+            break;
+        case EPI_BF16_ACT:
+            hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI_BF16_ACT>), grid, block, 0, s, p, tiles_m, tiles_n, a_rows);
+            break;
+        case EPI_BF16_DACT:
+            hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI_BF16_DACT>), grid, block, 0, s, p, tiles_m, tiles_n, a_rows);
+            break;
+        case EPI_F32:
+            hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI_F32>), grid, block, 0, s, p, tiles_m, tiles_n, a_rows);
+            break;
+        default:
+            return fail(RVLM_ERR_ARG, "gemm_bf16_nt: unknown epilogue");
+    }
+    RVLM_CHECK_LAUNCH();
+    return RVLM_OK;
+}
+
+}  // namespace rvlm

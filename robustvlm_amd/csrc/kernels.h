@@ -1,0 +1,124 @@
+// Internal launch API of the librvlm kernels (host side).  Each returns an rvlm_status.
+#pragma once
+#include "common.h"
+
+namespace rvlm {
+
+// ---------------------------------------------------------------------------------------------
+// Generic strided / batched fp32 GEMM (VALU, fmaf chain over k in order): the fp32 parity path
+// and all the small GEMMs (head projection, CE logits).
+//   C[b1,b2][m,n] = epi( alpha * sum_k A[b1,b2][m*sam + k*sak] * B[b1,b2][n*sbn + k*sbk] )
+// epi: +bias[n] -> (C2 = pre-activation) -> act -> *mul[m,n] (act' form) -> +residual[m,n]
+// ---------------------------------------------------------------------------------------------
+struct GemmF32 {
+    const float* A = nullptr; long sam = 0, sak = 0, sab1 = 0, sab2 = 0;
+    const float* B = nullptr; long sbn = 0, sbk = 0, sbb1 = 0, sbb2 = 0;
+    float* C = nullptr;       long scm = 0, scn = 1, scb1 = 0, scb2 = 0;
+    int M = 0, N = 0, K = 0, nb1 = 1, nb2 = 1;
+    float alpha = 1.0f;
+    const float* bias = nullptr;       // [N]
+    int act = -1;                      // -1 none, else RVLM_ACT_*
+    float* C_pre = nullptr;            // optional copy of the pre-activation (same layout as C)
+    const float* dact_h = nullptr;     // optional: multiply by act'(dact_h[m,n]) (layout of C)
+    int dact_kind = RVLM_ACT_QUICK_GELU;
+    const float* residual = nullptr;   // optional: + residual[m,n] (layout of C)
+};
+int gemm_f32(const GemmF32& p, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// bf16 MFMA GEMM, NT form: C[M,N] = A[M,K] (row-major, lda) x Bw[N,K]^T (row-major, ldb)
+// fp32 accumulate.  Requirements: K % 64 == 0, A/Bw rows readable up to round_up(M|N,128)
+// (buffers are padded), N % 4 == 0.
+// ---------------------------------------------------------------------------------------------
+enum GemmEpi {
+    EPI_BF16 = 0,          // out bf16 = acc (+bias)
+    EPI_F32_RESID = 1,     // out f32  = acc (+bias) (+residual f32)
+    EPI_BF16_ACT = 2,      // out_pre bf16 = acc+bias ; out bf16 = act(acc+bias)
+    EPI_BF16_DACT = 3,     // out bf16 = acc * act'(h_pre bf16)
+    EPI_F32 = 4            // out f32 = acc (+bias)
+};
+struct GemmBf16 {
+    const bf16_t* A = nullptr; long lda = 0;
+    const bf16_t* Bw = nullptr; long ldb = 0;
+    int M = 0, N = 0, K = 0;
+    int a_rows = 0;                     // allocated (readable) rows of A, >= M; 0 -> M
+    int epi = EPI_BF16;
+    const float* bias = nullptr;        // [N] or null
+    void* out = nullptr; long ldo = 0;  // bf16 or f32 per epi
+    bf16_t* out_pre = nullptr;          // EPI_BF16_ACT (ld = ldo)
+    const bf16_t* h_pre = nullptr;      // EPI_BF16_DACT (ld = ldo)
+    const float* residual = nullptr;    // EPI_F32_RESID (ld = ldo)
+    int act = RVLM_ACT_QUICK_GELU;
+};
+int gemm_bf16_nt(const GemmBf16& p, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over the last dim (eps 1e-5, biased variance), one wave per row.
+// ---------------------------------------------------------------------------------------------
+template <typename TO>
+int layernorm_fwd(const float* x, long ldx, const float* gamma, const float* beta, TO* y, long ldy,
+                  float* mean, float* rstd, int M, int W, hipStream_t s);
+// dres[m,:] (+)= LN'(dy[m,:]) ; optionally also writes dres as TB (A operand of the next dgrad GEMM)
+// accumulate=0 overwrites dres.
+template <typename TI, typename TB>
+int layernorm_bwd(const TI* dy, long lddy, const float* x, long ldx, const float* gamma,
+                  const float* mean, const float* rstd, float* dres, long lddres, TB* dres_lp,
+                  long ldlp, int accumulate, int M, int W, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// Patch embedding glue
+// ---------------------------------------------------------------------------------------------
+// A0[(b*g*g + py*g + px), c*P*P + i*P + j] = ((x(+delta))[b,c,py*P+i,px*P+j] - mean_c)/std_c ; cols
+// >= 3*P*P zero-filled up to Kpad.
+template <typename T>
+int im2col_normalize(const float* x, const float* delta, int B, int img, int P, const float* mean3,
+                     const float* std3, T* A0, long lda, int Kpad, hipStream_t s);
+// grad_x[b,c,y,x] = dA0[row, col] / std_c
+template <typename T>
+int col2im_grad(const T* dA0, long lda, int B, int img, int P, const float* std3, float* grad_x,
+                hipStream_t s);
+// tokens = [cls ; patch_out] + pos ; x0 = ln_pre(tokens)
+template <typename T>
+int embed_lnpre_fwd(const T* patch_out, long ldp, const float* cls, const float* pos,
+                    const float* gamma, const float* beta, float* x0, long ldx, float* mean,
+                    float* rstd, int B, int S, int W, hipStream_t s);
+// d_patch[b*(S-1)+s-1,:] = LN'(dx0[b*S+s,:]) for s >= 1
+template <typename T>
+int embed_lnpre_bwd(const float* dx0, long lddx, const float* patch_out, long ldp, const float* cls,
+                    const float* pos, const float* gamma, const float* mean, const float* rstd,
+                    T* d_patch, long lddp, int B, int S, int W, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// Head: pooled = ln_post(x[b,0,:]); emb = pooled @ proj; optional L2 normalise
+// ---------------------------------------------------------------------------------------------
+int l2_normalize_fwd(const float* e, float* out, float* inv_norm, int B, int D, hipStream_t s);
+// d_raw = (d - ehat*(ehat.d)) * inv_norm   (F.normalize backward, eps 1e-12)
+int l2_normalize_bwd(const float* d_out, const float* e_raw, const float* inv_norm, float* d_raw,
+                     int B, int D, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// Softmax rows for the fp32 attention path (scores materialised): in place
+// ---------------------------------------------------------------------------------------------
+int softmax_rows_fwd(float* s, long rows, int cols, hipStream_t st);
+// ds = p * (dp - sum_j p_j dp_j) * scale, in place over dp
+int softmax_rows_bwd(const float* p, float* dp, long rows, int cols, float scale, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------
+// bf16 flash attention (head_dim 64), qkv packed [M, 3W] bf16 (q | k | v), tokens of image b at
+// rows b*S .. b*S+S-1.
+// ---------------------------------------------------------------------------------------------
+int attn_fwd_bf16(const bf16_t* qkv, long ldqkv, bf16_t* o, long ldo, float* lse, int B, int H,
+                  int S, hipStream_t s);
+int attn_bwd_bf16(const bf16_t* qkv, long ldqkv, const bf16_t* o, long ldo, const bf16_t* d_o,
+                  long lddo, const float* lse, float* dsum_scratch, bf16_t* dqkv, long lddqkv,
+                  int B, int H, int S, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// misc
+// ---------------------------------------------------------------------------------------------
+int convert_f32_to_bf16(const float* src, long lds_, bf16_t* dst, long ldd, int rows, int cols,
+                        int transpose, hipStream_t s);  // dst[c,r] if transpose
+int scale_copy_f32(const float* src, float* dst, size_t n, float alpha, hipStream_t s);
+int fill_f32(float* dst, size_t n, float v, hipStream_t s);
+
+}  // namespace rvlm

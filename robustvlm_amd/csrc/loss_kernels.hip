@@ -1,0 +1,158 @@
+// FARE (l2) / TeCoA (ce) losses with their gradient w.r.t. the embedding, fused:
+// replaces compute_loss / l2 / ce (train/adversarial_training_clip.py:495-528) + autograd.
+#include "kernels.h"
+
+namespace rvlm {
+
+// per-sample  sum_d (e - e0)^2  (…clip.py:515-519) and d = 2 (e - e0) * gscale, one wave/sample
+__global__ void __launch_bounds__(256)
+l2_loss_kernel(const float* __restrict__ emb, const float* __restrict__ ref, int B, int D,
+               float gscale, float* __restrict__ per_sample, float* __restrict__ d_emb) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B) return;
+    float acc = 0.0f;
+    for (int c = lane; c < D; c += 64) {
+        const float d = emb[(long)row * D + c] - ref[(long)row * D + c];
+        acc = fmaf(d, d, acc);
+        if (d_emb) d_emb[(long)row * D + c] = 2.0f * d * gscale;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0 && per_sample) per_sample[row] = acc;
+}
+
+// logits row -> loss = logsumexp - logit[y] ; dlogits = (softmax - onehot) * gscale (in place);
+// pred_eq = (argmax == y), ties -> first index
+__global__ void __launch_bounds__(256)
+ce_loss_kernel(float* __restrict__ logits, const int64_t* __restrict__ targets, int B, int C,
+               float gscale, float* __restrict__ per_sample, uint8_t* __restrict__ pred_eq,
+               int write_grad) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B) return;
+    float* l = logits + (long)row * C;
+    const int y = (int)targets[row];
+    float m = -INFINITY;
+    int mi = 0x7fffffff;
+    for (int c = lane; c < C; c += 64) {
+        const float v = l[c];
+        if (v > m) { m = v; mi = c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(m, o, 64);
+        const int oi = __shfl_xor(mi, o, 64);
+        if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+    }
+    float sum = 0.0f;
+    for (int c = lane; c < C; c += 64) sum += expf(l[c] - m);
+    sum = wave_sum(sum);
+    const float lse = m + logf(sum);
+    if (lane == 0) {
+        if (per_sample) per_sample[row] = lse - l[y];
+        if (pred_eq) pred_eq[row] = (mi == y) ? 1 : 0;
+    }
+    if (write_grad) {
+        for (int c = lane; c < C; c += 64) {
+            const float p = expf(l[c] - lse);
+            l[c] = (p - (c == y ? 1.0f : 0.0f)) * gscale;
+        }
+    }
+}
+
+// deterministic single-block reduction of the per-sample losses -> scalar
+__global__ void __launch_bounds__(256)
+reduce_loss_kernel(const float* __restrict__ per_sample, int B, float scale, float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < B; i += 256) s += per_sample[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = ((red[0] + red[1]) + (red[2] + red[3])) * scale;
+}
+
+__global__ void __launch_bounds__(256)
+argmax_eq_kernel(const float* __restrict__ logits, const int64_t* __restrict__ targets, int B, int C,
+                 uint8_t* __restrict__ out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B) return;
+    const float* l = logits + (long)row * C;
+    float m = -INFINITY;
+    int mi = 0x7fffffff;
+    for (int c = lane; c < C; c += 64) {
+        const float v = l[c];
+        if (v > m) { m = v; mi = c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(m, o, 64);
+        const int oi = __shfl_xor(mi, o, 64);
+        if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+    }
+    if (lane == 0) out[row] = ((int64_t)mi == targets[row]) ? 1 : 0;
+}
+
+}  // namespace rvlm
+
+using namespace rvlm;
+
+extern "C" int rvlm_loss_grad(int loss_kind, int reduction, const float* emb, const float* ref,
+                              const int64_t* targets, int B, int D, int C, float logit_scale,
+                              float* loss_per_sample, float* loss_scalar, float* d_emb,
+                              uint8_t* pred_eq, float* scratch, rvlm_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    RVLM_REQUIRE(emb && ref && B > 0 && D > 0, "rvlm_loss_grad: bad arguments");
+    // the reference's losses assert batch > 1 (…clip.py:513,526)
+    RVLM_REQUIRE(B > 1, "rvlm_loss_grad: batch size must be > 1 (reference asserts out.shape[0] > 1)");
+    RVLM_REQUIRE(reduction == RVLM_RED_MEAN || reduction == RVLM_RED_NONE,
+                 "rvlm_loss_grad: unknown reduction");
+    const float gscale = (reduction == RVLM_RED_MEAN) ? 1.0f / (float)B : 1.0f;
+    if (loss_kind == RVLM_LOSS_L2) {
+        RVLM_REQUIRE(loss_per_sample || !loss_scalar, "rvlm_loss_grad: loss_scalar needs loss_per_sample");
+        hipLaunchKernelGGL(l2_loss_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, emb, ref, B, D, gscale,
+                           loss_per_sample, d_emb);
+        RVLM_CHECK_LAUNCH();
+    } else if (loss_kind == RVLM_LOSS_CE) {
+        RVLM_REQUIRE(targets && scratch && C > 0, "rvlm_loss_grad: ce needs targets, scratch, C");
+        RVLM_REQUIRE(loss_per_sample || !loss_scalar, "rvlm_loss_grad: loss_scalar needs loss_per_sample");
+        float* logits = scratch;                 // [B, C]
+        float* Ts = scratch + (size_t)B * C;     // [D, C] = logit_scale * T   (…clip.py:501)
+        int rc = scale_copy_f32(ref, Ts, (size_t)D * C, logit_scale, s);
+        if (rc) return rc;
+        GemmF32 g;
+        g.A = emb; g.sam = D; g.sak = 1;
+        g.B = Ts; g.sbn = 1; g.sbk = C;
+        g.C = logits; g.scm = C; g.scn = 1;
+        g.M = B; g.N = C; g.K = D;
+        rc = gemm_f32(g, s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(ce_loss_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, logits, targets, B, C,
+                           gscale, loss_per_sample, pred_eq, d_emb ? 1 : 0);
+        RVLM_CHECK_LAUNCH();
+        if (d_emb) {
+            GemmF32 h;
+            h.A = logits; h.sam = C; h.sak = 1;     // dlogits [B, C]
+            h.B = Ts; h.sbn = C; h.sbk = 1;         // (n = d, k = c)
+            h.C = d_emb; h.scm = D; h.scn = 1;
+            h.M = B; h.N = D; h.K = C;
+            rc = gemm_f32(h, s);
+            if (rc) return rc;
+        }
+    } else {
+        return fail(RVLM_ERR_ARG, "rvlm_loss_grad: loss not supported");  // ValueError in …clip.py:506
+    }
+    if (loss_scalar) {
+        hipLaunchKernelGGL(reduce_loss_kernel, dim3(1), dim3(256), 0, s, loss_per_sample, B,
+                           reduction == RVLM_RED_MEAN ? 1.0f / (float)B : 1.0f, loss_scalar);
+        RVLM_CHECK_LAUNCH();
+    }
+    return RVLM_OK;
+}
+
+extern "C" int rvlm_argmax_eq(const float* logits, const int64_t* targets, int B, int C,
+                              uint8_t* out, rvlm_stream_t stream) {
+    RVLM_REQUIRE(logits && targets && out && B > 0 && C > 0, "rvlm_argmax_eq: bad arguments");
+    hipLaunchKernelGGL(argmax_eq_kernel, dim3(cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, logits,
+                       targets, B, C, out);
+    RVLM_CHECK_LAUNCH();
+    return RVLM_OK;
+}

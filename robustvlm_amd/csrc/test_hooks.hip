@@ -1,0 +1,66 @@
+// Kernel-level C entry points (include/rvlm_kernels.h) used by tests/ to check each HIP kernel in
+// isolation against the oracle.
+#include "kernels.h"
+#include "../../include/rvlm_kernels.h"
+
+namespace rvlm {
+void attn_set_use_tr(int on);
+
+__global__ void probe_tr16_kernel(const bf16_t* __restrict__ src, const int32_t* __restrict__ offs,
+                                  bf16_t* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) bf16_t tile[2048];
+    for (int i = threadIdx.x; i < 2048; i += 64) tile[i] = src[i];
+    __syncthreads();
+    const int lane = threadIdx.x;
+    bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+        (__attribute__((address_space(3))) bf16x4*)((__attribute__((address_space(3))) char*)tile + offs[lane]));
+    for (int j = 0; j < 4; ++j) out[lane * 4 + j] = v[j];
+}
+}  // namespace rvlm
+using namespace rvlm;
+
+extern "C" int rvlm_k_gemm_bf16_nt(const uint16_t* A, long lda, const uint16_t* Bw, long ldb, int M, int N,
+                                   int K, int a_rows, int epi, const float* bias, void* out, long ldo,
+                                   uint16_t* out_pre, const uint16_t* h_pre, const float* residual, int act,
+                                   rvlm_stream_t stream) {
+    GemmBf16 g;
+    g.A = (const bf16_t*)A; g.lda = lda; g.Bw = (const bf16_t*)Bw; g.ldb = ldb; g.M = M; g.N = N; g.K = K;
+    g.a_rows = a_rows; g.epi = epi; g.bias = bias; g.out = out; g.ldo = ldo; g.out_pre = (bf16_t*)out_pre;
+    g.h_pre = (const bf16_t*)h_pre; g.residual = residual; g.act = act;
+    return gemm_bf16_nt(g, (hipStream_t)stream);
+}
+extern "C" int rvlm_k_gemm_f32(const float* A, long sam, long sak, const float* B, long sbn, long sbk,
+                               float* C, long scm, long scn, int M, int N, int K, float alpha,
+                               const float* bias, rvlm_stream_t stream) {
+    GemmF32 g;
+    g.A = A; g.sam = sam; g.sak = sak; g.B = B; g.sbn = sbn; g.sbk = sbk; g.C = C; g.scm = scm; g.scn = scn;
+    g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.bias = bias;
+    return gemm_f32(g, (hipStream_t)stream);
+}
+extern "C" int rvlm_k_attn_fwd_bf16(const uint16_t* qkv, uint16_t* o, float* lse2, int B, int H, int S,
+                                    rvlm_stream_t stream) {
+    return attn_fwd_bf16((const bf16_t*)qkv, 3L * H * 64, (bf16_t*)o, H * 64L, lse2, B, H, S, (hipStream_t)stream);
+}
+extern "C" int rvlm_k_attn_bwd_bf16(const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o,
+                                    const float* lse2, float* dsum_scratch, uint16_t* dqkv, int B, int H, int S,
+                                    rvlm_stream_t stream) {
+    return attn_bwd_bf16((const bf16_t*)qkv, 3L * H * 64, (const bf16_t*)o, H * 64L, (const bf16_t*)d_o, H * 64L,
+                         lse2, dsum_scratch, (bf16_t*)dqkv, 3L * H * 64, B, H, S, (hipStream_t)stream);
+}
+extern "C" int rvlm_k_attn_set_use_tr(int on) { attn_set_use_tr(on); return RVLM_OK; }
+extern "C" int rvlm_k_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y,
+                                        float* mean, float* rstd, int M, int W, rvlm_stream_t stream) {
+    return layernorm_fwd<float>(x, W, gamma, beta, y, W, mean, rstd, M, W, (hipStream_t)stream);
+}
+extern "C" int rvlm_k_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean,
+                                        const float* rstd, float* dres, int accumulate, int M, int W,
+                                        rvlm_stream_t stream) {
+    return layernorm_bwd<float, float>(dy, W, x, W, gamma, mean, rstd, dres, W, nullptr, W, accumulate, M, W,
+                                       (hipStream_t)stream);
+}
+extern "C" int rvlm_k_probe_tr16(const uint16_t* src, const int32_t* offs, uint16_t* out, rvlm_stream_t stream) {
+    hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)src, offs,
+                       (bf16_t*)out);
+    RVLM_CHECK_LAUNCH();
+    return RVLM_OK;
+}

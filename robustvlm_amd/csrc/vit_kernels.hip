@@ -1,0 +1,509 @@
+// HBM-bound glue kernels of the encoder: LayerNorm fwd/bwd (wave-shuffle row reductions), patch
+// im2col (+delta, Normalize fused into the load) / col2im, CLS+pos+ln_pre, L2-normalise, softmax
+// rows for the fp32 path, dtype conversion.  One wave (64 lanes) per row, float4 / bf16x4 accesses.
+#include "kernels.h"
+
+namespace rvlm {
+
+// ---- 4-wide row accessors ----------------------------------------------------------------------
+__device__ __forceinline__ void load4(const float* p, float (&v)[4]) { *(float4*)v = *(const float4*)p; }
+__device__ __forceinline__ void load4(const bf16_t* p, float (&v)[4]) {
+    bf16x4 t = *(const bf16x4*)p;
+    v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+}
+__device__ __forceinline__ void store4(float* p, const float (&v)[4]) { *(float4*)p = *(const float4*)v; }
+__device__ __forceinline__ void store4(bf16_t* p, const float (&v)[4]) {
+    bf16x4 t;
+    t[0] = (bf16_t)v[0]; t[1] = (bf16_t)v[1]; t[2] = (bf16_t)v[2]; t[3] = (bf16_t)v[3];
+    *(bf16x4*)p = t;
+}
+
+constexpr int LN_MAXV = 8;  // register-cached float4 chunks per lane: W <= 2048
+
+// =============================================================================================
+// LayerNorm forward
+// =============================================================================================
+template <typename TO>
+__global__ void __launch_bounds__(256)
+layernorm_fwd_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ gamma,
+                     const float* __restrict__ beta, TO* __restrict__ y, long ldy,
+                     float* __restrict__ mean, float* __restrict__ rstd, int M, int W) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float* xr = x + (long)row * ldx;
+    float v[LN_MAXV][4];
+    float s = 0.0f;
+#pragma unroll
+    for (int it = 0; it < LN_MAXV; ++it) {
+        const int c = lane * 4 + it * 256;
+        if (c < W) { load4(xr + c, v[it]); s += (v[it][0] + v[it][1]) + (v[it][2] + v[it][3]); }
+    }
+    const float mu = wave_sum(s) / (float)W;
+    float q = 0.0f;
+#pragma unroll
+    for (int it = 0; it < LN_MAXV; ++it) {
+        const int c = lane * 4 + it * 256;
+        if (c < W) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { float d = v[it][e] - mu; q = fmaf(d, d, q); }
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)W + 1e-5f);
+    if (lane == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
+    TO* yr = y + (long)row * ldy;
+#pragma unroll
+    for (int it = 0; it < LN_MAXV; ++it) {
+        const int c = lane * 4 + it * 256;
+        if (c < W) {
+            float g[4], b[4], o[4];
+            load4(gamma + c, g); load4(beta + c, b);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[it][e] - mu) * rs * g[e] + b[e];
+            store4(yr + c, o);
+        }
+    }
+}
+
+template <typename TO>
+int layernorm_fwd(const float* x, long ldx, const float* gamma, const float* beta, TO* y, long ldy,
+                  float* mean, float* rstd, int M, int W, hipStream_t s) {
+    if (W % 4 != 0 || W > LN_MAXV * 256) return fail(RVLM_ERR_UNSUPPORTED, "layernorm: width");
+    hipLaunchKernelGGL((layernorm_fwd_kernel<TO>), dim3(cdiv(M, 4)), dim3(256), 0, s, x, ldx, gamma,
+                       beta, y, ldy, mean, rstd, M, W);
+    RVLM_CHECK_LAUNCH();
+    return RVLM_OK;
+}
+template int layernorm_fwd<float>(const float*, long, const float*, const float*, float*, long,
+                                  float*, float*, int, int, hipStream_t);
+template int layernorm_fwd<bf16_t>(const float*, long, const float*, const float*, bf16_t*, long,
+                                   float*, float*, int, int, hipStream_t);
+
+// =============================================================================================
+// LayerNorm backward (input gradient only): dx = rstd * (g - mean(g) - xhat * mean(g*xhat)),
+// g = dy*gamma.  Accumulates into the fp32 residual-stream gradient and emits its low-precision
+// copy (the A operand of the next dgrad GEMM).
+// =============================================================================================
+template <typename TI, typename TB>
+__global__ void __launch_bounds__(256)
+layernorm_bwd_kernel(const TI* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx,
+                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                     const float* __restrict__ rstd, float* __restrict__ dres, long lddres,
+                     TB* __restrict__ dres_lp, long ldlp, int accumulate, int M, int W) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float mu = mean[row], rs = rstd[row];
+    const TI* dyr = dy + (long)row * lddy;
+    const float* xr = x + (long)row * ldx;
+    float g[LN_MAXV][4], xh[LN_MAXV][4];
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int it = 0; it < LN_MAXV; ++it) {
+        const int c = lane * 4 + it * 256;
+        if (c < W) {
+            float d[4], xv[4], gm[4];
+            load4(dyr + c, d); load4(xr + c, xv); load4(gamma + c, gm);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                g[it][e] = d[e] * gm[e];
+                xh[it][e] = (xv[e] - mu) * rs;
+                s1 += g[it][e];
+                s2 = fmaf(g[it][e], xh[it][e], s2);
+            }
+        }
+    }
+    const float c1 = wave_sum(s1) / (float)W;
+    const float c2 = wave_sum(s2) / (float)W;
+    float* dr = dres + (long)row * lddres;
+#pragma unroll
+    for (int it = 0; it < LN_MAXV; ++it) {
+        const int c = lane * 4 + it * 256;
+        if (c < W) {
+            float o[4];
+            if (accumulate) load4(dr + c, o); else { o[0] = o[1] = o[2] = o[3] = 0.0f; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] += rs * (g[it][e] - c1 - xh[it][e] * c2);
+            store4(dr + c, o);
+            if (dres_lp) store4(dres_lp + (long)row * ldlp + c, o);
+        }
+    }
+}
+
+template <typename TI, typename TB>
+int layernorm_bwd(const TI* dy, long lddy, const float* x, long ldx, const float* gamma,
+                  const float* mean, const float* rstd, float* dres, long lddres, TB* dres_lp,
+                  long ldlp, int accumulate, int M, int W, hipStream_t s) {
+    if (W % 4 != 0 || W > LN_MAXV * 256) return fail(RVLM_ERR_UNSUPPORTED, "layernorm: width");
+    hipLaunchKernelGGL((layernorm_bwd_kernel<TI, TB>), dim3(cdiv(M, 4)), dim3(256), 0, s, dy, lddy,
+                       x, ldx, gamma, mean, rstd, dres, lddres, dres_lp, ldlp, accumulate, M, W);
+    RVLM_CHECK_LAUNCH();
+    return RVLM_OK;
+}
+template int layernorm_bwd<float, float>(const float*, long, const float*, long, const float*,
+                                         const float*, const float*, float*, long, float*, long,
+                                         int, int, int, hipStream_t);
+template int layernorm_bwd<bf16_t, bf16_t>(const bf16_t*, long, const float*, long, const float*,
+                                           const float*, const float*, float*, long, bf16_t*, long,
+                                           int, int, int, hipStream_t);
+template int layernorm_bwd<float, bf16_t>(const float*, long, const float*, long, const float*,
+                                          const float*, const float*, float*, long, bf16_t*, long,
+                                          int, int, int, hipStream_t);
+
+// =============================================================================================
+// Patch im2col with (x + delta) and Normalize fused:  A0[row, col]
+// =============================================================================================
+template <typename T>
+__global__ void __launch_bounds__(256)
+im2col_kernel(const float* __restrict__ x, const float* __restrict__ delta, int B, int img, int P,
+              float m0, float m1, float m2, float s0, float s1, float s2, T* __restrict__ A0,
+              long lda, int Kpad) {
+    const int g = img / P, PP = P * P, K = 3 * PP;
+    const long total = (long)B * g * g * Kpad;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int col = (int)(idx % Kpad);
+        const long row = idx / Kpad;
+        float v = 0.0f;
+        if (col < K) {
+            const int c = col / PP, r = col - c * PP, i = r / P, j = r - i * P;
+            const int px = (int)(row % g);
+            const long t = row / g;
+            const int py = (int)(t % g);
+            const long b = t / g;
+            const long xi = ((b * 3 + c) * img + (long)py * P + i) * img + (long)px * P + j;
+            float pix = x[xi];
+            if (delta) pix = pix + delta[xi];                 // pgd_train.py:32  data_clean + perturbation
+            const float mu = c == 0 ? m0 : (c == 1 ? m1 : m2);
+            const float sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+            v = (pix - mu) / sd;                              // Normalize, …clip.py:116,254
+        }
+        A0[row * lda + col] = from_f32<T>(v);
+    }
+}
+
+template <typename T>
+int im2col_normalize(const float* x, const float* delta, int B, int img, int P, const float* mean3,
+                     const float* std3, T* A0, long lda, int Kpad, hipStream_t s) {
+    const long total = (long)B * (img / P) * (img / P) * Kpad;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 256 * 16) grid = 256 * 16;
+    hipLaunchKernelGGL((im2col_kernel<T>), dim3(grid), dim3(256), 0, s, x, delta, B, img, P,
+                       mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], A0, lda, Kpad);
+    RVLM_CHECK_LAUNCH();
+    return RVLM_OK;
+}
+template int im2col_normalize<float>(const float*, const float*, int, int, int, const float*,
+                                     const float*, float*, long, int, hipStream_t);
+template int im2col_normalize<bf16_t>(const float*, const float*, int, int, int, const float*,
+                                      const float*, bf16_t*, long, int, hipStream_t);
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+col2im_kernel(const T* __restrict__ dA0, long lda, int B, int img, int P, float s0, float s1,
+              float s2, float* __restrict__ grad_x) {
+    const int g = img / P, PP = P * P;
+    const long total = (long)B * 3 * img * img;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int xx = (int)(idx % img);
+        long t = idx / img;
+        const int yy = (int)(t % img);
+        t /= img;
+        const int c = (int)(t % 3);
+        const long b = t / 3;
+        const int py = yy / P, i = yy - py * P, px = xx / P, j = xx - px * P;
+        const long row = (b * g + py) * g + px;
+        const int col = c * PP + i * P + j;
+        const float sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+        grad_x[idx] = to_f32(dA0[row * lda + col]) / sd;
+    }
+}
+
+template <typename T>
+int col2im_grad(const T* dA0, long lda, int B, int img, int P, const float* std3, float* grad_x,
+                hipStream_t s) {
+    const long total = (long)B * 3 * img * img;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 256 * 16) grid = 256 * 16;
+    hipLaunchKernelGGL((col2im_kernel<T>), dim3(grid), dim3(256), 0, s, dA0, lda, B, img, P, std3[0],
+                       std3[1], std3[2], grad_x);
+    RVLM_CHECK_LAUNCH();
+    return RVLM_OK;
+}
+template int col2im_grad<float>(const float*, long, int, int, int, const float*, float*, hipStream_t);
+template int col2im_grad<bf16_t>(const bf16_t*, long, int, int, int, const float*, float*,
+                                 hipStream_t);
+
+// =============================================================================================
+// tokens = [cls ; patch_out] + pos ; x0 = ln_pre(tokens)     (Appendix B steps 2-3)
+// =============================================================================================
+template <typename T>
+__global__ void __launch_bounds__(256)
+embed_lnpre_fwd_kernel(const T* __restrict__ patch_out, long ldp, const float* __restrict__ cls,
+                       const float* __restrict__ pos, const float* __restrict__ gamma,
+                       const float* __restrict__ beta, float* __restrict__ x0, long ldx,
+                       float* __restrict__ mean, float* __restrict__ rstd, int B, int S, int W) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= B * S) return;
+    const int b = row / S, sidx = row - b * S;
+    const T* pr = patch_out + ((long)b * (S - 1) + (sidx - 1)) * ldp;
+    float v[LN_MAXV][4];
+    float sum = 0.0f;
+#pragma unroll
+    for (int it = 0; it < LN_MAXV; ++it) {
+        const int c = lane * 4 + it * 256;
+        if (c < W) {
+            float a[4], p[4];
+            if (sidx == 0) load4(cls + c, a); else load4(pr + c, a);
+            load4(pos + (long)sidx * W + c, p);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[it][e] = a[e] + p[e]; sum += v[it][e]; }
+        }
+    }
+    const float mu = wave_sum(sum) / (float)W;
+    float q = 0.0f;
+#pragma unroll
+    for (int it = 0; it < LN_MAXV; ++it) {
+        const int c = lane * 4 + it * 256;
+        if (c < W) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { float d = v[it][e] - mu; q = fmaf(d, d, q); }
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)W + 1e-5f);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+    for (int it = 0; it < LN_MAXV; ++it) {
+        const int c = lane * 4 + it * 256;
+        if (c < W) {
+            float g[4], bb[4], o[4];
+            load4(gamma + c, g); load4(beta + c, bb);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[it][e] - mu) * rs * g[e] + bb[e];
+            store4(x0 + (long)row * ldx + c, o);
+        }
+    }
+}
+
+template <typename T>
+int embed_lnpre_fwd(const T* patch_out, long ldp, const float* cls, const float* pos,
+                    const float* gamma, const float* beta, float* x0, long ldx, float* mean,
+                    float* rstd, int B, int S, int W, hipStream_t s) {
+    if (W % 4 != 0 || W > LN_MAXV * 256) return fail(RVLM_ERR_UNSUPPORTED, "embed: width");
+    hipLaunchKernelGGL((embed_lnpre_fwd_kernel<T>), dim3(cdiv((long)B * S, 4)), dim3(256), 0, s,
+                       patch_out, ldp, cls, pos, gamma, beta, x0, ldx, mean, rstd, B, S, W);
+    RVLM_CHECK_LAUNCH();
+    return RVLM_OK;
+}
+template int embed_lnpre_fwd<float>(const float*, long, const float*, const float*, const float*,
+                                    const float*, float*, long, float*, float*, int, int, int,
+                                    hipStream_t);
+
+template <typename TP, typename T>
+__global__ void __launch_bounds__(256)
+embed_lnpre_bwd_kernel(const float* __restrict__ dx0, long lddx, const TP* __restrict__ patch_out,
+                       long ldp, const float* __restrict__ pos, const float* __restrict__ gamma,
+                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                       T* __restrict__ d_patch, long lddp, int B, int S, int W) {
+    // one wave per patch token (CLS rows have no image gradient)
+    const int prow = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (prow >= B * (S - 1)) return;
+    const int b = prow / (S - 1), sidx = prow - b * (S - 1) + 1;
+    const long row = (long)b * S + sidx;
+    const float mu = mean[row], rs = rstd[row];
+    float g[LN_MAXV][4], xh[LN_MAXV][4];
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int it = 0; it < LN_MAXV; ++it) {
+        const int c = lane * 4 + it * 256;
+        if (c < W) {
+            float d[4], a[4], p[4], gm[4];
+            load4(dx0 + row * lddx + c, d);
+            load4(patch_out + (long)prow * ldp + c, a);
+            load4(pos + (long)sidx * W + c, p);
+            load4(gamma + c, gm);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                g[it][e] = d[e] * gm[e];
+                xh[it][e] = ((a[e] + p[e]) - mu) * rs;
+                s1 += g[it][e];
+                s2 = fmaf(g[it][e], xh[it][e], s2);
+            }
+        }
+    }
+    const float c1 = wave_sum(s1) / (float)W, c2 = wave_sum(s2) / (float)W;
+#pragma unroll
+    for (int it = 0; it < LN_MAXV; ++it) {
+        const int c = lane * 4 + it * 256;
+        if (c < W) {
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = rs * (g[it][e] - c1 - xh[it][e] * c2);
+            store4(d_patch + (long)prow * lddp + c, o);
+        }
+    }
+}
+
+template <typename T>
+int embed_lnpre_bwd(const float* dx0, long lddx, const float* patch_out, long ldp, const float* cls,
+                    const float* pos, const float* gamma, const float* mean, const float* rstd,
+                    T* d_patch, long lddp, int B, int S, int W, hipStream_t s) {
+    (void)cls;
+    if (W % 4 != 0 || W > LN_MAXV * 256) return fail(RVLM_ERR_UNSUPPORTED, "embed: width");
+    hipLaunchKernelGGL((embed_lnpre_bwd_kernel<float, T>), dim3(cdiv((long)B * (S - 1), 4)),
+                       dim3(256), 0, s, dx0, lddx, patch_out, ldp, pos, gamma, mean, rstd, d_patch,
+                       lddp, B, S, W);
+    RVLM_CHECK_LAUNCH();
+    return RVLM_OK;
+}
+template int embed_lnpre_bwd<float>(const float*, long, const float*, long, const float*,
+                                    const float*, const float*, const float*, const float*, float*,
+                                    long, int, int, int, hipStream_t);
+template int embed_lnpre_bwd<bf16_t>(const float*, long, const float*, long, const float*,
+                                     const float*, const float*, const float*, const float*,
+                                     bf16_t*, long, int, int, int, hipStream_t);
+
+// =============================================================================================
+// F.normalize(dim=-1) forward / backward (…clip.py:255-256), one wave per sample
+// =============================================================================================
+__global__ void __launch_bounds__(256)
+l2norm_fwd_kernel(const float* __restrict__ e, float* __restrict__ out, float* __restrict__ inv_norm,
+                  int B, int D) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B) return;
+    float q = 0.0f;
+    for (int c = lane; c < D; c += 64) { float v = e[(long)row * D + c]; q = fmaf(v, v, q); }
+    const float nrm = fmaxf(sqrtf(wave_sum(q)), 1e-12f);
+    if (lane == 0) inv_norm[row] = 1.0f / nrm;
+    for (int c = lane; c < D; c += 64) out[(long)row * D + c] = e[(long)row * D + c] / nrm;
+}
+__global__ void __launch_bounds__(256)
+l2norm_bwd_kernel(const float* __restrict__ d_out, const float* __restrict__ e_raw,
+                  const float* __restrict__ inv_norm, float* __restrict__ d_raw, int B, int D) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B) return;
+    const float inv = inv_norm[row];
+    float dot = 0.0f;
+    for (int c = lane; c < D; c += 64)
+        dot = fmaf(e_raw[(long)row * D + c] * inv, d_out[(long)row * D + c], dot);
+    dot = wave_sum(dot);
+    for (int c = lane; c < D; c += 64) {
+        const float eh = e_raw[(long)row * D + c] * inv;
+        d_raw[(long)row * D + c] = (d_out[(long)row * D + c] - eh * dot) * inv;
+    }
+}
+int l2_normalize_fwd(const float* e, float* out, float* inv_norm, int B, int D, hipStream_t s) {
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, e, out, inv_norm, B, D);
+    RVLM_CHECK_LAUNCH();
+    return RVLM_OK;
+}
+int l2_normalize_bwd(const float* d_out, const float* e_raw, const float* inv_norm, float* d_raw,
+                     int B, int D, hipStream_t s) {
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, d_out, e_raw, inv_norm,
+                       d_raw, B, D);
+    RVLM_CHECK_LAUNCH();
+    return RVLM_OK;
+}
+
+// =============================================================================================
+// Softmax over rows (fp32 attention path, scores materialised), one wave per row, in place
+// =============================================================================================
+__global__ void __launch_bounds__(256) softmax_fwd_kernel(float* __restrict__ s, long rows, int cols) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float* r = s + row * cols;
+    float m = -INFINITY;
+    for (int c = lane; c < cols; c += 64) m = fmaxf(m, r[c]);
+    m = wave_max(m);
+    float sum = 0.0f;
+    for (int c = lane; c < cols; c += 64) { float e = expf(r[c] - m); r[c] = e; sum += e; }
+    sum = wave_sum(sum);
+    for (int c = lane; c < cols; c += 64) r[c] = r[c] / sum;
+}
+__global__ void __launch_bounds__(256)
+softmax_bwd_kernel(const float* __restrict__ p, float* __restrict__ dp, long rows, int cols,
+                   float scale) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* pr = p + row * cols;
+    float* dr = dp + row * cols;
+    float dot = 0.0f;
+    for (int c = lane; c < cols; c += 64) dot = fmaf(pr[c], dr[c], dot);
+    dot = wave_sum(dot);
+    for (int c = lane; c < cols; c += 64) dr[c] = pr[c] * (dr[c] - dot) * scale;
+}
+int softmax_rows_fwd(float* s, long rows, int cols, hipStream_t st) {
+    hipLaunchKernelGGL(softmax_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, s, rows, cols);
+    RVLM_CHECK_LAUNCH();
+    return RVLM_OK;
+}
+int softmax_rows_bwd(const float* p, float* dp, long rows, int cols, float scale, hipStream_t st) {
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, p, dp, rows, cols,
+                       scale);
+    RVLM_CHECK_LAUNCH();
+    return RVLM_OK;
+}
+
+// =============================================================================================
+// misc
+// =============================================================================================
+__global__ void __launch_bounds__(256)
+convert_kernel(const float* __restrict__ src, long lds_, bf16_t* __restrict__ dst, long ldd,
+               int rows, int cols, int transpose) {
+    const long total = (long)rows * cols;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        if (!transpose) {
+            const long r = idx / cols, c = idx - r * cols;
+            dst[r * ldd + c] = (bf16_t)src[r * lds_ + c];
+        } else {  // write-coalesced: dst[c, r]
+            const long c = idx / rows, r = idx - c * rows;
+            dst[c * ldd + r] = (bf16_t)src[r * lds_ + c];
+        }
+    }
+}
+int convert_f32_to_bf16(const float* src, long lds_, bf16_t* dst, long ldd, int rows, int cols,
+                        int transpose, hipStream_t s) {
+    const long total = (long)rows * cols;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 256 * 16) grid = 256 * 16;
+    hipLaunchKernelGGL(convert_kernel, dim3(grid), dim3(256), 0, s, src, lds_, dst, ldd, rows, cols,
+                       transpose);
+    RVLM_CHECK_LAUNCH();
+    return RVLM_OK;
+}
+
+__global__ void __launch_bounds__(256)
+scale_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t n, float alpha) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = alpha * src[i];
+}
+int scale_copy_f32(const float* src, float* dst, size_t n, float alpha, hipStream_t s) {
+    int grid = (int)((n + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(scale_copy_kernel, dim3(grid), dim3(256), 0, s, src, dst, n, alpha);
+    RVLM_CHECK_LAUNCH();
+    return RVLM_OK;
+}
+__global__ void __launch_bounds__(256) fill_kernel(float* __restrict__ dst, size_t n, float v) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = v;
+}
+int fill_f32(float* dst, size_t n, float v, hipStream_t s) {
+    int grid = (int)((n + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(fill_kernel, dim3(grid), dim3(256), 0, s, dst, n, v);
+    RVLM_CHECK_LAUNCH();
+    return RVLM_OK;
+}
+
+}  // namespace rvlm

@@ -1,0 +1,202 @@
+"""Python handle of the native ViT forward + input-gradient engine (rvlm_vit in include/rvlm.h)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from .config import VitConfig, CONFIGS, CLIP_MEAN, CLIP_STD, state_dict_shapes
+
+
+def _require_cuda(t: torch.Tensor, name: str):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise L.RvlmError(f"{name} must be a CUDA (ROCm) tensor: the robustvlm_amd path runs on the "
+                          f"MI355X HIP kernels only and has no CPU fallback")
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().to(torch.float32).contiguous()
+
+
+class VitEngine:
+    """Owns a ``rvlm_vit`` handle: converted weights + a workspace sized for ``max_batch`` images.
+
+    precision: 'bf16' (MFMA throughput path) or 'fp32' (parity path, config C1)."""
+
+    def __init__(self, cfg, state_dict: dict, precision: str = "bf16", max_batch: int = 128,
+                 mean=CLIP_MEAN, std=CLIP_STD, device=None):
+        if isinstance(cfg, str):
+            cfg = CONFIGS[cfg]
+        if not torch.cuda.is_available():
+            raise L.RvlmError("no ROCm device visible: robustvlm_amd needs an MI355X (no CPU fallback)")
+        self.lib = L.load()
+        self.cfg = cfg
+        self.precision = precision
+        self.max_batch = int(max_batch)
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.mean, self.std = tuple(float(v) for v in mean), tuple(float(v) for v in std)
+        self.generation = 0
+        self._h = C.c_void_p()
+        c = L.VitConfigC()
+        c.image_size, c.patch, c.width, c.layers = cfg.image_size, cfg.patch, cfg.width, cfg.layers
+        c.heads, c.out_dim = cfg.heads, cfg.out_dim
+        c.act = L.ACT_QUICK_GELU if cfg.act == "quick_gelu" else L.ACT_GELU
+        c.precision = L.PREC_BF16 if precision == "bf16" else L.PREC_F32
+        if precision not in ("bf16", "fp32"):
+            raise ValueError(f"precision {precision!r} not supported")
+        c.max_batch = self.max_batch
+        c.mean = (C.c_float * 3)(*self.mean)
+        c.std = (C.c_float * 3)(*self.std)
+        with torch.cuda.device(self.device):
+            w, keep = self._weights_struct(state_dict)
+            L.check(self.lib.rvlm_vit_create(C.byref(c), C.byref(w), L.stream_ptr(), C.byref(self._h)),
+                    "rvlm_vit_create")
+        del keep
+
+    # ---- weights ------------------------------------------------------------------------------
+    def _weights_struct(self, sd: dict):
+        cfg = self.cfg
+        shapes = state_dict_shapes(cfg)
+        keep = {}
+        for k, shp in shapes.items():
+            if k not in sd:
+                raise KeyError(f"state_dict is missing {k!r}")
+            t = _f32c(sd[k]).to(self.device)
+            if tuple(t.shape) != tuple(shp):
+                raise ValueError(f"{k}: shape {tuple(t.shape)} != {tuple(shp)}")
+            keep[k] = t
+        w = L.VitWeightsC()
+        for f in L.TOP_FIELDS:
+            setattr(w, f, keep[L.TOP_KEYS[f]].data_ptr())
+        blocks = (L.BlockWeightsC * cfg.layers)()
+        for i in range(cfg.layers):
+            for f in L.BLOCK_FIELDS:
+                setattr(blocks[i], f, keep[f"transformer.resblocks.{i}.{L.BLOCK_KEYS[f]}"].data_ptr())
+        w.blocks_host = C.cast(blocks, C.POINTER(L.BlockWeightsC))
+        keep["__blocks__"] = blocks
+        return w, keep
+
+    def load_state_dict(self, state_dict: dict):
+        """Re-import weights (e.g. after an optimizer step of the outer trainer)."""
+        with torch.cuda.device(self.device):
+            w, keep = self._weights_struct(state_dict)
+            L.check(self.lib.rvlm_vit_load_weights(self._h, C.byref(w), L.stream_ptr()))
+            torch.cuda.current_stream().synchronize()
+        del keep
+
+    # ---- forward / backward --------------------------------------------------------------------
+    def _check_images(self, x):
+        _require_cuda(x, "vision")
+        c = self.cfg
+        if x.dim() != 4 or tuple(x.shape[1:]) != (3, c.image_size, c.image_size):
+            raise ValueError(f"expected [B,3,{c.image_size},{c.image_size}] images, got {tuple(x.shape)}")
+        if x.shape[0] > self.max_batch:
+            raise ValueError(f"batch {x.shape[0]} exceeds the engine's max_batch {self.max_batch}")
+
+    def forward(self, x, delta=None, output_normalize=False, save=False) -> torch.Tensor:
+        self._check_images(x)
+        x = _f32c(x)
+        d = _f32c(delta) if delta is not None else None
+        B = x.shape[0]
+        out = torch.empty(B, self.cfg.out_dim, device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            L.check(self.lib.rvlm_vit_forward(self._h, x.data_ptr(), L.ptr(d), B, int(bool(output_normalize)),
+                                              int(bool(save)), out.data_ptr(), L.stream_ptr()),
+                    "rvlm_vit_forward")
+        if save:
+            self.generation += 1
+        return out
+
+    def backward_input(self, d_emb) -> torch.Tensor:
+        _require_cuda(d_emb, "d_emb")
+        d = _f32c(d_emb)
+        B = d.shape[0]
+        c = self.cfg
+        g = torch.empty(B, 3, c.image_size, c.image_size, device=d.device, dtype=torch.float32)
+        with torch.cuda.device(d.device):
+            L.check(self.lib.rvlm_vit_backward_input(self._h, d.data_ptr(), B, g.data_ptr(), L.stream_ptr()),
+                    "rvlm_vit_backward_input")
+        return g
+
+    # ---- fused loops -----------------------------------------------------------------------------
+    def _loss_spec(self, loss_kind, reduction, output_normalize, ref, targets, logit_scale):
+        ls = L.LossSpecC()
+        ls.loss_kind = {"l2": L.LOSS_L2, "ce": L.LOSS_CE}[loss_kind]
+        ls.reduction = {"mean": L.RED_MEAN, "none": L.RED_NONE}[reduction]
+        ls.output_normalize = int(bool(output_normalize))
+        ls.logit_scale = float(logit_scale)
+        ls.ref = ref.data_ptr()
+        ls.n_classes = int(ref.shape[1]) if loss_kind == "ce" else 0
+        ls.targets = targets.data_ptr() if targets is not None else None
+        return ls
+
+    def pgd_run(self, x, delta0, loss_kind, reduction, ref, targets, output_normalize, eps, iterations,
+                stepsize, momentum, mode, logit_scale=100.0, want_trace=False):
+        """Whole pgd() loop on the device (rvlm_pgd_run).  Returns (x_adv, flags:int, loss_trace|None)."""
+        self._check_images(x)
+        x = _f32c(x)
+        d0 = _f32c(delta0) if delta0 is not None else None
+        ref = _f32c(ref)
+        tg = targets.detach().to(torch.int64).contiguous() if isinstance(targets, torch.Tensor) else None
+        ls = self._loss_spec(loss_kind, reduction, output_normalize, ref, tg, logit_scale)
+        out = torch.empty_like(x)
+        flags = torch.zeros(1, dtype=torch.int32, device=x.device)
+        trace = torch.zeros(max(iterations, 1), dtype=torch.float32, device=x.device) if want_trace else None
+        with torch.cuda.device(x.device):
+            L.check(self.lib.rvlm_pgd_run(self._h, x.data_ptr(), L.ptr(d0), x.shape[0], C.byref(ls), float(eps),
+                                          int(iterations), float(stepsize), float(momentum),
+                                          1 if mode == "max" else 0, out.data_ptr(), L.ptr(trace),
+                                          flags.data_ptr(), L.stream_ptr()), "rvlm_pgd_run")
+        self.generation += 1
+        return out, flags, trace
+
+    def apgd_run(self, x, x_init, loss_kind, ref, targets, output_normalize, eps, n_iter, step0,
+                 train_variant, logits_from_head, logit_scale=100.0, want_extra=False):
+        """Whole APGD Linf loop on the device (rvlm_apgd_run)."""
+        self._check_images(x)
+        x = _f32c(x)
+        xi = _f32c(x_init) if x_init is not None else None
+        ref = _f32c(ref)
+        tg = targets.detach().to(torch.int64).contiguous()
+        ls = self._loss_spec(loss_kind, "none", output_normalize, ref, tg, logit_scale)
+        B = x.shape[0]
+        x_best_adv = torch.empty_like(x)
+        x_best = torch.empty_like(x) if want_extra else None
+        loss_best = torch.empty(B, dtype=torch.float32, device=x.device) if want_extra else None
+        acc = torch.empty(B, dtype=torch.uint8, device=x.device) if want_extra else None
+        with torch.cuda.device(x.device):
+            L.check(self.lib.rvlm_apgd_run(self._h, x.data_ptr(), L.ptr(xi), B, C.byref(ls), float(eps),
+                                           int(n_iter), float(step0), int(bool(train_variant)),
+                                           int(bool(logits_from_head)), x_best_adv.data_ptr(), L.ptr(x_best),
+                                           L.ptr(loss_best), L.ptr(acc), L.stream_ptr()), "rvlm_apgd_run")
+        self.generation += 1
+        return x_best_adv, x_best, loss_best, acc
+
+    # ---- measurement -----------------------------------------------------------------------------
+    def set_profiling(self, on: bool):
+        L.check(self.lib.rvlm_vit_set_profiling(self._h, int(bool(on))))
+
+    def reset_profile(self):
+        L.check(self.lib.rvlm_vit_reset_profile(self._h))
+
+    def get_profile(self) -> dict:
+        n = C.c_int(64)
+        arr = (L.ProfileEntryC * 64)()
+        L.check(self.lib.rvlm_vit_get_profile(self._h, arr, C.byref(n)))
+        return {arr[i].name.decode(): dict(ms=arr[i].total_ms, flops=arr[i].flops, bytes=arr[i].bytes,
+                                           launches=arr[i].launches) for i in range(n.value)}
+
+    def workspace_bytes(self) -> int:
+        return int(self.lib.rvlm_vit_workspace_bytes(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.rvlm_vit_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

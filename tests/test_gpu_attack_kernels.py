@@ -1,0 +1,162 @@
+"""Bit-exact parity of the L-inf attack kernels with the oracle (C restatement) and the reference's
+own outputs (golden vectors): sign / momentum / step / project / clamp index arithmetic."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import linf_c
+from oracle.attacks_ref import _fwd_bwd
+from robustvlm_amd import _lib as L
+import robustvlm_amd as R
+from tests.gpu_helpers import dev, st, lib
+from tests.helpers import load_golden, SmallNet, InjectGrad
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+
+
+def _cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+
+
+@pytest.mark.parametrize("mode", ["max", "min"])
+def test_pgd_update_kernel_vs_golden(mode):
+    l = lib()
+    z = load_golden(f"pgd_linf_elementwise_{mode}.npz")
+    x = _cu(z["x"]); delta = _cu(z["delta0"]); vel = torch.zeros_like(x)
+    flags = torch.zeros(1, dtype=torch.int32, device=dev())
+    xadv = torch.zeros_like(x)
+    for i in range(4):
+        g = _cu(z["grads"][i])
+        L.check(l.rvlm_pgd_linf_update(x.data_ptr(), g.data_ptr(), delta.data_ptr(), vel.data_ptr(), x.numel(),
+                                       float(z["eps"]), float(z["stepsize"]), 0.9, int(mode == "max"),
+                                       xadv.data_ptr(), flags.data_ptr(), st()))
+        torch.cuda.synchronize()
+        assert np.array_equal(xadv.cpu().numpy(), z["xadv"][i]), f"step {i}"
+    assert int(flags.item()) == L.FLAG_NAN_GRAD      # NaNs were present (zeroed), nothing else tripped
+
+
+@pytest.mark.parametrize("n", [1, 63, 4096, 150528 * 3 + 1])
+def test_pgd_update_kernel_vs_c_oracle_random(n):
+    l = lib()
+    rng = np.random.default_rng(n)
+    x = rng.random(n, dtype=F32)
+    g = rng.standard_normal(n).astype(F32)
+    g[rng.random(n) < 0.1] = 0.0
+    g[rng.random(n) < 0.01] = np.nan
+    delta = rng.uniform(-4 / 255, 4 / 255, n).astype(F32)
+    vel = np.sign(rng.standard_normal(n)).astype(F32)
+    eps, step = 4 / 255, 1 / 255
+    dx, dg, dd, dv = _cu(x), _cu(g), _cu(delta), _cu(vel)
+    for it in range(3):
+        linf_c.pgd_linf_update(x, g, delta, vel, eps, step, 0.9, "max")
+        L.check(l.rvlm_pgd_linf_update(dx.data_ptr(), dg.data_ptr(), dd.data_ptr(), dv.data_ptr(), n, eps, step,
+                                       0.9, 1, None, None, st()))
+        torch.cuda.synchronize()
+        assert np.array_equal(dd.cpu().numpy(), delta) and np.array_equal(dv.cpu().numpy(), vel)
+    assert np.abs(delta).max() <= F32(eps)
+
+
+def test_range_flags():
+    l = lib()
+    x = torch.rand(1000, device=dev())
+    flags = torch.zeros(1, dtype=torch.int32, device=dev())
+    L.check(l.rvlm_check_image_range(x.data_ptr(), 1000, flags.data_ptr(), st()))
+    assert int(flags.item()) == 0
+    x[17] = 1.5
+    L.check(l.rvlm_check_image_range(x.data_ptr(), 1000, flags.data_ptr(), st()))
+    assert int(flags.item()) == L.FLAG_INPUT_RANGE
+
+
+@pytest.mark.parametrize("n_iter", [10, 50, 100])
+def test_apgd_kernels_vs_golden(n_iter):
+    """HIP step/controller/select kernels driven by CPU-evaluated losses: reproduces the reference's
+    apgd_train iterates bit for bit (apgd_train_smallnet_*.npz)."""
+    l = lib()
+    z = load_golden(f"apgd_train_smallnet_{n_iter}.npz")
+    net = SmallNet(torch.from_numpy(z["w1"]), torch.from_numpy(z["w2"])).eval()
+    ce = lambda lg, yy: torch.nn.functional.cross_entropy(lg, yy, reduction="none")  # noqa: E731
+    call = lambda t: net(t, output_normalize=True)  # noqa: E731
+    x = np.ascontiguousarray(z["x"]); y = torch.from_numpy(z["y"])
+    B = x.shape[0]; npix = x[0].size; eps = float(z["eps"])
+    from robustvlm_amd.apgd_train import apgd_schedule
+    k, n_iter_min, size_decr = apgd_schedule(n_iter)
+    x_adv_h = np.clip(x, F32(0), F32(1))
+    logits, loss, grad_h = _fwd_bwd(call, ce, x_adv_h, y)
+    dx = _cu(x); x_adv = _cu(x_adv_h); x_old = x_adv.clone(); x_best = x_adv.clone(); x_best_adv = x_adv.clone()
+    grad = _cu(grad_h); grad_best = grad.clone()
+    loss_best = _cu(loss); loss_best_lc = loss_best.clone(); reduced_lc = torch.ones(B, device=dev())
+    step = torch.full((B,), float(F32(2.0 * eps)), device=dev())
+    acc = _cu((logits.max(1)[1] == y).numpy().astype(np.uint8))
+    loss_steps = torch.zeros(n_iter, B, device=dev())
+    f0 = torch.zeros(B, dtype=torch.uint8, device=dev()); f1 = f0.clone(); f2 = f0.clone()
+    counter3 = 0
+    assert np.array_equal(x_adv.cpu().numpy(), z["iterates"][0])
+    for i in range(n_iter):
+        L.check(l.rvlm_apgd_linf_step(dx.data_ptr(), x_adv.data_ptr(), x_old.data_ptr(), grad.data_ptr(),
+                                      step.data_ptr(), 0.75 if i > 0 else 1.0, eps, npix, B, st()))
+        torch.cuda.synchronize()
+        xa = x_adv.cpu().numpy()
+        assert np.array_equal(xa, z["iterates"][i + 1]), f"iterate {i + 1}"
+        last = i == n_iter - 1
+        logits, loss, g = _fwd_bwd(call, ce, xa, y, need_grad=not last)
+        if not last:
+            grad.copy_(_cu(g))
+        pred = _cu((logits.max(1)[1] == y).numpy().astype(np.uint8))
+        dl = _cu(loss)
+        counter3 += 1
+        do_check = int(counter3 == k)
+        L.check(l.rvlm_apgd_controller(i, B, n_iter, k, do_check, dl.data_ptr(), pred.data_ptr(),
+                                       loss_steps.data_ptr(), loss_best.data_ptr(), loss_best_lc.data_ptr(),
+                                       reduced_lc.data_ptr(), step.data_ptr(), acc.data_ptr(), f0.data_ptr(),
+                                       f1.data_ptr(), f2.data_ptr(), st()))
+        L.check(l.rvlm_apgd_select(x_adv.data_ptr(), grad.data_ptr(), x_best.data_ptr(), grad_best.data_ptr(),
+                                   x_best_adv.data_ptr(), f0.data_ptr(), f1.data_ptr(), f2.data_ptr(), npix, B,
+                                   st()))
+        if do_check:
+            counter3 = 0
+            k = max(k - size_decr, n_iter_min)
+    torch.cuda.synchronize()
+    assert np.array_equal(x_best_adv.cpu().numpy(), z["x_best_adv"])
+
+
+def test_random_start_kernel():
+    l = lib()
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(3, 3, 8, 8, generator=g)
+    t = 2 * torch.rand(x.shape, generator=g) - 1
+    eps = 4 / 255
+    tmax = t.abs().view(3, -1).max(1)[0].view(-1, 1, 1, 1)
+    ref = x + eps * torch.ones_like(x) * (t / (tmax + 1e-12))
+    out = torch.zeros_like(x, device=dev())
+    L.check(l.rvlm_linf_random_start(x.to(dev()).data_ptr(), t.to(dev()).data_ptr(), eps, 192, 3,
+                                     out.data_ptr(), st()))
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), ref.numpy())
+
+
+@pytest.mark.parametrize("mode", ["max", "min"])
+def test_generic_pgd_injected_gradients_bit_exact(mode):
+    """The public pgd() (generic route: torch autograd + HIP update kernel) against the reference's
+    own output for prescribed gradients."""
+    z = load_golden(f"pgd_linf_elementwise_{mode}.npz")
+    grads = [_cu(z["grads"][i]) for i in range(4)]
+    it = iter(range(4))
+    out = R.pgd(lambda v, output_normalize=False: v, lambda o, t: InjectGrad.apply(o, grads[next(it)]),
+                _cu(z["x"]), None, "linf", float(z["eps"]), 4, float(z["stepsize"]), False,
+                perturbation=_cu(z["delta0"]).requires_grad_(True), mode=mode)
+    assert np.array_equal(out.cpu().numpy(), z["xadv"][3])
+
+
+def test_pgd_error_behaviour():
+    x = torch.rand(2, 3, 4, 4, device=dev())
+    f = lambda v, output_normalize=False: v.flatten(1)  # noqa: E731
+    lf = lambda o, t: o.sum()  # noqa: E731
+    with pytest.raises(ValueError):
+        R.pgd(f, lf, x, None, "linf", 4 / 255, 1, 1 / 255, False, mode="sideways")
+    with pytest.raises(NotImplementedError):
+        R.pgd(f, lf, x, None, "l7", 4 / 255, 1, 1 / 255, False, mode="max")
+    with pytest.raises(AssertionError):
+        R.pgd(f, lf, x + 2.0, None, "linf", 4 / 255, 1, 1 / 255, False, mode="max")
+    with pytest.raises(L.RvlmError):
+        R.pgd(f, lf, x.cpu(), None, "linf", 4 / 255, 1, 1 / 255, False, mode="max")   # no CPU fallback

@@ -1,0 +1,164 @@
+"""Kernel-level parity of the HIP building blocks (through include/rvlm_kernels.h)."""
+import numpy as np
+import pytest
+import torch
+
+from robustvlm_amd import _lib as L
+from tests.gpu_helpers import (dev, st, lib, cos_sim, rel_max, gemm_bf16, act_ref, dact_ref, attn_ref)
+
+pytestmark = pytest.mark.gpu
+
+
+def test_library_is_the_in_tree_hip_build():
+    l = lib()
+    assert l.rvlm_version() == 100
+    assert L.LIB_PATH.endswith("robustvlm_amd/librvlm.so")
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (257, 192, 128), (1028, 3072, 1024), (300, 640, 256),
+                                   (64, 64, 64), (514, 1024, 4096)])
+def test_gemm_bf16_plain(M, N, K):
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g, device=dev()).bfloat16()
+    Bw = (torch.randn(N, K, generator=g, device=dev()) * K ** -0.5).bfloat16()
+    bias = torch.randn(N, generator=g, device=dev())
+    ref = A.double() @ Bw.double().t() + bias.double()
+    out, _ = gemm_bf16(A, Bw, epi=4, bias=bias)          # fp32 out: only accumulation-order error
+    assert rel_max(out, ref) < 2e-5, "transpose / fragment-layout bug"
+    outb, _ = gemm_bf16(A, Bw, epi=0, bias=bias)
+    assert rel_max(outb.float(), ref) < 1e-2
+
+
+@pytest.mark.parametrize("act", [0, 1])
+def test_gemm_bf16_epilogues(act):
+    M, N, K = 385, 512, 256
+    g = torch.Generator(device="cuda").manual_seed(7)
+    A = torch.randn(M, K, generator=g, device=dev()).bfloat16()
+    Bw = (torch.randn(N, K, generator=g, device=dev()) * K ** -0.5).bfloat16()
+    bias = torch.randn(N, generator=g, device=dev())
+    res = torch.randn(M, N, generator=g, device=dev())
+    acc = A.double() @ Bw.double().t()
+    out, _ = gemm_bf16(A, Bw, epi=1, bias=bias, residual=res)
+    assert rel_max(out, acc + bias.double() + res.double()) < 2e-5
+    out, pre = gemm_bf16(A, Bw, epi=2, bias=bias, act=act)
+    h = acc + bias.double()
+    assert rel_max(pre.float(), h) < 1e-2
+    assert rel_max(out.float(), act_ref(h, act)) < 1.5e-2
+    hp = torch.randn(M, N, generator=g, device=dev()).bfloat16()
+    out, _ = gemm_bf16(A, Bw, epi=3, h_pre=hp, act=act)
+    assert rel_max(out.float(), acc * dact_ref(hp.double(), act)) < 1.5e-2
+
+
+def test_gemm_f32_strided():
+    l = lib()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    M, N, K = 70, 130, 50
+    A = torch.randn(M, K, generator=g, device=dev())
+    Bt = torch.randn(K, N, generator=g, device=dev())       # (n, k) at k*N + n
+    C = torch.zeros(M, N, device=dev())
+    L.check(l.rvlm_k_gemm_f32(A.data_ptr(), K, 1, Bt.data_ptr(), 1, N, C.data_ptr(), N, 1, M, N, K, 0.5,
+                              None, st()))
+    torch.cuda.synchronize()
+    assert rel_max(C, 0.5 * (A.double() @ Bt.double())) < 1e-6
+    At = A.t().contiguous()                                 # (m, k) at k*M + m
+    Bn = Bt.t().contiguous()                                # (n, k) at n*K + k
+    L.check(l.rvlm_k_gemm_f32(At.data_ptr(), 1, M, Bn.data_ptr(), K, 1, C.data_ptr(), N, 1, M, N, K, 1.0,
+                              None, st()))
+    torch.cuda.synchronize()
+    assert rel_max(C, A.double() @ Bt.double()) < 1e-6
+
+
+def test_ds_read_tr16_semantics():
+    """Pins the LDS transpose-read the attention kernels rely on: within a 16-lane group, lanes
+    4j..4j+3 supply the 8-byte chunks of row j of a 4x16 block and lane i receives column i."""
+    l = lib()
+    src = torch.arange(2048, dtype=torch.int16, device=dev())            # value = element index
+    src_bf = src.view(torch.bfloat16)
+    offs = torch.zeros(64, dtype=torch.int32)
+    row_stride = 128                                                      # elements
+    for lane in range(64):
+        grp, i = lane >> 4, lane & 15
+        offs[lane] = 2 * ((grp * 4 + (i >> 2)) * row_stride + (i & 3) * 4)
+    out = torch.zeros(256, dtype=torch.int16, device=dev())
+    L.check(l.rvlm_k_probe_tr16(src_bf.data_ptr(), offs.to(dev()).data_ptr(), out.data_ptr(), st()))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().reshape(64, 4)
+    exp = np.zeros((64, 4), dtype=np.int16)
+    for lane in range(64):
+        grp, i = lane >> 4, lane & 15
+        for j in range(4):
+            exp[lane, j] = (grp * 4 + j) * row_stride + i
+    assert np.array_equal(got, exp), f"ds_read_b64_tr_b16 layout differs:\n{got[:20]}\nexpected\n{exp[:20]}"
+
+
+@pytest.mark.parametrize("use_tr", [1, 0])
+@pytest.mark.parametrize("B,H,S", [(2, 1, 17), (3, 2, 50), (2, 4, 257), (1, 2, 577)])
+def test_attention_bf16_fwd_bwd(B, H, S, use_tr):
+    l = lib()
+    l.rvlm_k_attn_set_use_tr(use_tr)
+    try:
+        W = H * 64
+        g = torch.Generator(device="cuda").manual_seed(B * 100 + S)
+        qkv = torch.randn(B * S, 3 * W, generator=g, device=dev()).bfloat16()
+        d_o = torch.randn(B * S, W, generator=g, device=dev()).bfloat16()
+        Sp = (S + 31) // 32 * 32
+        o = torch.zeros(B * S, W, dtype=torch.bfloat16, device=dev())
+        lse = torch.zeros(B * H * Sp, device=dev())
+        L.check(l.rvlm_k_attn_fwd_bf16(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), B, H, S, st()))
+        torch.cuda.synchronize()
+        qd = qkv.double().requires_grad_(True)
+        ref = attn_ref(qd, B, H, S)
+        assert rel_max(o.float(), ref.detach()) < 2e-2
+        assert cos_sim(o.float(), ref.detach()) > 0.9999
+        (gref,) = torch.autograd.grad((ref * d_o.double()).sum(), qd)
+        dqkv = torch.zeros_like(qkv)
+        dsum = torch.zeros(B * H * Sp, device=dev())
+        L.check(l.rvlm_k_attn_bwd_bf16(qkv.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(),
+                                       dsum.data_ptr(), dqkv.data_ptr(), B, H, S, st()))
+        torch.cuda.synchronize()
+        for name, sl in (("dq", slice(0, W)), ("dk", slice(W, 2 * W)), ("dv", slice(2 * W, 3 * W))):
+            c = cos_sim(dqkv[:, sl].float(), gref[:, sl])
+            r = rel_max(dqkv[:, sl].float(), gref[:, sl])
+            assert c > 0.999 and r < 5e-2, f"{name}: cos {c} rel {r}"
+    finally:
+        l.rvlm_k_attn_set_use_tr(1)
+
+
+def test_attention_forced_large_scores():
+    """Online-softmax rescale path: one key dominates a query late in the sequence."""
+    l = lib()
+    B, H, S = 1, 1, 257
+    g = torch.Generator(device="cuda").manual_seed(11)
+    qkv = torch.randn(S, 192, generator=g, device=dev())
+    qkv[5, 0:64] = 6.0 * qkv[250, 64:128]          # q_5 . k_250 >> others (last key tile)
+    qkv = qkv.bfloat16()
+    o = torch.zeros(S, 64, dtype=torch.bfloat16, device=dev())
+    lse = torch.zeros(288, device=dev())
+    L.check(l.rvlm_k_attn_fwd_bf16(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), B, H, S, st()))
+    torch.cuda.synchronize()
+    ref = attn_ref(qkv, B, H, S)
+    assert rel_max(o.float(), ref) < 2e-2
+
+
+@pytest.mark.parametrize("M,W", [(37, 64), (50, 768), (257, 1024), (9, 128)])
+def test_layernorm_f32(M, W):
+    l = lib()
+    g = torch.Generator(device="cuda").manual_seed(M + W)
+    x = torch.randn(M, W, generator=g, device=dev()) * 3 + 1
+    gm = 1 + 0.1 * torch.randn(W, generator=g, device=dev())
+    bt = 0.1 * torch.randn(W, generator=g, device=dev())
+    dy = torch.randn(M, W, generator=g, device=dev())
+    y = torch.zeros_like(x)
+    mean = torch.zeros(M, device=dev())
+    rstd = torch.zeros(M, device=dev())
+    L.check(l.rvlm_k_layernorm_fwd_f32(x.data_ptr(), gm.data_ptr(), bt.data_ptr(), y.data_ptr(),
+                                       mean.data_ptr(), rstd.data_ptr(), M, W, st()))
+    xd = x.double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xd, (W,), gm.double(), bt.double(), 1e-5)
+    (gx,) = torch.autograd.grad((ref * dy.double()).sum(), xd)
+    dres = torch.ones_like(x)
+    L.check(l.rvlm_k_layernorm_bwd_f32(dy.data_ptr(), x.data_ptr(), gm.data_ptr(), mean.data_ptr(),
+                                       rstd.data_ptr(), dres.data_ptr(), 1, M, W, st()))
+    torch.cuda.synchronize()
+    assert rel_max(y, ref.detach()) < 1e-5
+    assert rel_max(dres - 1, gx) < 1e-4
