@@ -124,6 +124,7 @@ _SIGS = {
     "rvlm_k_attn_bwd_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_f32p, c_f32p,
                                        C.c_void_p, C.c_int, C.c_int, C.c_int, c_stream]),
     "rvlm_k_attn_set_use_tr": (C.c_int, [C.c_int]),
+    "rvlm_k_gemm_set_variant": (C.c_int, [C.c_int]),
     "rvlm_k_layernorm_fwd_f32": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int,
                                            C.c_int, c_stream]),
     "rvlm_k_layernorm_bwd_f32": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int,

@@ -104,15 +104,15 @@ struct ProfScope {
         if (!h->prof) return;
         ProfRec r;
         r.cls = prof_class(h, name);
-        hipEventCreate(&r.a); hipEventCreate(&r.b);
-        hipEventRecord(r.a, s);
+        (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b);
+        (void)hipEventRecord(r.a, s);
         h->recs.push_back(r);
         idx = (int)h->recs.size() - 1;
         h->accs[r.cls].flops += flops;
         h->accs[r.cls].bytes += bytes;
         h->accs[r.cls].n += 1;
     }
-    ~ProfScope() { if (idx >= 0) hipEventRecord(h->recs[idx].b, s); }
+    ~ProfScope() { if (idx >= 0) (void)hipEventRecord(h->recs[idx].b, s); }
 };
 #define PROF(name, flops, bytes) ProfScope _ps(h, s, name, (double)(flops), (double)(bytes))
 
@@ -604,9 +604,9 @@ extern "C" int rvlm_vit_create(const rvlm_vit_config* cfg, const rvlm_vit_weight
 
 extern "C" int rvlm_vit_destroy(rvlm_vit* h) {
     if (!h) return RVLM_OK;
-    hipDeviceSynchronize();
-    for (auto& r : h->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
-    for (void* p : h->allocs) hipFree(p);
+    (void)hipDeviceSynchronize();
+    for (auto& r : h->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (void* p : h->allocs) (void)hipFree(p);
     delete h;
     return RVLM_OK;
 }
@@ -750,8 +750,8 @@ extern "C" int rvlm_vit_set_profiling(rvlm_vit* h, int enabled) {
 }
 extern "C" int rvlm_vit_reset_profile(rvlm_vit* h) {
     RVLM_REQUIRE(h, "rvlm_vit_reset_profile: null handle");
-    hipDeviceSynchronize();
-    for (auto& r : h->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    (void)hipDeviceSynchronize();
+    for (auto& r : h->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     h->recs.clear();
     for (auto& a : h->accs) a = ProfAcc();
     return RVLM_OK;

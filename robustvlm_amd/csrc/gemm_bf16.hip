@@ -162,13 +162,19 @@ gemm_bf16_nt_kernel(GemmBf16 p, int tiles_m, int tiles_n, int a_rows) {
     }
 }
 
-int gemm_bf16_nt(const GemmBf16& p, hipStream_t s) {
-    if (!p.A || !p.Bw || !p.out || p.M <= 0 || p.N <= 0 || p.K <= 0)
-        return fail(RVLM_ERR_ARG, "gemm_bf16_nt: bad arguments");
-    if (p.K % GB_K != 0 || p.N % 4 != 0 || p.lda % 8 != 0 || p.ldb % 8 != 0 || p.ldo % 4 != 0)
-        return fail(RVLM_ERR_UNSUPPORTED, "gemm_bf16_nt: need K%64==0, N%4==0, lda/ldb%8==0, ldo%4==0");
-    if (p.epi == EPI_BF16_ACT && !p.out_pre) return fail(RVLM_ERR_ARG, "gemm_bf16_nt: out_pre");
-    if (p.epi == EPI_BF16_DACT && !p.h_pre) return fail(RVLM_ERR_ARG, "gemm_bf16_nt: h_pre");
+int gemm_bf16_nt_256(const GemmBf16& p, int* rows_done, hipStream_t s);
+
+static int g_gemm_variant = -1;   // 0: 128x128 kernel only; 1: 256x256 kernel + 128x128 on the remainder rows
+void gemm_set_variant(int v) { g_gemm_variant = v; }
+static int gemm_variant() {
+    if (g_gemm_variant < 0) {
+        const char* e = getenv("RVLM_GEMM_VARIANT");
+        g_gemm_variant = e ? atoi(e) : 0;
+    }
+    return g_gemm_variant;
+}
+
+static int gemm_bf16_nt_128(const GemmBf16& p, hipStream_t s) {
     const int tiles_m = cdiv(p.M, GB_M), tiles_n = cdiv(p.N, GB_N);
     const int a_rows = p.a_rows > 0 ? p.a_rows : p.M;
     dim3 grid(tiles_m * tiles_n), block(256);
@@ -193,6 +199,33 @@ int gemm_bf16_nt(const GemmBf16& p, hipStream_t s) {
     }
     RVLM_CHECK_LAUNCH();
     return RVLM_OK;
+}
+
+int gemm_bf16_nt(const GemmBf16& p, hipStream_t s) {
+    if (!p.A || !p.Bw || !p.out || p.M <= 0 || p.N <= 0 || p.K <= 0)
+        return fail(RVLM_ERR_ARG, "gemm_bf16_nt: bad arguments");
+    if (p.K % GB_K != 0 || p.N % 4 != 0 || p.lda % 8 != 0 || p.ldb % 8 != 0 || p.ldo % 4 != 0)
+        return fail(RVLM_ERR_UNSUPPORTED, "gemm_bf16_nt: need K%64==0, N%4==0, lda/ldb%8==0, ldo%4==0");
+    if (p.epi == EPI_BF16_ACT && !p.out_pre) return fail(RVLM_ERR_ARG, "gemm_bf16_nt: out_pre");
+    if (p.epi == EPI_BF16_DACT && !p.h_pre) return fail(RVLM_ERR_ARG, "gemm_bf16_nt: h_pre");
+    int done = 0;
+    if (gemm_variant() == 1) {
+        int rc = gemm_bf16_nt_256(p, &done, s);
+        if (rc) return rc;
+        if (done >= p.M) return RVLM_OK;
+    }
+    GemmBf16 r = p;
+    if (done > 0) {   // remainder rows [done, M) on the 128x128 kernel
+        const bool f32out = (p.epi == EPI_F32_RESID || p.epi == EPI_F32);
+        r.A = p.A + (long)done * p.lda;
+        r.out = (char*)p.out + (long)done * p.ldo * (f32out ? 4 : 2);
+        if (p.out_pre) r.out_pre = p.out_pre + (long)done * p.ldo;
+        if (p.h_pre) r.h_pre = p.h_pre + (long)done * p.ldo;
+        if (p.residual) r.residual = p.residual + (long)done * p.ldo;
+        r.M = p.M - done;
+        r.a_rows = (p.a_rows > 0 ? p.a_rows : p.M) - done;
+    }
+    return gemm_bf16_nt_128(r, s);
 }
 
 }  // namespace rvlm

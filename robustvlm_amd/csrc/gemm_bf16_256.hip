@@ -1,0 +1,200 @@
+// bf16 MFMA GEMM, large-tile variant for gfx950: 256x256 block tile, BK = 32, 8 waves (2 x 4, each a
+// 128x64 sub-tile = 4x2 v_mfma_f32_32x32x16_bf16), 4-stage LDS ring (4 x 32 KiB = 128 KiB, one
+// workgroup per CU) filled by global_load_lds_dwordx4 with COUNTED vmcnt: two K-steps of DMA stay
+// in flight across the single raw s_barrier per K-step (never drained to 0 in the main loop).
+//
+// Why 256x256: at 128x128 every CU pulls (128+128)*2 B per 128*128*2 FLOP*k => ~39 TB/s of L2 traffic
+// at the MFMA peak, above the measured ~34 TB/s aggregate L2 bandwidth; 256x256 halves that.
+// LDS rows are 64 B (BK bf16); the 16-B chunk index is XOR-swizzled with (row>>2)&3 so a 16-lane
+// ds_read_b128 group covers all 16 slots of the 256-B bank row.  The swizzle is applied to the
+// per-lane GLOBAL source address (the DMA writes LDS lane-linearly).
+//
+// Requirements: M % 256 == 0 rows handled here (the caller runs the 128x128 kernel on the remainder
+// rows), N % 256 == 0, K % 32 == 0.
+#include "kernels.h"
+
+namespace rvlm {
+
+constexpr int L_M = 256, L_N = 256, L_K = 32, L_STAGES = 4;
+constexpr int L_OPER_BYTES = L_M * L_K * 2;        // 16 KiB per operand per stage
+constexpr int L_STAGE_BYTES = 2 * L_OPER_BYTES;    // 32 KiB
+
+__device__ __forceinline__ void glds16b(const void* gptr, void* lds_ptr) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                     (__attribute__((address_space(3))) void*)lds_ptr, 16, 0, 0);
+}
+
+template <int EPI>
+__global__ void __launch_bounds__(512)
+gemm_bf16_nt_256_kernel(GemmBf16 p, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int nwg = gridDim.x, pid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = pid & 7, loc = pid >> 3;
+    const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+    const int group_size = 8 * tiles_n;
+    const int first_m = (t / group_size) * 8;
+    const int gm = min(tiles_m - first_m, 8);
+    const int tm = first_m + (t % group_size) % gm;
+    const int tn = (t % group_size) / gm;
+    const int m0 = tm * L_M, n0 = tn * L_N;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 2, wn = w & 3;
+
+    // ---- staging: wave w loads rows [32w, 32w+32) of both operand tiles, 16 rows (1 KiB) per DMA ----
+    const bf16_t* a_src[2];
+    const bf16_t* b_src[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = w * 32 + j * 16 + (lane >> 2);
+        const int clog = (lane & 3) ^ ((r >> 2) & 3);
+        a_src[j] = p.A + (long)(m0 + r) * p.lda + clog * 8;
+        b_src[j] = p.Bw + (long)(n0 + r) * p.ldb + clog * 8;
+    }
+    const int stage_wave_off = (w * 32) * 64;
+
+    // ---- fragment offsets ----
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int swz = (l31 >> 2) & 3;
+    int koff[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) koff[kk] = ((kk * 2 + hi) ^ swz) << 4;
+    const int a_row_off = (wm * 128 + l31) * 64;
+    const int b_row_off = L_OPER_BYTES + (wn * 64 + l31) * 64;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int nk = p.K / L_K;
+    auto issue = [&](int kt) {
+        char* dst = lds + (kt & (L_STAGES - 1)) * L_STAGE_BYTES + stage_wave_off;
+        const int ko = kt * L_K;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            glds16b(a_src[j] + ko, dst + j * 1024);
+            glds16b(b_src[j] + ko, dst + L_OPER_BYTES + j * 1024);
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < L_STAGES - 1; ++s)
+        if (s < nk) issue(s);
+
+    for (int kt = 0; kt < nk; ++kt) {
+        // retire stage kt (4 DMAs per stage per wave); leave the younger stages in flight
+        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + L_STAGES - 1 < nk) issue(kt + L_STAGES - 1);   // refills the slot read in step kt-1
+        const char* st = lds + (kt & (L_STAGES - 1)) * L_STAGE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 a[4], b[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = *(const bf16x8*)(st + a_row_off + i * 32 * 64 + koff[kk]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = *(const bf16x8*)(st + b_row_off + j * 32 * 64 + koff[kk]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue (lane owns 4 consecutive columns of row m) ----
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int m = m0 + wm * 128 + mi * 32 + l31;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wn * 64 + ni * 32 + 8 * g + 4 * hi;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][g * 4 + e];
+                if (p.bias) {
+                    const float4 bv = *(const float4*)(p.bias + n);
+                    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+                }
+                const long o = (long)m * p.ldo + n;
+                if (EPI == EPI_BF16) {
+                    bf16x4 ov;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ov[e] = (bf16_t)v[e];
+                    *(bf16x4*)((bf16_t*)p.out + o) = ov;
+                } else if (EPI == EPI_F32_RESID) {
+                    if (p.residual) {
+                        const float4 rv = *(const float4*)(p.residual + o);
+                        v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+                    }
+                    *(float4*)((float*)p.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+                } else if (EPI == EPI_BF16_ACT) {
+                    bf16x4 pv, ov;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        pv[e] = (bf16_t)v[e];
+                        ov[e] = (bf16_t)act_fwd(v[e], p.act);
+                    }
+                    *(bf16x4*)(p.out_pre + o) = pv;
+                    *(bf16x4*)((bf16_t*)p.out + o) = ov;
+                } else if (EPI == EPI_BF16_DACT) {
+                    const bf16x4 hv = *(const bf16x4*)(p.h_pre + o);
+                    bf16x4 ov;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ov[e] = (bf16_t)(v[e] * act_bwd((float)hv[e], p.act));
+                    *(bf16x4*)((bf16_t*)p.out + o) = ov;
+                } else {
+                    *(float4*)((float*)p.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+    }
+}
+
+template <int EPI>
+static int launch_256(const GemmBf16& p, int tiles_m, int tiles_n, hipStream_t s) {
+    static bool attr_set = false;
+    const size_t lds_bytes = (size_t)L_STAGES * L_STAGE_BYTES;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel<EPI>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return fail(RVLM_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_bf16_nt_256_kernel<EPI>), dim3(tiles_m * tiles_n), dim3(512), lds_bytes, s, p,
+                       tiles_m, tiles_n);
+    RVLM_CHECK_LAUNCH();
+    return RVLM_OK;
+}
+
+// rows [0, 256*floor(M/256)) of the problem; returns the number of rows it covered in *rows_done
+int gemm_bf16_nt_256(const GemmBf16& p, int* rows_done, hipStream_t s) {
+    *rows_done = 0;
+    if (p.M < L_M || p.N % L_N != 0 || p.K % L_K != 0 || p.K < L_K) return RVLM_OK;
+    GemmBf16 q = p;
+    const int tiles_m = p.M / L_M, tiles_n = p.N / L_N;
+    q.M = tiles_m * L_M;
+    int rc;
+    switch (p.epi) {
+        case EPI_BF16: rc = launch_256<EPI_BF16>(q, tiles_m, tiles_n, s); break;
+        case EPI_F32_RESID: rc = launch_256<EPI_F32_RESID>(q, tiles_m, tiles_n, s); break;
+        case EPI_BF16_ACT: rc = launch_256<EPI_BF16_ACT>(q, tiles_m, tiles_n, s); break;
+        case EPI_BF16_DACT: rc = launch_256<EPI_BF16_DACT>(q, tiles_m, tiles_n, s); break;
+        case EPI_F32: rc = launch_256<EPI_F32>(q, tiles_m, tiles_n, s); break;
+        default: return fail(RVLM_ERR_ARG, "gemm_bf16_nt_256: unknown epilogue");
+    }
+    if (rc) return rc;
+    *rows_done = q.M;
+    return RVLM_OK;
+}
+
+}  // namespace rvlm

@@ -5,6 +5,7 @@
 
 namespace rvlm {
 void attn_set_use_tr(int on);
+void gemm_set_variant(int v);
 
 __global__ void probe_tr16_kernel(const bf16_t* __restrict__ src, const int32_t* __restrict__ offs,
                                   bf16_t* __restrict__ out) {
@@ -48,6 +49,7 @@ extern "C" int rvlm_k_attn_bwd_bf16(const uint16_t* qkv, const uint16_t* o, cons
                          lse2, dsum_scratch, (bf16_t*)dqkv, 3L * H * 64, B, H, S, (hipStream_t)stream);
 }
 extern "C" int rvlm_k_attn_set_use_tr(int on) { attn_set_use_tr(on); return RVLM_OK; }
+extern "C" int rvlm_k_gemm_set_variant(int v) { gemm_set_variant(v); return RVLM_OK; }
 extern "C" int rvlm_k_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y,
                                         float* mean, float* rstd, int M, int W, rvlm_stream_t stream) {
     return layernorm_fwd<float>(x, W, gamma, beta, y, W, mean, rstd, M, W, (hipStream_t)stream);

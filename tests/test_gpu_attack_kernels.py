@@ -129,8 +129,8 @@ def test_random_start_kernel():
     tmax = t.abs().view(3, -1).max(1)[0].view(-1, 1, 1, 1)
     ref = x + eps * torch.ones_like(x) * (t / (tmax + 1e-12))
     out = torch.zeros_like(x, device=dev())
-    L.check(l.rvlm_linf_random_start(x.to(dev()).data_ptr(), t.to(dev()).data_ptr(), eps, 192, 3,
-                                     out.data_ptr(), st()))
+    xd, td = x.to(dev()), t.to(dev())          # keep the device copies alive across the launch
+    L.check(l.rvlm_linf_random_start(xd.data_ptr(), td.data_ptr(), eps, 192, 3, out.data_ptr(), st()))
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy(), ref.numpy())
 
@@ -160,3 +160,67 @@ def test_pgd_error_behaviour():
         R.pgd(f, lf, x + 2.0, None, "linf", 4 / 255, 1, 1 / 255, False, mode="max")
     with pytest.raises(L.RvlmError):
         R.pgd(f, lf, x.cpu(), None, "linf", 4 / 255, 1, 1 / 255, False, mode="max")   # no CPU fallback
+
+
+@pytest.mark.parametrize("n_iter", [10, 50, 100])
+def test_apgd_kernels_vs_c_oracle_state_by_state(n_iter):
+    """Synthetic losses / predictions / gradients: every state array of the HIP controller+select+step
+    kernels must equal the C oracle's after every iteration (pinpoints the first divergence)."""
+    l = lib()
+    rng = np.random.default_rng(n_iter)
+    B, npix, eps = 7, 3 * 8 * 8, 8 / 255
+    x = rng.random((B, npix), dtype=F32)
+    from robustvlm_amd.apgd_train import apgd_schedule
+    k, n_iter_min, size_decr = apgd_schedule(n_iter)
+    x_adv = x.copy(); x_old = x.copy(); x_best = x.copy(); x_best_adv = x.copy()
+    grad = rng.standard_normal((B, npix)).astype(F32); grad_best = grad.copy()
+    loss0 = rng.random(B, dtype=F32)
+    pred0 = (rng.random(B) < 0.7).astype(np.uint8)
+    stc = linf_c.ApgdStateC(n_iter, loss0, np.full(B, F32(2.0 * eps), F32), pred0)
+    d = {n: _cu(a) for n, a in dict(x=x, x_adv=x_adv, x_old=x_old, x_best=x_best, x_best_adv=x_best_adv, grad=grad,
+                                   grad_best=grad_best, loss_best=loss0, loss_best_lc=loss0,
+                                   reduced_lc=np.ones(B, F32), step=np.full(B, F32(2.0 * eps), F32), acc=pred0).items()}
+    d["loss_steps"] = torch.zeros(n_iter, B, device=dev())
+    for f in ("f0", "f1", "f2"):
+        d[f] = torch.zeros(B, dtype=torch.uint8, device=dev())
+    counter3 = 0
+    loss = loss0.copy()
+    for i in range(n_iter):
+        a = 0.75 if i > 0 else 1.0
+        linf_c.apgd_linf_step(x, x_adv, x_old, grad, stc.step, a, eps)
+        L.check(l.rvlm_apgd_linf_step(d["x"].data_ptr(), d["x_adv"].data_ptr(), d["x_old"].data_ptr(),
+                                      d["grad"].data_ptr(), d["step"].data_ptr(), a, eps, npix, B, st()))
+        # slowly saturating noisy loss so that improvements, plateaus and oscillations all occur
+        loss = (loss + rng.standard_normal(B).astype(F32) * F32(0.3 / (1 + i)) + F32(0.02)).astype(F32)
+        if i % 7 == 3:
+            loss[i % B] = stc.loss_best[i % B]           # exact tie with the best
+        pred = (rng.random(B) < 0.6).astype(np.uint8)
+        if i < n_iter - 1:
+            g = rng.standard_normal((B, npix)).astype(F32)
+            grad[...] = g
+            d["grad"].copy_(_cu(g))
+        dl, dp = _cu(loss), _cu(pred)
+        counter3 += 1
+        do_check = int(counter3 == k)
+        stc.update(i, loss, pred, x_adv, grad, x_best, grad_best, x_best_adv)
+        L.check(l.rvlm_apgd_controller(i, B, n_iter, k, do_check, dl.data_ptr(), dp.data_ptr(),
+                                       d["loss_steps"].data_ptr(), d["loss_best"].data_ptr(),
+                                       d["loss_best_lc"].data_ptr(), d["reduced_lc"].data_ptr(), d["step"].data_ptr(),
+                                       d["acc"].data_ptr(), d["f0"].data_ptr(), d["f1"].data_ptr(), d["f2"].data_ptr(), st()))
+        L.check(l.rvlm_apgd_select(d["x_adv"].data_ptr(), d["grad"].data_ptr(), d["x_best"].data_ptr(),
+                                   d["grad_best"].data_ptr(), d["x_best_adv"].data_ptr(), d["f0"].data_ptr(),
+                                   d["f1"].data_ptr(), d["f2"].data_ptr(), npix, B, st()))
+        torch.cuda.synchronize()
+        if do_check:
+            counter3 = 0
+            k = max(k - size_decr, n_iter_min)
+        ref = dict(x_adv=x_adv, x_old=x_old, x_best=x_best, x_best_adv=x_best_adv, grad=grad, grad_best=grad_best,
+                   loss_best=stc.loss_best, loss_best_lc=stc.loss_best_last_check, reduced_lc=stc.reduced_last_check,
+                   step=stc.step, acc=stc.acc, f0=stc.f_notpred, f1=stc.f_improved, f2=stc.f_reduced,
+                   loss_steps=stc.loss_steps)
+        for name, r in ref.items():
+            got = d[name].cpu().numpy().reshape(r.shape)
+            if not np.array_equal(got, r):
+                bad = np.argwhere(got != r)[:5]
+                raise AssertionError(f"iteration {i} (do_check={do_check}, k={k}): {name} differs at {bad.tolist()} "
+                                     f"got {got[tuple(bad[0])]} want {r[tuple(bad[0])]}")

@@ -195,7 +195,8 @@ def test_full_size_properties_vit_l14_bf16():
     xb = R.pgd(model, wrap, x, None, "linf", eps, 10, step, False, perturbation=d0.clone(), mode="max")
     assert torch.equal(xa, xb), "not deterministic"
     d = (xa - x)
-    assert float(d.abs().max()) <= float(np.float32(eps)) and float(xa.min()) >= 0 and float(xa.max()) <= 1
+    # (x+delta)-x is evaluated in fp32: allow one ulp of the O(1) pixel values on top of float32(eps)
+    assert float(d.abs().max()) <= float(np.float32(eps)) + 1.2e-7 and float(xa.min()) >= 0 and float(xa.max()) <= 1
     assert float((d.abs() >= np.float32(eps) * 0.999).float().mean()) > 0.3
     l0 = float(wrap(model(x + d0.clamp(-eps, eps), False), None))
     l1 = float(wrap(model(xa, False), None))

@@ -15,9 +15,16 @@ def test_library_is_the_in_tree_hip_build():
     assert L.LIB_PATH.endswith("robustvlm_amd/librvlm.so")
 
 
+@pytest.fixture(params=[0, 1], ids=["gemm128", "gemm256"])
+def gemm_variant(request):
+    lib().rvlm_k_gemm_set_variant(request.param)
+    yield request.param
+    lib().rvlm_k_gemm_set_variant(-1)
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (257, 192, 128), (1028, 3072, 1024), (300, 640, 256),
-                                   (64, 64, 64), (514, 1024, 4096)])
-def test_gemm_bf16_plain(M, N, K):
+                                   (64, 64, 64), (514, 1024, 4096), (256, 256, 64), (1285, 768, 3072)])
+def test_gemm_bf16_plain(M, N, K, gemm_variant):
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
     A = torch.randn(M, K, generator=g, device=dev()).bfloat16()
     Bw = (torch.randn(N, K, generator=g, device=dev()) * K ** -0.5).bfloat16()
@@ -30,8 +37,8 @@ def test_gemm_bf16_plain(M, N, K):
 
 
 @pytest.mark.parametrize("act", [0, 1])
-def test_gemm_bf16_epilogues(act):
-    M, N, K = 385, 512, 256
+def test_gemm_bf16_epilogues(act, gemm_variant):
+    M, N, K = 641, 512, 256
     g = torch.Generator(device="cuda").manual_seed(7)
     A = torch.randn(M, K, generator=g, device=dev()).bfloat16()
     Bw = (torch.randn(N, K, generator=g, device=dev()) * K ** -0.5).bfloat16()
