@@ -49,13 +49,15 @@ def cpu_baseline(iterations_full=10):
     from oracle import vit_ref as V
     from oracle.attacks_ref import pgd_ref
     from oracle.losses_ref import ComputeLossWrapperRef
-    cores = os.cpu_count() or 1
+    # 32 threads: the small-M GEMMs of a 2-image batch do not scale past that (256 threads on the
+    # GPU box's 2x64-core host was 50x SLOWER than 32: oversubscribed OpenMP teams on 514-row matmuls)
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     cfg = V.VIT_L_14
     w = V.init_weights(cfg, seed=0)
     model = V.ClipVisionModelRef(cfg, w).eval()
     g = torch.Generator().manual_seed(0)
-    B, iters = 2, 2
+    B, iters = 2, 1
     x = torch.rand(B, 3, 224, 224, generator=g)
     eps = 4 / 255
     d0 = torch.zeros_like(x).uniform_(-eps, eps, generator=g)
@@ -68,7 +70,8 @@ def cpu_baseline(iterations_full=10):
     per_call_full = dt * iterations_full / iters
     return {"value": B / per_call_full, "unit": "adversarial images/sec", "cores": cores, "kind": "port",
             "sample": f"oracle pgd_ref (torch {torch.__version__} CPU fp32, {cores} threads): ViT-L/14, batch {B}, "
-                      f"{iters} of {iterations_full} PGD iterations timed ({dt:.1f} s) and scaled x{iterations_full // iters}"}
+                      f"{iters} of {iterations_full} PGD iterations timed ({dt:.1f} s) and scaled x{iterations_full // iters}; "
+                      f"host has {os.cpu_count()} hardware threads"}
 
 
 def main():

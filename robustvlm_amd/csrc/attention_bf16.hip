@@ -28,15 +28,19 @@ __device__ __forceinline__ int swz_off(int row, int chunk) {  // byte offset ins
     return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
-// cooperative stage of rows [0,Sp) x 64 bf16 from global (row stride ld elements) into a swizzled tile;
-// rows >= S are zero-filled.
+// cooperative stage of rows [0,Sp) x 64 bf16 from global (row stride ld elements) into a swizzled tile
+// by LDS-DMA (global_load_lds_dwordx4: 8 rows = 1 KiB per wave instruction, asynchronous, no VGPR
+// round trip).  The DMA writes LDS lane-linearly, so the swizzle goes on the per-lane source address.
+// Rows >= S replicate row S-1 (finite data); every consumer masks them (scores -> -inf / p = 0).
 __device__ __forceinline__ void stage_tile(char* tile, const bf16_t* src, long ld, int S, int Sp,
-                                           int tid, int nthreads) {
-    for (int idx = tid; idx < Sp * 8; idx += nthreads) {
-        const int r = idx >> 3, c = idx & 7;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (r < S) v = *(const uint4*)(src + (long)r * ld + c * 8);
-        *(uint4*)(tile + swz_off(r, c)) = v;
+                                           int w, int nw, int lane) {
+    for (int blk = w; blk < (Sp >> 3); blk += nw) {
+        const int row = blk * 8 + (lane >> 3);
+        const int lc = (lane & 7) ^ ((row >> 1) & 7);
+        const int rs = min(row, S - 1);
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(src + (long)rs * ld + lc * 8),
+            (__attribute__((address_space(3))) void*)(tile + blk * 1024), 16, 0, 0);
     }
 }
 
@@ -101,7 +105,7 @@ __device__ __forceinline__ f32x16 zero16() {
 // forward
 // =============================================================================================
 template <bool USE_TR>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(576)
 attn_fwd_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict__ o, long ldo,
                 float* __restrict__ lse2, int H, int S, int Sp, int W, float scale_log2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -111,8 +115,8 @@ attn_fwd_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict__ o,
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const bf16_t* base = qkv + (long)b * S * ld + h * 64;
-    stage_tile(Kt, base + W, ld, S, Sp, tid, blockDim.x);
-    stage_tile(Vt, base + 2 * W, ld, S, Sp, tid, blockDim.x);
+    stage_tile(Kt, base + W, ld, S, Sp, w, nw, lane);
+    stage_tile(Vt, base + 2 * W, ld, S, Sp, w, nw, lane);
     __syncthreads();
 
     const int ntiles = Sp / 32;
@@ -199,7 +203,7 @@ attn_bwd_prep_kernel(const bf16_t* __restrict__ o, long ldo, const bf16_t* __res
 // backward dQ: wave owns a query tile, K and V LDS-resident
 // =============================================================================================
 template <bool USE_TR>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(576)
 attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __restrict__ d_o, long lddo,
                    const float* __restrict__ lse2, const float* __restrict__ dsum,
                    bf16_t* __restrict__ dqkv, long lddq, int H, int S, int Sp, int W, float scale,
@@ -211,8 +215,8 @@ attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __rest
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const bf16_t* base = qkv + (long)b * S * ld + h * 64;
-    stage_tile(Kt, base + W, ld, S, Sp, tid, blockDim.x);
-    stage_tile(Vt, base + 2 * W, ld, S, Sp, tid, blockDim.x);
+    stage_tile(Kt, base + W, ld, S, Sp, w, nw, lane);
+    stage_tile(Vt, base + 2 * W, ld, S, Sp, w, nw, lane);
     __syncthreads();
 
     const int ntiles = Sp / 32;
@@ -271,23 +275,30 @@ attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __rest
 // =============================================================================================
 // backward dK, dV: wave owns a key tile, Q and dO LDS-resident
 // =============================================================================================
-template <bool USE_TR>
-__global__ void __launch_bounds__(256)
+template <bool USE_TR, bool KV_LDS>
+__global__ void __launch_bounds__(576)
 attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __restrict__ d_o, long lddo,
                     const float* __restrict__ lse2, const float* __restrict__ dsum,
                     bf16_t* __restrict__ dqkv, long lddq, int H, int S, int Sp, int W, float scale,
                     float scale_log2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // LDS: Q | dO | [K | V when KV_LDS] | lse2 | D
     char* Qt = smem;
     char* Dt = smem + (size_t)Sp * 128;
-    float* Ls = (float*)(smem + (size_t)Sp * 256);
+    char* Kt = smem + (size_t)Sp * 256;
+    char* Vt = smem + (size_t)Sp * 384;
+    float* Ls = (float*)(smem + (size_t)Sp * (KV_LDS ? 512 : 256));
     float* Ds = Ls + Sp;
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const bf16_t* base = qkv + (long)b * S * ld + h * 64;
-    stage_tile(Qt, base, ld, S, Sp, tid, blockDim.x);
-    stage_tile(Dt, d_o + (long)b * S * lddo + h * 64, lddo, S, Sp, tid, blockDim.x);
+    stage_tile(Qt, base, ld, S, Sp, w, nw, lane);
+    stage_tile(Dt, d_o + (long)b * S * lddo + h * 64, lddo, S, Sp, w, nw, lane);
+    if (KV_LDS) {
+        stage_tile(Kt, base + W, ld, S, Sp, w, nw, lane);
+        stage_tile(Vt, base + 2 * W, ld, S, Sp, w, nw, lane);
+    }
     for (int i = tid; i < Sp; i += blockDim.x) {
         Ls[i] = (i < S) ? lse2[((long)b * H + h) * Sp + i] : INFINITY;   // pad rows -> p = 0
         Ds[i] = (i < S) ? dsum[((long)b * H + h) * Sp + i] : 0.0f;
@@ -299,20 +310,24 @@ attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __res
         const int key = kt * 32 + l31;
         const int kc = min(key, S - 1);
         bf16x8 kf[4], vf[4];
+        if (!KV_LDS) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            kf[kk] = frag_global(base + W, ld, kc, kk, lane);
-            vf[kk] = frag_global(base + 2 * W, ld, kc, kk, lane);
+            for (int kk = 0; kk < 4; ++kk) {
+                kf[kk] = frag_global(base + W, ld, kc, kk, lane);
+                vf[kk] = frag_global(base + 2 * W, ld, kc, kk, lane);
+            }
         }
         f32x16 dk[2] = {zero16(), zero16()}, dv[2] = {zero16(), zero16()};
         for (int qt = 0; qt < ntiles; ++qt) {
             f32x16 s = zero16(), dp = zero16();
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                s = MFMA(frag_rowmajor(Qt, qt * 32, kk, lane), kf[kk], s);     // S[q][key]
-                dp = MFMA(frag_rowmajor(Dt, qt * 32, kk, lane), vf[kk], dp);   // dP[q][key]
+                const bf16x8 kb = KV_LDS ? frag_rowmajor(Kt, kt * 32, kk, lane) : kf[kk];
+                const bf16x8 vb = KV_LDS ? frag_rowmajor(Vt, kt * 32, kk, lane) : vf[kk];
+                s = MFMA(frag_rowmajor(Qt, qt * 32, kk, lane), kb, s);     // S[q][key]
+                dp = MFMA(frag_rowmajor(Dt, qt * 32, kk, lane), vb, dp);   // dP[q][key]
+                __builtin_amdgcn_sched_barrier(0);   // bound the live fragment set (3 waves/SIMD budget)
             }
-            f32x16 ds;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float4 lq = *(const float4*)(Ls + qt * 32 + 8 * g + 4 * hi);
@@ -322,18 +337,19 @@ attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __res
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float p = exp2f(s[g * 4 + e] * scale_log2 - lqa[e]);
-                    s[g * 4 + e] = p;
-                    ds[g * 4 + e] = p * (dp[g * 4 + e] - dqa[e]);
+                    s[g * 4 + e] = p;                                   // P   (in place)
+                    dp[g * 4 + e] = p * (dp[g * 4 + e] - dqa[e]);       // dS  (in place)
                 }
             }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8 pb = pack_b(s, ks), db = pack_b(ds, ks);
+                const bf16x8 pb = pack_b(s, ks), db = pack_b(dp, ks);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
                     dv[dt] = MFMA(frag_transposed<USE_TR>(Dt, qt * 32 + ks * 16, dt, lane), pb, dv[dt]);
                     dk[dt] = MFMA(frag_transposed<USE_TR>(Qt, qt * 32 + ks * 16, dt, lane), db, dk[dt]);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (key < S) {
@@ -361,10 +377,8 @@ static bool g_use_tr = true;
 void attn_set_use_tr(int on) { g_use_tr = on != 0; }
 
 static int attn_block_threads(int ntiles) {
-    // 9 tiles (S=257) split evenly over 3 waves; otherwise up to 4 waves
-    if (ntiles % 3 == 0) return 192;
-    if (ntiles >= 4) return 256;
-    return ntiles * 64;
+    // one 32-row tile per wave, up to 9 waves (S = 257 -> 9 tiles -> 576 threads, perfectly balanced)
+    return (ntiles < 9 ? ntiles : 9) * 64;
 }
 
 template <typename K>
@@ -404,25 +418,28 @@ int attn_bwd_bf16(const bf16_t* qkv, long ldqkv, const bf16_t* o, long ldo, cons
     hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(B * S), dim3(256), 0, s, o, ldo, d_o, lddo,
                        dsum_scratch, H, S, Sp);
     RVLM_CHECK_LAUNCH();
-    const size_t lds_q = (size_t)Sp * 256, lds_kv = (size_t)Sp * 256 + (size_t)Sp * 8;
+    const size_t lds_q = (size_t)Sp * 256;
+    const bool kv_lds = ((size_t)Sp * 520 <= 160 * 1024);     // Q, dO, K, V all LDS-resident (S <= 315)
+    const size_t lds_kv = kv_lds ? (size_t)Sp * 520 : (size_t)Sp * 264;
     int rc;
-    if (g_use_tr) {
-        if ((rc = set_lds(attn_bwd_dq_kernel<true>, lds_q))) return rc;
-        if ((rc = set_lds(attn_bwd_dkv_kernel<true>, lds_kv))) return rc;
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<true>), dim3(B * H), dim3(nt), lds_q, s, qkv, ldqkv, d_o,
-                           lddo, lse, dsum_scratch, dqkv, lddqkv, H, S, Sp, W, scale, sl2);
-        RVLM_CHECK_LAUNCH();
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<true>), dim3(B * H), dim3(nt), lds_kv, s, qkv, ldqkv, d_o,
-                           lddo, lse, dsum_scratch, dqkv, lddqkv, H, S, Sp, W, scale, sl2);
-    } else {
-        if ((rc = set_lds(attn_bwd_dq_kernel<false>, lds_q))) return rc;
-        if ((rc = set_lds(attn_bwd_dkv_kernel<false>, lds_kv))) return rc;
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<false>), dim3(B * H), dim3(nt), lds_q, s, qkv, ldqkv, d_o,
-                           lddo, lse, dsum_scratch, dqkv, lddqkv, H, S, Sp, W, scale, sl2);
-        RVLM_CHECK_LAUNCH();
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<false>), dim3(B * H), dim3(nt), lds_kv, s, qkv, ldqkv, d_o,
-                           lddo, lse, dsum_scratch, dqkv, lddqkv, H, S, Sp, W, scale, sl2);
-    }
+#define LAUNCH_BWD(TR)                                                                                         \
+    do {                                                                                                        \
+        if ((rc = set_lds(attn_bwd_dq_kernel<TR>, lds_q))) return rc;                                          \
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<TR>), dim3(B * H), dim3(nt), lds_q, s, qkv, ldqkv, d_o, lddo,   \
+                           lse, dsum_scratch, dqkv, lddqkv, H, S, Sp, W, scale, sl2);                          \
+        RVLM_CHECK_LAUNCH();                                                                                    \
+        if (kv_lds) {                                                                                           \
+            if ((rc = set_lds(attn_bwd_dkv_kernel<TR, true>, lds_kv))) return rc;                              \
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<TR, true>), dim3(B * H), dim3(nt), lds_kv, s, qkv, ldqkv,  \
+                               d_o, lddo, lse, dsum_scratch, dqkv, lddqkv, H, S, Sp, W, scale, sl2);           \
+        } else {                                                                                                \
+            if ((rc = set_lds(attn_bwd_dkv_kernel<TR, false>, lds_kv))) return rc;                             \
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<TR, false>), dim3(B * H), dim3(nt), lds_kv, s, qkv, ldqkv, \
+                               d_o, lddo, lse, dsum_scratch, dqkv, lddqkv, H, S, Sp, W, scale, sl2);           \
+        }                                                                                                       \
+    } while (0)
+    if (g_use_tr) LAUNCH_BWD(true); else LAUNCH_BWD(false);
+#undef LAUNCH_BWD
     RVLM_CHECK_LAUNCH();
     return RVLM_OK;
 }
