@@ -12,6 +12,7 @@
 // consecutive output columns of one row -> 8/16-byte epilogue accesses.  Workgroup ids are remapped
 // XCD-aware (each XCD's L2 sees a contiguous group of tiles) with GROUP_M=8 tile grouping.
 #include "kernels.h"
+#include "gemm_epilogue.h"
 
 namespace rvlm {
 
@@ -25,7 +26,7 @@ __device__ __forceinline__ void glds16(const void* gptr, void* lds_ptr) {
 
 template <int EPI>
 __global__ void __launch_bounds__(256)
-gemm_bf16_nt_kernel(GemmBf16 p, int tiles_m, int tiles_n, int a_rows) {
+gemm_bf16_nt_kernel(GemmBf16 p, int tiles_m, int tiles_n, int a_rows, int desync) {
     __shared__ __attribute__((aligned(16))) char lds[4 * GB_TILE_BYTES];
 
     // ---- XCD-aware, grouped tile order ----------------------------------------------------
@@ -41,6 +42,13 @@ gemm_bf16_nt_kernel(GemmBf16 p, int tiles_m, int tiles_n, int a_rows) {
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w >> 1, wn = w & 1;
+
+    // ---- phase offset (performance only): co-resident workgroups otherwise run in lockstep, so their
+    // epilogue store bursts and pipeline fills coincide chip-wide instead of hiding under the partner's
+    // MFMA phase.  Half of the first wave of workgroups starts `desync` x 3.4 us late.
+    if (desync > 0 && pid < 2 * 256 && ((pid >> 3) & 1)) {
+        for (int i = 0; i < desync; ++i) __builtin_amdgcn_s_sleep(127);
+    }
 
     // ---- staging: wave w loads rows [32w, 32w+32) of both operand tiles, 8 rows per DMA ----
     const int srow = lane >> 3, cphys = lane & 7;
@@ -109,90 +117,54 @@ gemm_bf16_nt_kernel(GemmBf16 p, int tiles_m, int tiles_n, int a_rows) {
         }
     }
 
-    // ---- epilogue ------------------------------------------------------------------------------
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        const int m = m0 + wm * 64 + mi * 32 + l31;
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = n0 + wn * 64 + ni * 32 + 8 * g + 4 * hi;
-                if (n >= p.N) continue;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][g * 4 + e];
-                if (p.bias) {
-                    const float4 bv = *(const float4*)(p.bias + n);
-                    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-                }
-                const long o = (long)m * p.ldo + n;
-                if (EPI == EPI_BF16) {
-                    bf16x4 ov;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) ov[e] = (bf16_t)v[e];
-                    *(bf16x4*)((bf16_t*)p.out + o) = ov;
-                } else if (EPI == EPI_F32_RESID) {
-                    if (p.residual) {
-                        const float4 rv = *(const float4*)(p.residual + o);
-                        v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
-                    }
-                    *(float4*)((float*)p.out + o) = make_float4(v[0], v[1], v[2], v[3]);
-                } else if (EPI == EPI_BF16_ACT) {
-                    bf16x4 pv, ov;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        pv[e] = (bf16_t)v[e];
-                        ov[e] = (bf16_t)act_fwd(v[e], p.act);
-                    }
-                    *(bf16x4*)(p.out_pre + o) = pv;
-                    *(bf16x4*)((bf16_t*)p.out + o) = ov;
-                } else if (EPI == EPI_BF16_DACT) {
-                    const bf16x4 hv = *(const bf16x4*)(p.h_pre + o);
-                    bf16x4 ov;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) ov[e] = (bf16_t)(v[e] * act_bwd((float)hv[e], p.act));
-                    *(bf16x4*)((bf16_t*)p.out + o) = ov;
-                } else {  // EPI_F32
-                    *(float4*)((float*)p.out + o) = make_float4(v[0], v[1], v[2], v[3]);
-                }
-            }
-        }
-    }
+    // ---- epilogue (wave-private LDS transpose -> full-line global accesses) ----
+    __syncthreads();   // every wave is done reading the pipeline buffers
+    if (desync == -1 && acc[0][0][0] != 123456.789f) return;   // ablation: no stores
+    gemm_epilogue<EPI, 2, 2>(acc, p, m0 + wm * 64, n0 + wn * 64, lane, lds + w * EPI_LDS_BYTES_PER_WAVE);
 }
 
 int gemm_bf16_nt_256(const GemmBf16& p, int* rows_done, hipStream_t s);
 
-static int g_gemm_variant = -1;   // 0: 128x128 kernel only; 1: 256x256 kernel + 128x128 on the remainder rows
+// 0: 128x128 kernel only; 1: 256x256 kernel (+128x128 on the remainder rows) wherever it applies;
+// 2 (default): per-shape choice measured on MI355X (scripts/gemm_bench.py): the 256x256 4-stage kernel
+// wins when the mainloop dominates (plain bf16 epilogue or K >= 2048), the 128x128 kernel (2 workgroups
+// per CU) when a heavy epilogue (fp32 residual, activation pair, act' multiply) rides on a K=1024 mainloop.
+static int g_gemm_variant = -1;
 void gemm_set_variant(int v) { g_gemm_variant = v; }
 static int gemm_variant() {
     if (g_gemm_variant < 0) {
         const char* e = getenv("RVLM_GEMM_VARIANT");
-        g_gemm_variant = e ? atoi(e) : 0;
+        g_gemm_variant = e ? atoi(e) : 2;
     }
     return g_gemm_variant;
 }
 
+static int g_desync = -1;
+static int gemm_desync() {
+    if (g_desync < 0) { const char* e = getenv("RVLM_GEMM_DESYNC"); g_desync = e ? atoi(e) : 0; }
+    return g_desync;
+}
+
 static int gemm_bf16_nt_128(const GemmBf16& p, hipStream_t s) {
+    const int desync = gemm_desync();
     const int tiles_m = cdiv(p.M, GB_M), tiles_n = cdiv(p.N, GB_N);
     const int a_rows = p.a_rows > 0 ? p.a_rows : p.M;
     dim3 grid(tiles_m * tiles_n), block(256);
     switch (p.epi) {
         case EPI_BF16:
-            hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI_BF16>), grid, block, 0, s, p, tiles_m, tiles_n, a_rows);
+            hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI_BF16>), grid, block, 0, s, p, tiles_m, tiles_n, a_rows, desync);
             break;
         case EPI_F32_RESID:
-            hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI_F32_RESID>), grid, block, 0, s, p, tiles_m, tiles_n, a_rows);
+            hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI_F32_RESID>), grid, block, 0, s, p, tiles_m, tiles_n, a_rows, desync);
             break;
         case EPI_BF16_ACT:
-            hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI_BF16_ACT>), grid, block, 0, s, p, tiles_m, tiles_n, a_rows);
+            hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI_BF16_ACT>), grid, block, 0, s, p, tiles_m, tiles_n, a_rows, desync);
             break;
         case EPI_BF16_DACT:
-            hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI_BF16_DACT>), grid, block, 0, s, p, tiles_m, tiles_n, a_rows);
+            hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI_BF16_DACT>), grid, block, 0, s, p, tiles_m, tiles_n, a_rows, desync);
             break;
         case EPI_F32:
-            hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI_F32>), grid, block, 0, s, p, tiles_m, tiles_n, a_rows);
+            hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI_F32>), grid, block, 0, s, p, tiles_m, tiles_n, a_rows, desync);
             break;
         default:
             return fail(RVLM_ERR_ARG, "gemm_bf16_nt: unknown epilogue");
@@ -209,7 +181,9 @@ int gemm_bf16_nt(const GemmBf16& p, hipStream_t s) {
     if (p.epi == EPI_BF16_ACT && !p.out_pre) return fail(RVLM_ERR_ARG, "gemm_bf16_nt: out_pre");
     if (p.epi == EPI_BF16_DACT && !p.h_pre) return fail(RVLM_ERR_ARG, "gemm_bf16_nt: h_pre");
     int done = 0;
-    if (gemm_variant() == 1) {
+    const int variant = gemm_variant();
+    const bool big = variant == 1 || (variant == 2 && (p.epi == EPI_BF16 || p.K >= 2048));
+    if (big) {
         int rc = gemm_bf16_nt_256(p, &done, s);
         if (rc) return rc;
         if (done >= p.M) return RVLM_OK;

@@ -12,6 +12,7 @@
 // Requirements: M % 256 == 0 rows handled here (the caller runs the 128x128 kernel on the remainder
 // rows), N % 256 == 0, K % 32 == 0.
 #include "kernels.h"
+#include "gemm_epilogue.h"
 
 namespace rvlm {
 
@@ -109,55 +110,9 @@ gemm_bf16_nt_256_kernel(GemmBf16 p, int tiles_m, int tiles_n) {
         }
     }
 
-    // ---- epilogue (lane owns 4 consecutive columns of row m) ----
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        const int m = m0 + wm * 128 + mi * 32 + l31;
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = n0 + wn * 64 + ni * 32 + 8 * g + 4 * hi;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][g * 4 + e];
-                if (p.bias) {
-                    const float4 bv = *(const float4*)(p.bias + n);
-                    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-                }
-                const long o = (long)m * p.ldo + n;
-                if (EPI == EPI_BF16) {
-                    bf16x4 ov;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) ov[e] = (bf16_t)v[e];
-                    *(bf16x4*)((bf16_t*)p.out + o) = ov;
-                } else if (EPI == EPI_F32_RESID) {
-                    if (p.residual) {
-                        const float4 rv = *(const float4*)(p.residual + o);
-                        v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
-                    }
-                    *(float4*)((float*)p.out + o) = make_float4(v[0], v[1], v[2], v[3]);
-                } else if (EPI == EPI_BF16_ACT) {
-                    bf16x4 pv, ov;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        pv[e] = (bf16_t)v[e];
-                        ov[e] = (bf16_t)act_fwd(v[e], p.act);
-                    }
-                    *(bf16x4*)(p.out_pre + o) = pv;
-                    *(bf16x4*)((bf16_t*)p.out + o) = ov;
-                } else if (EPI == EPI_BF16_DACT) {
-                    const bf16x4 hv = *(const bf16x4*)(p.h_pre + o);
-                    bf16x4 ov;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) ov[e] = (bf16_t)(v[e] * act_bwd((float)hv[e], p.act));
-                    *(bf16x4*)((bf16_t*)p.out + o) = ov;
-                } else {
-                    *(float4*)((float*)p.out + o) = make_float4(v[0], v[1], v[2], v[3]);
-                }
-            }
-        }
-    }
+    // ---- epilogue (wave-private LDS transpose -> full-line global accesses) ----
+    __builtin_amdgcn_s_barrier();   // all DMA retired (vmcnt(0) above), every wave done with the ring
+    gemm_epilogue<EPI, 4, 2>(acc, p, m0 + wm * 128, n0 + wn * 64, lane, lds + w * EPI_LDS_BYTES_PER_WAVE);
 }
 
 template <int EPI>

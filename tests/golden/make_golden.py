@@ -125,16 +125,22 @@ def g1_pgd_elementwise():
 
 # ------------------------------------------------------------------ G2: apgd controller traces
 class SmallNet(torch.nn.Module):
+    """tanh-MLP; records every input it sees, the gradient that flows back to it, and its argmax."""
+
     def __init__(self, seed, d_in, n_cls=10, hidden=32, sharp=6.0):
         super().__init__()
         g = torch.Generator().manual_seed(seed)
         self.w1 = torch.randn(d_in, hidden, generator=g) * sharp / d_in ** 0.5
         self.w2 = torch.randn(hidden, n_cls, generator=g) * sharp / hidden ** 0.5
-        self.seen = []
+        self.seen, self.grads, self.argmax = [], [], []
 
     def forward(self, x, output_normalize=True):
         self.seen.append(x.detach().clone())
-        return torch.tanh(x.flatten(1) @ self.w1) @ self.w2
+        if x.requires_grad:
+            x.register_hook(lambda g: self.grads.append(g.detach().clone()))
+        out = torch.tanh(x.flatten(1) @ self.w1) @ self.w2
+        self.argmax.append(out.detach().max(1)[1].clone())
+        return out
 
 
 def g2_apgd_controller():
@@ -144,11 +150,22 @@ def g2_apgd_controller():
         x = torch.rand(shape, generator=g)
         y = torch.randint(0, 10, (6,), generator=g)
         net = SmallNet(7 + n_iter, 3 * 8 * 8).eval()
-        ce = lambda lg, yy: torch.nn.functional.cross_entropy(lg, yy, reduction="none")  # noqa
+        losses = []
+
+        def ce(lg, yy):
+            l = torch.nn.functional.cross_entropy(lg, yy, reduction="none")
+            losses.append(l.detach().clone())
+            return l
+
         out = ref_apgd_train(net, x, y, "linf", 8 / 255, n_iter=n_iter, loss_fn=ce)
+        # traces (model input k -> loss k, argmax k, and - except for the last call - gradient k) let the
+        # device kernels be replayed without re-evaluating the network (CPU BLAS rounding differs by host)
         save(f"apgd_train_smallnet_{n_iter}.npz", x=x.numpy(), y=y.numpy(),
              w1=net.w1.numpy(), w2=net.w2.numpy(), eps=np.float64(8 / 255),
-             iterates=np.stack([t.numpy() for t in net.seen]), x_best_adv=out.numpy())
+             iterates=np.stack([t.numpy() for t in net.seen]), x_best_adv=out.numpy(),
+             losses=np.stack([t.numpy() for t in losses]),
+             argmax=np.stack([t.numpy() for t in net.argmax]),
+             grads=np.stack([t.numpy() for t in net.grads]))
 
 
 # ------------------------------------------------------------------ G3: end to end on a tiny ViT

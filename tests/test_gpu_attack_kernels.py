@@ -5,7 +5,6 @@ import pytest
 import torch
 
 from oracle import linf_c
-from oracle.attacks_ref import _fwd_bwd
 from robustvlm_amd import _lib as L
 import robustvlm_amd as R
 from tests.gpu_helpers import dev, st, lib
@@ -70,24 +69,22 @@ def test_range_flags():
 
 @pytest.mark.parametrize("n_iter", [10, 50, 100])
 def test_apgd_kernels_vs_golden(n_iter):
-    """HIP step/controller/select kernels driven by CPU-evaluated losses: reproduces the reference's
-    apgd_train iterates bit for bit (apgd_train_smallnet_*.npz)."""
+    """HIP step/controller/select kernels replaying the reference's own loss / argmax / gradient traces
+    (apgd_train_smallnet_*.npz): every x_adv iterate and the returned x_best_adv must be bit-identical
+    to what train/apgd_train.py produced.  (Replay instead of re-evaluating the little network: the
+    losses are compared at the last ulp and CPU BLAS rounding differs from host to host.)"""
     l = lib()
     z = load_golden(f"apgd_train_smallnet_{n_iter}.npz")
-    net = SmallNet(torch.from_numpy(z["w1"]), torch.from_numpy(z["w2"])).eval()
-    ce = lambda lg, yy: torch.nn.functional.cross_entropy(lg, yy, reduction="none")  # noqa: E731
-    call = lambda t: net(t, output_normalize=True)  # noqa: E731
-    x = np.ascontiguousarray(z["x"]); y = torch.from_numpy(z["y"])
+    x = np.ascontiguousarray(z["x"]); y = z["y"]
     B = x.shape[0]; npix = x[0].size; eps = float(z["eps"])
     from robustvlm_amd.apgd_train import apgd_schedule
     k, n_iter_min, size_decr = apgd_schedule(n_iter)
-    x_adv_h = np.clip(x, F32(0), F32(1))
-    logits, loss, grad_h = _fwd_bwd(call, ce, x_adv_h, y)
-    dx = _cu(x); x_adv = _cu(x_adv_h); x_old = x_adv.clone(); x_best = x_adv.clone(); x_best_adv = x_adv.clone()
-    grad = _cu(grad_h); grad_best = grad.clone()
-    loss_best = _cu(loss); loss_best_lc = loss_best.clone(); reduced_lc = torch.ones(B, device=dev())
+    dx = _cu(x); x_adv = _cu(np.clip(x, F32(0), F32(1))); x_old = x_adv.clone(); x_best = x_adv.clone()
+    x_best_adv = x_adv.clone()
+    grad = _cu(z["grads"][0]); grad_best = grad.clone()
+    loss_best = _cu(z["losses"][0]); loss_best_lc = loss_best.clone(); reduced_lc = torch.ones(B, device=dev())
     step = torch.full((B,), float(F32(2.0 * eps)), device=dev())
-    acc = _cu((logits.max(1)[1] == y).numpy().astype(np.uint8))
+    acc = _cu((z["argmax"][0] == y).astype(np.uint8))
     loss_steps = torch.zeros(n_iter, B, device=dev())
     f0 = torch.zeros(B, dtype=torch.uint8, device=dev()); f1 = f0.clone(); f2 = f0.clone()
     counter3 = 0
@@ -96,14 +93,11 @@ def test_apgd_kernels_vs_golden(n_iter):
         L.check(l.rvlm_apgd_linf_step(dx.data_ptr(), x_adv.data_ptr(), x_old.data_ptr(), grad.data_ptr(),
                                       step.data_ptr(), 0.75 if i > 0 else 1.0, eps, npix, B, st()))
         torch.cuda.synchronize()
-        xa = x_adv.cpu().numpy()
-        assert np.array_equal(xa, z["iterates"][i + 1]), f"iterate {i + 1}"
-        last = i == n_iter - 1
-        logits, loss, g = _fwd_bwd(call, ce, xa, y, need_grad=not last)
-        if not last:
-            grad.copy_(_cu(g))
-        pred = _cu((logits.max(1)[1] == y).numpy().astype(np.uint8))
-        dl = _cu(loss)
+        assert np.array_equal(x_adv.cpu().numpy(), z["iterates"][i + 1]), f"iterate {i + 1}"
+        if i < n_iter - 1:                                   # apgd_train.py:293-295 skips the last backward
+            grad.copy_(_cu(z["grads"][i + 1]))
+        pred = _cu((z["argmax"][i + 1] == y).astype(np.uint8))
+        dl = _cu(z["losses"][i + 1])
         counter3 += 1
         do_check = int(counter3 == k)
         L.check(l.rvlm_apgd_controller(i, B, n_iter, k, do_check, dl.data_ptr(), pred.data_ptr(),
