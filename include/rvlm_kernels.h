@@ -30,6 +30,8 @@ int rvlm_k_attn_bwd_bf16(const uint16_t* qkv, const uint16_t* o, const uint16_t*
 int rvlm_k_attn_set_use_tr(int on);
 /* 0: 128x128 GEMM kernel only; 1: 256x256 4-stage kernel (+128x128 on remainder rows); -1: env RVLM_GEMM_VARIANT */
 int rvlm_k_gemm_set_variant(int v);
+/* workgroups per CU reported by the runtime for attn fwd (96-VGPR build), attn fwd (default), attn dq */
+int rvlm_k_attn_occupancy(int S, int* out3);
 int rvlm_k_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y,
                              float* mean, float* rstd, int M, int W, rvlm_stream_t stream);
 int rvlm_k_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean,

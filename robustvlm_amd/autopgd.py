@@ -81,8 +81,7 @@ class APGDAttack():
         alpha = 2. if self.alpha is None else self.alpha                    # :296-299
         step0 = alpha * self.eps
         m = self.model
-        if isinstance(m, ClassificationModel) and x.shape[0] > 1 and m.logit_scale \
-                and m.resizer.__class__.__name__ == "function":
+        if isinstance(m, ClassificationModel) and x.shape[0] > 1 and m.logit_scale and m._identity_resizer:
             x_best_adv, x_best, loss_best, acc = m.model.apgd_run(
                 x, start, "ce", m.text_embedding, y, True, self.eps, self.n_iter, step0,
                 train_variant=False, logits_from_head=True, logit_scale=m.logit_scale_value, want_extra=True)

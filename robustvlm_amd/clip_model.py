@@ -175,6 +175,7 @@ class ClassificationModel(torch.nn.Module):
                                                                                         input_normalize)
         self.model = self.vision.model
         self.args = args
+        self._identity_resizer = resizer is None
         self.resizer = resizer if resizer is not None else (lambda x: x)
         self.text_embedding = text_embedding
         self.logit_scale = logit_scale

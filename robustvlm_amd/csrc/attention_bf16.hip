@@ -81,6 +81,46 @@ __device__ __forceinline__ bf16x8 frag_transposed(const char* tile, int rowbase,
     return out;
 }
 
+// Per-lane byte offsets that do not depend on the tile index (32-row tiles start at multiples of 16
+// rows, which leaves the (row>>1)&7 swizzle term unchanged): address = tile + row0*128 + offset.
+struct FragOffs {
+    int rm[4];      // row-major fragment, k-chunk kk:      row0 = first row of the 32-row tile
+    int tr[2][2];   // transposed fragment [dt][r]:          row0 = first row of the 16-row k-slice
+};
+__device__ __forceinline__ FragOffs make_offs(int lane) {
+    FragOffs o;
+    const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) o.rm[kk] = swz_off(l31, kk * 2 + hi);
+    const int i = lane & 15, dblk = (lane >> 4) & 1;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int x = 4 * hi + 8 * r + (i >> 2);
+            o.tr[dt][r] = swz_off(x, dt * 4 + dblk * 2 + ((i & 3) >> 1)) + (i & 1) * 8;
+        }
+    return o;
+}
+__device__ __forceinline__ bf16x8 frag_rm(const char* tile, int row0, int off) {
+    return *(const bf16x8*)(tile + row0 * 128 + off);
+}
+__device__ __forceinline__ bf16x8 frag_tr(const char* tile, int row0, const FragOffs& o, int dt) {
+    bf16x8 out;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+            (__attribute__((address_space(3))) bf16x4*)((lds_char*)tile + row0 * 128 + o.tr[dt][r]));
+        out[4 * r + 0] = v[0]; out[4 * r + 1] = v[1]; out[4 * r + 2] = v[2]; out[4 * r + 3] = v[3];
+    }
+    return out;
+}
+template <bool USE_TR>
+__device__ __forceinline__ bf16x8 frag_t(const char* tile, int row0, const FragOffs& o, int dt, int lane) {
+    if (USE_TR) return frag_tr(tile, row0, o, dt);
+    return frag_transposed<false>(tile, row0, dt, lane);
+}
+
 // accumulator (D layout: row = (reg&3)+8*(reg>>2)+4*hi) -> B operand for k-slice ks (16 rows)
 __device__ __forceinline__ bf16x8 pack_b(const f32x16& p, int ks) {
     bf16x8 o;
@@ -100,12 +140,15 @@ __device__ __forceinline__ f32x16 zero16() {
 }
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+// raw v_exp_f32 (2^x): arguments here are <= ~6 and results below 2^-126 may flush to 0, which is what
+// softmax wants; exp2f() would wrap every call in denormal-range fix-ups (~6 VALU instead of 1)
+#define EXP2(x) __builtin_amdgcn_exp2f(x)
 
 // =============================================================================================
 // forward
 // =============================================================================================
-template <bool USE_TR>
-__global__ void __launch_bounds__(576)
+template <bool USE_TR, int MINW>
+__global__ void __launch_bounds__(576, MINW)
 attn_fwd_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict__ o, long ldo,
                 float* __restrict__ lse2, int H, int S, int Sp, int W, float scale_log2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -120,6 +163,8 @@ attn_fwd_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict__ o,
     __syncthreads();
 
     const int ntiles = Sp / 32;
+    const FragOffs fo = make_offs(lane);
+    constexpr float RESCALE_THR = 6.0f;   // log2 units: P stays <= 2^6 between rescales (fp32 accumulate)
     for (int qt = w; qt < ntiles; qt += nw) {
         const int q = qt * 32 + l31;
         const int qc = min(q, S - 1);
@@ -131,37 +176,36 @@ attn_fwd_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict__ o,
         for (int kt = 0; kt < ntiles; ++kt) {
             f32x16 s = zero16();
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) s = MFMA(frag_rowmajor(Kt, kt * 32, kk, lane), qf[kk], s);
-            const bool tail = (kt * 32 + 32 > S);
-            float tmax = -INFINITY;
+            for (int kk = 0; kk < 4; ++kk) s = MFMA(frag_rm(Kt, kt * 32, fo.rm[kk]), qf[kk], s);
+            if (kt * 32 + 32 > S) {   // tail tile: padded keys contribute exp2(-inf) = 0
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float t = s[r] * scale_log2;
-                if (tail) {
-                    const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (key >= S) t = -INFINITY;
-                }
-                s[r] = t;
-                tmax = fmaxf(tmax, t);
+                for (int r = 0; r < 16; ++r)
+                    if (kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= S) s[r] = -INFINITY;
             }
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            const float mnew = fmaxf(m, tmax);
-            const float alpha = exp2f(m - mnew);
+            float tmax = s[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * scale_log2;
+            if (__any(tmax > m + RESCALE_THR)) {   // wave-uniform; always taken on the first tile (m = -inf)
+                const float mnew = fmaxf(m, tmax);
+                const float alpha = EXP2(m - mnew);
+                l *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+                m = mnew;
+            }
             float psum = 0.0f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = exp2f(s[r] - mnew); psum += s[r]; }
-            l = l * alpha + psum;
-            m = mnew;
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+            for (int r = 0; r < 16; ++r) { s[r] = EXP2(fmaf(s[r], scale_log2, -m)); psum += s[r]; }
+            l += psum;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const bf16x8 pb = pack_b(s, ks);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
-                    oacc[dt] = MFMA(frag_transposed<USE_TR>(Vt, kt * 32 + ks * 16, dt, lane), pb, oacc[dt]);
+                    oacc[dt] = MFMA(frag_t<USE_TR>(Vt, kt * 32 + ks * 16, fo, dt, lane), pb, oacc[dt]);
             }
         }
         const float ltot = l + __shfl_xor(l, 32, 64);
@@ -204,10 +248,10 @@ attn_bwd_prep_kernel(const bf16_t* __restrict__ o, long ldo, const bf16_t* __res
 // =============================================================================================
 template <bool USE_TR>
 __global__ void __launch_bounds__(576)
-attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __restrict__ d_o, long lddo,
-                   const float* __restrict__ lse2, const float* __restrict__ dsum,
-                   bf16_t* __restrict__ dqkv, long lddq, int H, int S, int Sp, int W, float scale,
-                   float scale_log2) {
+attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __restrict__ o, long ldo,
+                   const bf16_t* __restrict__ d_o, long lddo, const float* __restrict__ lse2,
+                   float* __restrict__ dsum, bf16_t* __restrict__ dqkv, long lddq, int H, int S, int Sp, int W,
+                   float scale, float scale_log2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Kt = smem;
     char* Vt = smem + (size_t)Sp * 128;
@@ -220,29 +264,37 @@ attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __rest
     __syncthreads();
 
     const int ntiles = Sp / 32;
+    const FragOffs fo = make_offs(lane);
     for (int qt = w; qt < ntiles; qt += nw) {
         const int q = qt * 32 + l31;
         const int qc = min(q, S - 1);
         bf16x8 qf[4], dof[4];
+        // D[q] = sum_d dO[q,d] * O[q,d]  (the "prep" pass of flash backward, fused here: this lane holds
+        // 32 of the 64 d's of dO as its MFMA fragments, the other half sits in lane ^ 32)
+        float dq_sum = 0.0f;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             qf[kk] = frag_global(base, ld, qc, kk, lane);
             dof[kk] = frag_global(d_o + (long)b * S * lddo + h * 64, lddo, qc, kk, lane);
+            const bf16x8 of = frag_global(o + (long)b * S * ldo + h * 64, ldo, qc, kk, lane);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dq_sum = fmaf((float)dof[kk][e], (float)of[e], dq_sum);
         }
+        dq_sum += __shfl_xor(dq_sum, 32, 64);
+        if (hi == 0 && q < S) dsum[((long)b * H + h) * Sp + q] = dq_sum;   // consumed by the dK/dV kernel
         const float lq = lse2[((long)b * H + h) * Sp + qc];
-        const float dq_sum = dsum[((long)b * H + h) * Sp + qc];
         f32x16 acc[2] = {zero16(), zero16()};
         for (int kt = 0; kt < ntiles; ++kt) {
             f32x16 s = zero16(), dp = zero16();
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                s = MFMA(frag_rowmajor(Kt, kt * 32, kk, lane), qf[kk], s);
-                dp = MFMA(frag_rowmajor(Vt, kt * 32, kk, lane), dof[kk], dp);
+                s = MFMA(frag_rm(Kt, kt * 32, fo.rm[kk]), qf[kk], s);
+                dp = MFMA(frag_rm(Vt, kt * 32, fo.rm[kk]), dof[kk], dp);
             }
             const bool tail = (kt * 32 + 32 > S);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float p = exp2f(s[r] * scale_log2 - lq);
+                float p = EXP2(fmaf(s[r], scale_log2, -lq));
                 if (tail) {
                     const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                     if (key >= S) p = 0.0f;
@@ -254,7 +306,7 @@ attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __rest
                 const bf16x8 db = pack_b(s, ks);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
-                    acc[dt] = MFMA(frag_transposed<USE_TR>(Kt, kt * 32 + ks * 16, dt, lane), db, acc[dt]);
+                    acc[dt] = MFMA(frag_t<USE_TR>(Kt, kt * 32 + ks * 16, fo, dt, lane), db, acc[dt]);
             }
         }
         if (q < S) {
@@ -306,6 +358,7 @@ attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __res
     __syncthreads();
 
     const int ntiles = Sp / 32;
+    const FragOffs fo = make_offs(lane);
     for (int kt = w; kt < ntiles; kt += nw) {
         const int key = kt * 32 + l31;
         const int kc = min(key, S - 1);
@@ -322,10 +375,10 @@ attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __res
             f32x16 s = zero16(), dp = zero16();
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                const bf16x8 kb = KV_LDS ? frag_rowmajor(Kt, kt * 32, kk, lane) : kf[kk];
-                const bf16x8 vb = KV_LDS ? frag_rowmajor(Vt, kt * 32, kk, lane) : vf[kk];
-                s = MFMA(frag_rowmajor(Qt, qt * 32, kk, lane), kb, s);     // S[q][key]
-                dp = MFMA(frag_rowmajor(Dt, qt * 32, kk, lane), vb, dp);   // dP[q][key]
+                const bf16x8 kb = KV_LDS ? frag_rm(Kt, kt * 32, fo.rm[kk]) : kf[kk];
+                const bf16x8 vb = KV_LDS ? frag_rm(Vt, kt * 32, fo.rm[kk]) : vf[kk];
+                s = MFMA(frag_rm(Qt, qt * 32, fo.rm[kk]), kb, s);     // S[q][key]
+                dp = MFMA(frag_rm(Dt, qt * 32, fo.rm[kk]), vb, dp);   // dP[q][key]
                 __builtin_amdgcn_sched_barrier(0);   // bound the live fragment set (3 waves/SIMD budget)
             }
 #pragma unroll
@@ -336,7 +389,7 @@ attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __res
                 const float dqa[4] = {dq.x, dq.y, dq.z, dq.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float p = exp2f(s[g * 4 + e] * scale_log2 - lqa[e]);
+                    const float p = EXP2(fmaf(s[g * 4 + e], scale_log2, -lqa[e]));
                     s[g * 4 + e] = p;                                   // P   (in place)
                     dp[g * 4 + e] = p * (dp[g * 4 + e] - dqa[e]);       // dS  (in place)
                 }
@@ -346,8 +399,8 @@ attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __res
                 const bf16x8 pb = pack_b(s, ks), db = pack_b(dp, ks);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
-                    dv[dt] = MFMA(frag_transposed<USE_TR>(Dt, qt * 32 + ks * 16, dt, lane), pb, dv[dt]);
-                    dk[dt] = MFMA(frag_transposed<USE_TR>(Qt, qt * 32 + ks * 16, dt, lane), db, dk[dt]);
+                    dv[dt] = MFMA(frag_t<USE_TR>(Dt, qt * 32 + ks * 16, fo, dt, lane), pb, dv[dt]);
+                    dk[dt] = MFMA(frag_t<USE_TR>(Qt, qt * 32 + ks * 16, fo, dt, lane), db, dk[dt]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -396,15 +449,19 @@ int attn_fwd_bf16(const bf16_t* qkv, long ldqkv, bf16_t* o, long ldo, float* lse
     const float sl2 = 0.125f * 1.4426950408889634f;
     const int nt = attn_block_threads(Sp / 32);
     int rc;
-    if (g_use_tr) {
-        if ((rc = set_lds(attn_fwd_kernel<true>, lds_bytes))) return rc;
-        hipLaunchKernelGGL((attn_fwd_kernel<true>), dim3(B * H), dim3(nt), lds_bytes, s, qkv, ldqkv, o,
-                           ldo, lse, H, S, Sp, W, sl2);
-    } else {
-        if ((rc = set_lds(attn_fwd_kernel<false>, lds_bytes))) return rc;
-        hipLaunchKernelGGL((attn_fwd_kernel<false>), dim3(B * H), dim3(nt), lds_bytes, s, qkv, ldqkv, o,
-                           ldo, lse, H, S, Sp, W, sl2);
-    }
+    // MINW = 5 caps the kernel at 96 VGPRs so that two 9-wave workgroups (2 x 74 KiB LDS) share a CU:
+    // one workgroup's K/V staging then hides under the other's MFMA/softmax phase.
+    static int occ = -1;
+    if (occ < 0) { const char* e = getenv("RVLM_ATTN_OCC"); occ = e ? atoi(e) : 5; }
+#define LAUNCH_FWD(TR, MW)                                                                                   \
+    do {                                                                                                      \
+        if ((rc = set_lds(attn_fwd_kernel<TR, MW>, lds_bytes))) return rc;                                   \
+        hipLaunchKernelGGL((attn_fwd_kernel<TR, MW>), dim3(B * H), dim3(nt), lds_bytes, s, qkv, ldqkv, o,    \
+                           ldo, lse, H, S, Sp, W, sl2);                                                      \
+    } while (0)
+    if (g_use_tr) { if (occ == 5) LAUNCH_FWD(true, 5); else LAUNCH_FWD(true, 1); }
+    else LAUNCH_FWD(false, 1);
+#undef LAUNCH_FWD
     RVLM_CHECK_LAUNCH();
     return RVLM_OK;
 }
@@ -415,9 +472,6 @@ int attn_bwd_bf16(const bf16_t* qkv, long ldqkv, const bf16_t* o, long ldo, cons
     const int Sp = (int)round_up(S, 32), W = H * 64;
     const float scale = 0.125f, sl2 = 0.125f * 1.4426950408889634f;
     const int nt = attn_block_threads(Sp / 32);
-    hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(B * S), dim3(256), 0, s, o, ldo, d_o, lddo,
-                       dsum_scratch, H, S, Sp);
-    RVLM_CHECK_LAUNCH();
     const size_t lds_q = (size_t)Sp * 256;
     const bool kv_lds = ((size_t)Sp * 520 <= 160 * 1024);     // Q, dO, K, V all LDS-resident (S <= 315)
     const size_t lds_kv = kv_lds ? (size_t)Sp * 520 : (size_t)Sp * 264;
@@ -425,8 +479,8 @@ int attn_bwd_bf16(const bf16_t* qkv, long ldqkv, const bf16_t* o, long ldo, cons
 #define LAUNCH_BWD(TR)                                                                                         \
     do {                                                                                                        \
         if ((rc = set_lds(attn_bwd_dq_kernel<TR>, lds_q))) return rc;                                          \
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<TR>), dim3(B * H), dim3(nt), lds_q, s, qkv, ldqkv, d_o, lddo,   \
-                           lse, dsum_scratch, dqkv, lddqkv, H, S, Sp, W, scale, sl2);                          \
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<TR>), dim3(B * H), dim3(nt), lds_q, s, qkv, ldqkv, o, ldo, d_o, \
+                           lddo, lse, dsum_scratch, dqkv, lddqkv, H, S, Sp, W, scale, sl2);                    \
         RVLM_CHECK_LAUNCH();                                                                                    \
         if (kv_lds) {                                                                                           \
             if ((rc = set_lds(attn_bwd_dkv_kernel<TR, true>, lds_kv))) return rc;                              \
@@ -441,6 +495,22 @@ int attn_bwd_bf16(const bf16_t* qkv, long ldqkv, const bf16_t* o, long ldo, cons
     if (g_use_tr) LAUNCH_BWD(true); else LAUNCH_BWD(false);
 #undef LAUNCH_BWD
     RVLM_CHECK_LAUNCH();
+    return RVLM_OK;
+}
+
+// occupancy (workgroups per CU) the runtime reports for the three kernels at sequence length S
+int attn_occupancy(int S, int* out3) {
+    const int Sp = (int)round_up(S, 32);
+    const int nt = attn_block_threads(Sp / 32);
+    const size_t lds_f = (size_t)Sp * 256, lds_kv = ((size_t)Sp * 520 <= 160 * 1024) ? (size_t)Sp * 520 : (size_t)Sp * 264;
+    int rc;
+    if ((rc = set_lds(attn_fwd_kernel<true, 5>, lds_f))) return rc;
+    if ((rc = set_lds(attn_fwd_kernel<true, 1>, lds_f))) return rc;
+    if ((rc = set_lds(attn_bwd_dq_kernel<true>, lds_f))) return rc;
+    RVLM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[0], attn_fwd_kernel<true, 5>, nt, lds_f));
+    RVLM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[1], attn_fwd_kernel<true, 1>, nt, lds_f));
+    RVLM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[2], attn_bwd_dq_kernel<true>, nt, lds_f));
+    (void)lds_kv;
     return RVLM_OK;
 }
 

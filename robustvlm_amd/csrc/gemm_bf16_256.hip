@@ -16,6 +16,8 @@
 
 namespace rvlm {
 
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
 constexpr int L_M = 256, L_N = 256, L_K = 32, L_STAGES = 4;
 constexpr int L_OPER_BYTES = L_M * L_K * 2;        // 16 KiB per operand per stage
 constexpr int L_STAGE_BYTES = 2 * L_OPER_BYTES;    // 32 KiB
@@ -25,7 +27,7 @@ __device__ __forceinline__ void glds16b(const void* gptr, void* lds_ptr) {
                                      (__attribute__((address_space(3))) void*)lds_ptr, 16, 0, 0);
 }
 
-template <int EPI>
+template <int EPI, bool PRIO>
 __global__ void __launch_bounds__(512)
 gemm_bf16_nt_256_kernel(GemmBf16 p, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -82,32 +84,68 @@ gemm_bf16_nt_256_kernel(GemmBf16 p, int tiles_m, int tiles_n) {
             glds16b(b_src[j] + ko, dst + L_OPER_BYTES + j * 1024);
         }
     };
+    // Fragment reads are inline asm so that the waits can be COUNTED by hand: hipcc's own scoreboard
+    // loses the in-order information across the loop back-edge and falls back to lgkmcnt(0), which
+    // would drain the reads that were just issued for the next k-slice.
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+    auto load_frags = [&](int kt, int kk, i32x4 (&a)[4], i32x4 (&b)[2]) {
+        const unsigned st = lds_base + (kt & (L_STAGES - 1)) * L_STAGE_BYTES + koff[kk];
+        const unsigned aa = st + a_row_off, bb = st + b_row_off;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(a[0]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(a[1]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(a[2]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(a[3]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(b[0]) : "v"(bb));
+        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(b[1]) : "v"(bb));
+    };
+    auto mma = [&](const i32x4 (&a)[4], const i32x4 (&b)[2]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b[j]),
+                                                                    __builtin_bit_cast(bf16x8, a[i]), acc[i][j],
+                                                                    0, 0, 0);
+    };
+
+    // Software pipeline (fragments double-buffered in registers): while the 8 MFMAs of one k-slice
+    // issue, the ds_read_b128s of the next k-slice are in flight, so LDS latency never idles the matrix
+    // pipe.  Stage kt+1 therefore has to be landed and barrier-published one step early: at most two
+    // K-steps of DMA (kt+2, kt+3) are in flight during step kt.
 #pragma unroll
     for (int s = 0; s < L_STAGES - 1; ++s)
         if (s < nk) issue(s);
+    if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    i32x4 a0[4], b0[2], a1[4], b1[2];
+    load_frags(0, 0, a0, b0);
 
     for (int kt = 0; kt < nk; ++kt) {
-        // retire stage kt (4 DMAs per stage per wave); leave the younger stages in flight
-        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        // retire stage kt+1 (4 DMAs per stage per wave): younger stage kt+2 may stay in flight
+        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();           // stage kt+1 visible to all; slot of stage kt-1 is free
         __builtin_amdgcn_sched_barrier(0);
-        if (kt + L_STAGES - 1 < nk) issue(kt + L_STAGES - 1);   // refills the slot read in step kt-1
-        const char* st = lds + (kt & (L_STAGES - 1)) * L_STAGE_BYTES;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 a[4], b[2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = *(const bf16x8*)(st + a_row_off + i * 32 * 64 + koff[kk]);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = *(const bf16x8*)(st + b_row_off + j * 32 * 64 + koff[kk]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+        if (kt + L_STAGES - 1 < nk) issue(kt + L_STAGES - 1);
+        load_frags(kt, 1, a1, b1);
+        asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");    // a0/b0 (issued one group earlier) landed
+        __builtin_amdgcn_sched_barrier(0);
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+        mma(a0, b0);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nk) {
+            load_frags(kt + 1, 0, a0, b0);
+            asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");   // a1/b1 landed, next a0/b0 in flight
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+        mma(a1, b1);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
     }
 
     // ---- epilogue (wave-private LDS transpose -> full-line global accesses) ----
@@ -118,15 +156,24 @@ gemm_bf16_nt_256_kernel(GemmBf16 p, int tiles_m, int tiles_n) {
 template <int EPI>
 static int launch_256(const GemmBf16& p, int tiles_m, int tiles_n, hipStream_t s) {
     static bool attr_set = false;
+    static int prio = -1;
+    if (prio < 0) { const char* e = getenv("RVLM_GEMM_PRIO"); prio = e ? atoi(e) : 0; }
     const size_t lds_bytes = (size_t)L_STAGES * L_STAGE_BYTES;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel<EPI>,
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel<EPI, false>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel<EPI, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return fail(RVLM_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_bf16_nt_256_kernel<EPI>), dim3(tiles_m * tiles_n), dim3(512), lds_bytes, s, p,
-                       tiles_m, tiles_n);
+    if (prio)
+        hipLaunchKernelGGL((gemm_bf16_nt_256_kernel<EPI, true>), dim3(tiles_m * tiles_n), dim3(512), lds_bytes, s, p,
+                           tiles_m, tiles_n);
+    else
+        hipLaunchKernelGGL((gemm_bf16_nt_256_kernel<EPI, false>), dim3(tiles_m * tiles_n), dim3(512), lds_bytes, s, p,
+                           tiles_m, tiles_n);
     RVLM_CHECK_LAUNCH();
     return RVLM_OK;
 }

@@ -6,6 +6,7 @@
 namespace rvlm {
 void attn_set_use_tr(int on);
 void gemm_set_variant(int v);
+int attn_occupancy(int S, int* out3);
 
 __global__ void probe_tr16_kernel(const bf16_t* __restrict__ src, const int32_t* __restrict__ offs,
                                   bf16_t* __restrict__ out) {
@@ -66,3 +67,4 @@ extern "C" int rvlm_k_probe_tr16(const uint16_t* src, const int32_t* offs, uint1
     RVLM_CHECK_LAUNCH();
     return RVLM_OK;
 }
+extern "C" int rvlm_k_attn_occupancy(int S, int* out3) { return attn_occupancy(S, out3); }
