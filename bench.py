@@ -187,10 +187,21 @@ def main():
         attn_gemm = {k: v for k, v in prof.items() if k in ("gemm_qkv_fwd", "gemm_out_fwd", "gemm_qkv_bwd",
                                                             "gemm_out_bwd", "attn_fwd", "attn_bwd")}
         achieved = gflops / (gms * 1e-3) / 1e12 if gms > 0 else 0.0
+        # HBM-side traffic comes from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE cannot be
+        # read from inside this process); the committed measurement of this same command is reported.
+        traffic, traffic_src = None, None
+        tj = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+        if os.path.exists(tj) and args.model == "ViT-L-14" and args.batch == 128 and args.precision == "bf16":
+            try:
+                traffic = json.load(open(tj))["gemm_bytes_per_logical_launch"]
+                traffic_src = "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+            except Exception:
+                traffic = None
         res["roofline"] = {
             "bound": "mfma", "kernel": "gemm_bf16_nt_kernel (QKV/out-proj/fc1/fc2, fwd + dgrad)",
             "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
-            "traffic": None,
+            "traffic": traffic, "traffic_unit": "bytes per GEMM launch (fabric side: 2*FETCH_SIZE + WRITE_SIZE)",
+            "traffic_source": traffic_src,
             "flops_per_launch": gflops / max(glaunch, 1), "avg_launch_ms": gms / max(glaunch, 1),
             "launches": glaunch,
             "attention_gemm_subset": {

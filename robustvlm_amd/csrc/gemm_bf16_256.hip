@@ -27,7 +27,7 @@ __device__ __forceinline__ void glds16b(const void* gptr, void* lds_ptr) {
                                      (__attribute__((address_space(3))) void*)lds_ptr, 16, 0, 0);
 }
 
-template <int EPI, bool PRIO>
+template <int EPI, bool PRIO, bool SUPER>
 __global__ void __launch_bounds__(512)
 gemm_bf16_nt_256_kernel(GemmBf16 p, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -110,42 +110,85 @@ gemm_bf16_nt_256_kernel(GemmBf16 p, int tiles_m, int tiles_n) {
 
     // Software pipeline (fragments double-buffered in registers): while the 8 MFMAs of one k-slice
     // issue, the ds_read_b128s of the next k-slice are in flight, so LDS latency never idles the matrix
-    // pipe.  Stage kt+1 therefore has to be landed and barrier-published one step early: at most two
-    // K-steps of DMA (kt+2, kt+3) are in flight during step kt.
-#pragma unroll
-    for (int s = 0; s < L_STAGES - 1; ++s)
-        if (s < nk) issue(s);
-    if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    // pipe.
     i32x4 a0[4], b0[2], a1[4], b1[2];
-    load_frags(0, 0, a0, b0);
-
-    for (int kt = 0; kt < nk; ++kt) {
-        // retire stage kt+1 (4 DMAs per stage per wave): younger stage kt+2 may stay in flight
-        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (!SUPER) {
+        // one barrier per BK=32 stage; stage kt+1 is landed and barrier-published one step early, two
+        // K-steps of DMA (kt+2, kt+3) stay in flight during step kt.
+#pragma unroll
+        for (int s = 0; s < L_STAGES - 1; ++s)
+            if (s < nk) issue(s);
+        if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();           // stage kt+1 visible to all; slot of stage kt-1 is free
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + L_STAGES - 1 < nk) issue(kt + L_STAGES - 1);
-        load_frags(kt, 1, a1, b1);
-        asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");    // a0/b0 (issued one group earlier) landed
-        __builtin_amdgcn_sched_barrier(0);
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
-        mma(a0, b0);
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < nk) {
-            load_frags(kt + 1, 0, a0, b0);
-            asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");   // a1/b1 landed, next a0/b0 in flight
-        } else {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        load_frags(0, 0, a0, b0);
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();           // stage kt+1 visible to all; slot of stage kt-1 is free
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + L_STAGES - 1 < nk) issue(kt + L_STAGES - 1);
+            load_frags(kt, 1, a1, b1);
+            asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");    // a0/b0 (issued one group earlier) landed
+            __builtin_amdgcn_sched_barrier(0);
+            if (PRIO) __builtin_amdgcn_s_setprio(1);
+            mma(a0, b0);
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 1 < nk) {
+                load_frags(kt + 1, 0, a0, b0);
+                asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");   // a1/b1 landed, next a0/b0 in flight
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (PRIO) __builtin_amdgcn_s_setprio(1);
+            mma(a1, b1);
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
-        mma(a1, b1);
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
+    } else {
+        // "super-stage" schedule: the ring is 2 x (two BK=32 stages); ONE barrier per 64-deep K-step
+        // (32 MFMAs per wave between barriers), the other super-stage's 8 DMAs per wave in flight.
+        const int ns = (nk + 1) / 2;
+        auto issue_super = [&](int sp) { issue(2 * sp); if (2 * sp + 1 < nk) issue(2 * sp + 1); };
+        issue_super(0);
+        if (ns > 1) issue_super(1);
+        for (int sp = 0; sp < ns; ++sp) {
+            // retire super-stage sp; only in step 0 is a younger super-stage (1) already in flight
+            if (sp == 0 && ns > 1) {
+                if (3 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();   // super-stage sp visible; every wave is done reading sp-1
+            __builtin_amdgcn_sched_barrier(0);
+            if (sp >= 1 && sp + 1 < ns) issue_super(sp + 1);   // refills the slots of super-stage sp-1
+            const int k0 = 2 * sp;
+            const bool two = (k0 + 1 < nk);
+            load_frags(k0, 0, a0, b0);
+            load_frags(k0, 1, a1, b1);
+            asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (two) { load_frags(k0 + 1, 0, a0, b0); asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory"); }
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (two) {
+                load_frags(k0 + 1, 1, a1, b1);
+                asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                mma(a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                mma(a1, b1);
+            }
+        }
     }
 
     // ---- epilogue (wave-private LDS transpose -> full-line global accesses) ----
@@ -153,26 +196,164 @@ gemm_bf16_nt_256_kernel(GemmBf16 p, int tiles_m, int tiles_n) {
     gemm_epilogue<EPI, 4, 2>(acc, p, m0 + wm * 128, n0 + wn * 64, lane, lds + w * EPI_LDS_BYTES_PER_WAVE);
 }
 
+// =================================================================================================
+// Staggered ("role-split") schedule.  Same tile / ring / swizzle as above, but every K-step is cut into
+// two barrier-delimited phases,  L(t): issue the DMAs of stage t+3 + the 12 ds_read_b128 of stage t,
+// M(t): the 16 MFMAs of stage t,  and wave group B (waves 4-7) runs ONE BARRIER BEHIND group A
+// (waves 0-3): B executes one extra s_barrier before its loop, A one extra after.  A workgroup's waves
+// go to the SIMDs in cyclic order, so wave w and wave w+4 share a SIMD: while one of them is in its
+// MFMA phase the other is in its load phase, i.e. the matrix pipe no longer idles while both waves issue
+// DMA / LDS reads in lockstep (measured: 53 % MFMA-busy with the lockstep schedule above).
+// Because the two groups are one barrier apart, every producer->consumer edge through LDS keeps one
+// barrier of slack: own-DMA waits for stage t+1 sit at the end of L(t) (two barriers before the reads in
+// L(t+1)), and the slot of stage t is refilled in L(t+1) (two barriers after its last read).
+// =================================================================================================
+template <int EPI>
+__global__ void __launch_bounds__(512)
+gemm_bf16_nt_256s_kernel(GemmBf16 p, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int nwg = gridDim.x, pid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = pid & 7, loc = pid >> 3;
+    const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+    const int group_size = 8 * tiles_n;
+    const int first_m = (t / group_size) * 8;
+    const int gm = min(tiles_m - first_m, 8);
+    const int tm = first_m + (t % group_size) % gm;
+    const int tn = (t % group_size) / gm;
+    const int m0 = tm * L_M, n0 = tn * L_N;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 2, wn = w & 3;
+    const bool groupB = w >= 4;
+
+    const bf16_t* a_src[2];
+    const bf16_t* b_src[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = w * 32 + j * 16 + (lane >> 2);
+        const int clog = (lane & 3) ^ ((r >> 2) & 3);
+        a_src[j] = p.A + (long)(m0 + r) * p.lda + clog * 8;
+        b_src[j] = p.Bw + (long)(n0 + r) * p.ldb + clog * 8;
+    }
+    const int stage_wave_off = (w * 32) * 64;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int swz = (l31 >> 2) & 3;
+    int koff[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) koff[kk] = ((kk * 2 + hi) ^ swz) << 4;
+    const int a_row_off = (wm * 128 + l31) * 64;
+    const int b_row_off = L_OPER_BYTES + (wn * 64 + l31) * 64;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int nk = p.K / L_K;
+    auto issue = [&](int kt) {
+        char* dst = lds + (kt & (L_STAGES - 1)) * L_STAGE_BYTES + stage_wave_off;
+        const int ko = kt * L_K;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            glds16b(a_src[j] + ko, dst + j * 1024);
+            glds16b(b_src[j] + ko, dst + L_OPER_BYTES + j * 1024);
+        }
+    };
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+    auto load_frags = [&](int kt, int kk, i32x4 (&a)[4], i32x4 (&b)[2]) {
+        const unsigned st = lds_base + (kt & (L_STAGES - 1)) * L_STAGE_BYTES + koff[kk];
+        const unsigned aa = st + a_row_off, bb = st + b_row_off;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(a[0]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(a[1]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(a[2]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(a[3]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(b[0]) : "v"(bb));
+        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(b[1]) : "v"(bb));
+    };
+    auto mma = [&](const i32x4 (&a)[4], const i32x4 (&b)[2]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b[j]),
+                                                                    __builtin_bit_cast(bf16x8, a[i]), acc[i][j],
+                                                                    0, 0, 0);
+    };
+
+    // ---- prologue: stages 0..2 in flight, stage 0 landed (own part) before barrier X ----
+#pragma unroll
+    for (int s = 0; s < L_STAGES - 1; ++s)
+        if (s < nk) issue(s);
+    if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                    // X
+    if (groupB) __builtin_amdgcn_s_barrier();        // E : group B now runs one barrier behind group A
+
+    i32x4 a0[4], b0[2], a1[4], b1[2];
+    for (int kt = 0; kt < nk; ++kt) {
+        // ---------------- L(kt) ----------------
+        __builtin_amdgcn_s_barrier();                // B_alpha(kt)
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + L_STAGES - 1 < nk) issue(kt + L_STAGES - 1);   // slot of stage kt-1 (last read in L(kt-1))
+        load_frags(kt, 0, a0, b0);
+        load_frags(kt, 1, a1, b1);
+        // own DMA of stage kt+1 must have landed two barriers before L(kt+1) reads it
+        if (kt + 3 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // ---------------- M(kt) ----------------
+        __builtin_amdgcn_s_barrier();                // B_beta(kt)
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        mma(a0, b0);
+        mma(a1, b1);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!groupB) __builtin_amdgcn_s_barrier();       // E': pairs with group B's last B_beta
+
+    __builtin_amdgcn_s_barrier();                    // F: every wave is done with the ring
+    gemm_epilogue<EPI, 4, 2>(acc, p, m0 + wm * 128, n0 + wn * 64, lane, lds + w * EPI_LDS_BYTES_PER_WAVE);
+}
+
 template <int EPI>
 static int launch_256(const GemmBf16& p, int tiles_m, int tiles_n, hipStream_t s) {
     static bool attr_set = false;
     static int prio = -1;
-    if (prio < 0) { const char* e = getenv("RVLM_GEMM_PRIO"); prio = e ? atoi(e) : 0; }
+    if (prio < 0) { const char* e = getenv("RVLM_GEMM_SUPER"); prio = e ? atoi(e) : 0; }
     const size_t lds_bytes = (size_t)L_STAGES * L_STAGE_BYTES;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel<EPI, false>,
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel<EPI, false, false>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel<EPI, true>,
+            e = hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel<EPI, false, true>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return fail(RVLM_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
         attr_set = true;
     }
-    if (prio)
-        hipLaunchKernelGGL((gemm_bf16_nt_256_kernel<EPI, true>), dim3(tiles_m * tiles_n), dim3(512), lds_bytes, s, p,
+    if (prio == 2) {
+        static bool attr2 = false;
+        if (!attr2) {
+            hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_nt_256s_kernel<EPI>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (e != hipSuccess) return fail(RVLM_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
+            attr2 = true;
+        }
+        hipLaunchKernelGGL((gemm_bf16_nt_256s_kernel<EPI>), dim3(tiles_m * tiles_n), dim3(512), lds_bytes, s, p,
+                           tiles_m, tiles_n);
+    } else if (prio)
+        hipLaunchKernelGGL((gemm_bf16_nt_256_kernel<EPI, false, true>), dim3(tiles_m * tiles_n), dim3(512), lds_bytes, s, p,
                            tiles_m, tiles_n);
     else
-        hipLaunchKernelGGL((gemm_bf16_nt_256_kernel<EPI, false>), dim3(tiles_m * tiles_n), dim3(512), lds_bytes, s, p,
+        hipLaunchKernelGGL((gemm_bf16_nt_256_kernel<EPI, false, false>), dim3(tiles_m * tiles_n), dim3(512), lds_bytes, s, p,
                            tiles_m, tiles_n);
     RVLM_CHECK_LAUNCH();
     return RVLM_OK;
