@@ -14,6 +14,7 @@
 
 namespace rvlm {
 void attn_set_use_tr(int on);
+void gemm_set_splitk_scratch(float* ptr, size_t bytes);
 
 struct Layer {
     float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *b_in, *b_out, *b_fc, *b_proj;
@@ -52,6 +53,7 @@ struct rvlm_vit {
     float* dres;  void* dres_lp;  void* d_o;  void* dqkv;  void* dh;  void* d_ln;  void* d_patch;
     float* dA0;   float* dsum;   float *d_raw, *d_pooled;
     float *scores, *dscores;   // fp32 mode [B,H,S,S]
+    float* splitk_scratch;     // fp32 slabs for the split-K remainder GEMMs
     // attack state
     float* img_buf[5];         // [maxB*3*img*img]
     float *emb, *d_emb, *loss_ps, *loss_scalar, *loss_scratch;
@@ -580,6 +582,11 @@ extern "C" int rvlm_vit_create(const rvlm_vit_config* cfg, const rvlm_vit_weight
         ALLOC_OR_DIE(h->scores, (size_t)B * h->H * S * S * 4);
         ALLOC_OR_DIE(h->dscores, (size_t)B * h->H * S * S * 4);
     } else { h->scores = h->dscores = nullptr; }
+    {
+        const size_t sk = (size_t)8 * 256 * 4 * W * sizeof(float);   // 8 slabs x <=256 rows x 4W columns
+        ALLOC_OR_DIE(h->splitk_scratch, sk);
+        gemm_set_splitk_scratch(h->splitk_scratch, sk);
+    }
     const size_t npix = (size_t)B * 3 * h->img * h->img;
     for (int i = 0; i < 5; ++i) ALLOC_OR_DIE(h->img_buf[i], npix * 4);
     ALLOC_OR_DIE(h->emb, (size_t)B * D * 4);

@@ -28,6 +28,13 @@ template <int EPI>
 __global__ void __launch_bounds__(256)
 gemm_bf16_nt_kernel(GemmBf16 p, int tiles_m, int tiles_n, int a_rows, int desync) {
     __shared__ __attribute__((aligned(16))) char lds[4 * GB_TILE_BYTES];
+    if (gridDim.y > 1) {   // split-K slice blockIdx.y: fp32 partial sums into its own slab of p.out
+        const int ks = p.K / (int)gridDim.y;
+        p.A += (long)blockIdx.y * ks;
+        p.Bw += (long)blockIdx.y * ks;
+        p.K = ks;
+        p.out = (float*)p.out + (long)blockIdx.y * p.M * p.ldo;
+    }
 
     // ---- XCD-aware, grouped tile order ----------------------------------------------------
     const int nwg = gridDim.x, pid = blockIdx.x;
@@ -123,6 +130,56 @@ gemm_bf16_nt_kernel(GemmBf16 p, int tiles_m, int tiles_n, int a_rows, int desync
     gemm_epilogue<EPI, 2, 2>(acc, p, m0 + wm * 64, n0 + wn * 64, lane, lds + w * EPI_LDS_BYTES_PER_WAVE);
 }
 
+// ---- split-K for the short "remainder" GEMMs ---------------------------------------------------------
+// The 256x256 kernel covers floor(M/256)*256 rows; the <=255 remaining rows (the 128 CLS-token rows at
+// B=128) are 0.4 % of the FLOPs but, as N/128 workgroups walking the whole K serially, cost 46-61 us at
+// K = 3072/4096 (latency-bound: ~1 us per 64-deep K-step).  They are split SPLITK ways along K into
+// fp32 slabs (deterministic: no atomics) and combined by a tiny reduce+epilogue kernel.
+template <int EPI>
+__global__ void __launch_bounds__(256)
+splitk_reduce_kernel(const float* __restrict__ slabs, int splitk, GemmBf16 p) {
+    const int n4 = p.N >> 2;
+    const long total = (long)p.M * n4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(idx / n4), n = (int)(idx - (long)m * n4) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int sidx = 0; sidx < splitk; ++sidx) {
+            const float4 t = *(const float4*)(slabs + ((long)sidx * p.M + m) * p.N + n);
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        if (p.bias) { const float4 b = *(const float4*)(p.bias + n); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+        const long o = (long)m * p.ldo + n;
+        float f[4] = {v.x, v.y, v.z, v.w};
+        if (EPI == EPI_BF16) {
+            bf16x4 ov;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ov[e] = (bf16_t)f[e];
+            *(bf16x4*)((bf16_t*)p.out + o) = ov;
+        } else if (EPI == EPI_F32_RESID) {
+            if (p.residual) { const float4 r = *(const float4*)(p.residual + o); f[0] += r.x; f[1] += r.y; f[2] += r.z; f[3] += r.w; }
+            *(float4*)((float*)p.out + o) = make_float4(f[0], f[1], f[2], f[3]);
+        } else if (EPI == EPI_BF16_ACT) {
+            bf16x4 pv, ov;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { pv[e] = (bf16_t)f[e]; ov[e] = (bf16_t)act_fwd(f[e], p.act); }
+            *(bf16x4*)(p.out_pre + o) = pv;
+            *(bf16x4*)((bf16_t*)p.out + o) = ov;
+        } else if (EPI == EPI_BF16_DACT) {
+            const bf16x4 hv = *(const bf16x4*)(p.h_pre + o);
+            bf16x4 ov;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ov[e] = (bf16_t)(f[e] * act_bwd((float)hv[e], p.act));
+            *(bf16x4*)((bf16_t*)p.out + o) = ov;
+        } else {
+            *(float4*)((float*)p.out + o) = make_float4(f[0], f[1], f[2], f[3]);
+        }
+    }
+}
+
+static float* g_splitk_scratch = nullptr;
+static size_t g_splitk_bytes = 0;
+void gemm_set_splitk_scratch(float* ptr, size_t bytes) { g_splitk_scratch = ptr; g_splitk_bytes = bytes; }
+
 int gemm_bf16_nt_256(const GemmBf16& p, int* rows_done, hipStream_t s);
 
 // 0: 128x128 kernel only; 1: 256x256 kernel (+128x128 on the remainder rows) wherever it applies;
@@ -198,6 +255,28 @@ int gemm_bf16_nt(const GemmBf16& p, hipStream_t s) {
         if (p.residual) r.residual = p.residual + (long)done * p.ldo;
         r.M = p.M - done;
         r.a_rows = (p.a_rows > 0 ? p.a_rows : p.M) - done;
+        // split-K when the serial K walk dominates (K >= 2048) and a scratch slab is available
+        const int splitk = (p.K >= 4096) ? 8 : (p.K >= 2048 ? (p.K % (6 * GB_K) == 0 ? 6 : 4) : 1);
+        const size_t need = (size_t)splitk * r.M * p.N * sizeof(float);
+        if (splitk > 1 && r.M <= 256 && g_splitk_scratch && need <= g_splitk_bytes && p.K % (splitk * GB_K) == 0) {
+            GemmBf16 part = r;
+            part.epi = EPI_F32; part.bias = nullptr; part.residual = nullptr; part.out = g_splitk_scratch;
+            part.ldo = p.N; part.out_pre = nullptr; part.h_pre = nullptr;
+            const int tiles_m = cdiv(part.M, GB_M), tiles_n = cdiv(part.N, GB_N);
+            hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI_F32>), dim3(tiles_m * tiles_n, splitk), dim3(256), 0, s, part,
+                               tiles_m, tiles_n, part.a_rows, 0);
+            RVLM_CHECK_LAUNCH();
+            const int rb = cdiv((long)r.M * (p.N / 4), 256);
+            switch (p.epi) {
+                case EPI_BF16: hipLaunchKernelGGL((splitk_reduce_kernel<EPI_BF16>), dim3(rb), dim3(256), 0, s, g_splitk_scratch, splitk, r); break;
+                case EPI_F32_RESID: hipLaunchKernelGGL((splitk_reduce_kernel<EPI_F32_RESID>), dim3(rb), dim3(256), 0, s, g_splitk_scratch, splitk, r); break;
+                case EPI_BF16_ACT: hipLaunchKernelGGL((splitk_reduce_kernel<EPI_BF16_ACT>), dim3(rb), dim3(256), 0, s, g_splitk_scratch, splitk, r); break;
+                case EPI_BF16_DACT: hipLaunchKernelGGL((splitk_reduce_kernel<EPI_BF16_DACT>), dim3(rb), dim3(256), 0, s, g_splitk_scratch, splitk, r); break;
+                default: hipLaunchKernelGGL((splitk_reduce_kernel<EPI_F32>), dim3(rb), dim3(256), 0, s, g_splitk_scratch, splitk, r); break;
+            }
+            RVLM_CHECK_LAUNCH();
+            return RVLM_OK;
+        }
     }
     return gemm_bf16_nt_128(r, s);
 }

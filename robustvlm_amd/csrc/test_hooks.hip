@@ -6,6 +6,7 @@
 namespace rvlm {
 void attn_set_use_tr(int on);
 void gemm_set_variant(int v);
+void gemm_set_splitk_scratch(float* ptr, size_t bytes);
 int attn_occupancy(int S, int* out3);
 
 __global__ void probe_tr16_kernel(const bf16_t* __restrict__ src, const int32_t* __restrict__ offs,
@@ -25,6 +26,11 @@ extern "C" int rvlm_k_gemm_bf16_nt(const uint16_t* A, long lda, const uint16_t* 
                                    int K, int a_rows, int epi, const float* bias, void* out, long ldo,
                                    uint16_t* out_pre, const uint16_t* h_pre, const float* residual, int act,
                                    rvlm_stream_t stream) {
+    static float* scratch = nullptr;      // split-K slabs for the remainder rows (test surface only)
+    if (!scratch) {
+        const size_t bytes = (size_t)8 * 256 * 4096 * sizeof(float);
+        if (hipMalloc((void**)&scratch, bytes) == hipSuccess) gemm_set_splitk_scratch(scratch, bytes);
+    }
     GemmBf16 g;
     g.A = (const bf16_t*)A; g.lda = lda; g.Bw = (const bf16_t*)Bw; g.ldb = ldb; g.M = M; g.N = N; g.K = K;
     g.a_rows = a_rows; g.epi = epi; g.bias = bias; g.out = out; g.ldo = ldo; g.out_pre = (bf16_t*)out_pre;

@@ -169,3 +169,31 @@ def test_layernorm_f32(M, W):
     torch.cuda.synchronize()
     assert rel_max(y, ref.detach()) < 1e-5
     assert rel_max(dres - 1, gx) < 1e-4
+
+
+@pytest.mark.parametrize("K", [2048, 3072, 4096])
+def test_gemm_bf16_splitk_remainder(K):
+    """M = 256*q + r rows: the r remainder rows take the split-K path (K >= 2048) for every epilogue."""
+    lib().rvlm_k_gemm_set_variant(1)
+    try:
+        M, N = 256 + 128, 512
+        g = torch.Generator(device="cuda").manual_seed(K)
+        A = torch.randn(M, K, generator=g, device=dev()).bfloat16()
+        Bw = (torch.randn(N, K, generator=g, device=dev()) * K ** -0.5).bfloat16()
+        bias = torch.randn(N, generator=g, device=dev())
+        res = torch.randn(M, N, generator=g, device=dev())
+        hp = torch.randn(M, N, generator=g, device=dev()).bfloat16()
+        acc = A.double() @ Bw.double().t()
+        out, _ = gemm_bf16(A, Bw, epi=4, bias=bias)
+        assert rel_max(out, acc + bias.double()) < 2e-5
+        out, _ = gemm_bf16(A, Bw, epi=1, bias=bias, residual=res)
+        assert rel_max(out, acc + bias.double() + res.double()) < 2e-5
+        out, _ = gemm_bf16(A, Bw, epi=0, bias=bias)
+        assert rel_max(out.float(), acc + bias.double()) < 1e-2
+        out, pre = gemm_bf16(A, Bw, epi=2, bias=bias, act=0)
+        assert rel_max(pre.float(), acc + bias.double()) < 1e-2
+        assert rel_max(out.float(), act_ref(acc + bias.double(), 0)) < 1.5e-2
+        out, _ = gemm_bf16(A, Bw, epi=3, h_pre=hp, act=0)
+        assert rel_max(out.float(), acc * dact_ref(hp.double(), 0)) < 1.5e-2
+    finally:
+        lib().rvlm_k_gemm_set_variant(-1)
