@@ -69,6 +69,7 @@ typedef struct {
     int32_t max_batch;  /* workspace is sized for this many images */
     float mean[3];      /* Normalize constants, …clip.py:116 */
     float std[3];
+    int32_t trainable;  /* != 0: also keep what the weight-gradient backward needs (rvlm_vit_backward_params) */
 } rvlm_vit_config;
 
 /* fp32 device pointers in `visual.state_dict()` layout (…clip.py:239,470; Appendix B key list). */
@@ -109,12 +110,25 @@ int rvlm_vit_load_weights(rvlm_vit* h, const rvlm_vit_weights* weights, rvlm_str
 size_t rvlm_vit_workspace_bytes(const rvlm_vit* h);
 
 /* emb[B,out_dim] = visual(Normalize(x + delta)) (delta may be NULL), L2-normalised iff
- * output_normalize.  save_for_backward != 0 keeps the activations rvlm_vit_backward_input needs. */
+ * output_normalize.  save_for_backward: 0 = inference, 1 = keep what rvlm_vit_backward_input needs,
+ * 2 = additionally keep the linear-layer inputs for rvlm_vit_backward_params (trainable handles). */
 int rvlm_vit_forward(rvlm_vit* h, const float* x, const float* delta, int B, int output_normalize,
                      int save_for_backward, float* out_emb, rvlm_stream_t stream);
 /* grad_x[B,3,H,W] = d<d_emb, emb>/d(x+delta) for the last saved forward (dgrad only, no wgrad). */
 int rvlm_vit_backward_input(rvlm_vit* h, const float* d_emb, int B, float* grad_x,
                             rvlm_stream_t stream);
+
+/* Weight gradients of the outer training step (loss_total.backward(), …clip.py:361): for the last
+ * forward run with save_for_backward == 2 on a `trainable` handle, writes (accumulate == 0) or adds
+ * (accumulate != 0) d<d_emb, emb>/d(param) for EVERY parameter into the fp32 tensors `grads` points to
+ * (same struct / shapes as the weights).  No input gradient is produced. */
+int rvlm_vit_backward_params(rvlm_vit* h, const float* d_emb, int B, const rvlm_vit_weights* grads,
+                             int accumulate, rvlm_stream_t stream);
+/* torch.optim.AdamW single-tensor step on flat fp32 buffers (optimizer.step(), …clip.py:196-197,362):
+ * grads are multiplied by grad_scale first (1/world_size after a sum all-reduce). `step` counts from 1. */
+int rvlm_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n,
+                    float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                    float grad_scale, rvlm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Losses (replace compute_loss / l2 / ce, …clip.py:495-528) - loss value and d loss / d emb.

@@ -27,7 +27,7 @@ class VitConfigC(C.Structure):
     _fields_ = [("image_size", C.c_int32), ("patch", C.c_int32), ("width", C.c_int32),
                 ("layers", C.c_int32), ("heads", C.c_int32), ("out_dim", C.c_int32),
                 ("act", C.c_int32), ("precision", C.c_int32), ("max_batch", C.c_int32),
-                ("mean", C.c_float * 3), ("std", C.c_float * 3)]
+                ("mean", C.c_float * 3), ("std", C.c_float * 3), ("trainable", C.c_int32)]
 
 
 BLOCK_FIELDS = ["ln_1_weight", "ln_1_bias", "attn_in_proj_weight", "attn_in_proj_bias",
@@ -87,6 +87,9 @@ _SIGS = {
     "rvlm_vit_forward": (C.c_int, [C.c_void_p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, c_f32p,
                                    c_stream]),
     "rvlm_vit_backward_input": (C.c_int, [C.c_void_p, c_f32p, C.c_int, c_f32p, c_stream]),
+    "rvlm_vit_backward_params": (C.c_int, [C.c_void_p, c_f32p, C.c_int, C.POINTER(VitWeightsC), C.c_int, c_stream]),
+    "rvlm_adamw_step": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_size_t, C.c_float, C.c_float, C.c_float,
+                                  C.c_float, C.c_float, C.c_int, C.c_float, c_stream]),
     "rvlm_loss_grad": (C.c_int, [C.c_int, C.c_int, c_f32p, c_f32p, C.c_void_p, C.c_int, C.c_int,
                                  C.c_int, C.c_float, c_f32p, c_f32p, c_f32p, C.c_void_p, c_f32p,
                                  c_stream]),

@@ -54,6 +54,13 @@ struct rvlm_vit {
     float* dA0;   float* dsum;   float *d_raw, *d_pooled;
     float *scores, *dscores;   // fp32 mode [B,H,S,S]
     float* splitk_scratch;     // fp32 slabs for the split-K remainder GEMMs
+    // training (cfg.trainable): inputs of every linear layer + embedding tokens + transpose scratch
+    bool trainable = false;
+    bool inference_only = false;
+    std::vector<void*> ln1_out, ln2_out, g_act_l;   // L x [Mp,W], [Mp,W], [Mp,4W] T
+    float *tokens, *dtok;      // [Mp, W] f32
+    void *tA, *tB;             // bf16 mode: [4W, Mpt] transposed operands of the wgrad GEMMs
+    long Mpt = 0;
     // attack state
     float* img_buf[5];         // [maxB*3*img*img]
     float *emb, *d_emb, *loss_ps, *loss_scalar, *loss_scratch;
@@ -64,6 +71,7 @@ struct rvlm_vit {
     std::vector<void*> allocs;
     size_t bytes = 0;
     int saved_B = 0;
+    int saved_mode = 0;
     bool saved_norm = false;
     // profiling
     bool prof = false;
@@ -333,20 +341,24 @@ static int forward_impl(rvlm_vit* h, const float* x, const float* delta, int B, 
     {
         PROF("embed_lnpre_fwd", 0, (double)M * W * 8);
         if ((rc = embed_lnpre_fwd<float>(h->patch_out, W, h->cls, h->pos, h->lnpre_w, h->lnpre_b, XS(0), W,
-                                         h->mean_at(0), h->rstd_at(0), B, S, W, s))) return rc;
+                                         h->mean_at(0), h->rstd_at(0), B, S, W, s,
+                                         save == 2 ? h->tokens : nullptr))) return rc;
     }
     for (int l = 0; l < L; ++l) {
         Layer& y = h->layers[l];
         const int sl = save ? l : 0;
         float* x_in = XS(2 * l); float* x_mid = XS(2 * l + 1); float* x_out = XS(2 * l + 2);
+        void* ln1o = save == 2 ? h->ln1_out[l] : h->ln_out;     // linear inputs are kept only for wgrad
+        void* ln2o = save == 2 ? h->ln2_out[l] : h->ln_out;
+        void* gact = save == 2 ? h->g_act_l[l] : h->g_act;
         {
             PROF("layernorm_fwd", 0, (double)M * W * (4 + sizeof(T)));
-            if ((rc = layernorm_fwd<T>(x_in, W, y.ln1_w, y.ln1_b, (T*)h->ln_out, W, h->mean_at(1 + 2 * l),
+            if ((rc = layernorm_fwd<T>(x_in, W, y.ln1_w, y.ln1_b, (T*)ln1o, W, h->mean_at(1 + 2 * l),
                                        h->rstd_at(1 + 2 * l), M, W, s))) return rc;
         }
         {
             PROF("gemm_qkv_fwd", 2.0 * M * W * 3 * W, 0);
-            if ((rc = linear_fwd<T>(h, s, h->ln_out, W, M, 3 * W, W, y.w_in, y.w_in_nk, y.b_in, EPI_BF16,
+            if ((rc = linear_fwd<T>(h, s, ln1o, W, M, 3 * W, W, y.w_in, y.w_in_nk, y.b_in, EPI_BF16,
                                     h->qkv[sl], 3 * W, nullptr, nullptr))) return rc;
         }
         {
@@ -360,17 +372,17 @@ static int forward_impl(rvlm_vit* h, const float* x, const float* delta, int B, 
         }
         {
             PROF("layernorm_fwd", 0, (double)M * W * (4 + sizeof(T)));
-            if ((rc = layernorm_fwd<T>(x_mid, W, y.ln2_w, y.ln2_b, (T*)h->ln_out, W, h->mean_at(2 + 2 * l),
+            if ((rc = layernorm_fwd<T>(x_mid, W, y.ln2_w, y.ln2_b, (T*)ln2o, W, h->mean_at(2 + 2 * l),
                                        h->rstd_at(2 + 2 * l), M, W, s))) return rc;
         }
         {
             PROF("gemm_fc1_fwd", 2.0 * M * W * 4 * W, 0);
-            if ((rc = linear_fwd<T>(h, s, h->ln_out, W, M, 4 * W, W, y.w_fc, y.w_fc_nk, y.b_fc, EPI_BF16_ACT,
-                                    h->g_act, 4 * W, h->h_pre[sl], nullptr))) return rc;
+            if ((rc = linear_fwd<T>(h, s, ln2o, W, M, 4 * W, W, y.w_fc, y.w_fc_nk, y.b_fc, EPI_BF16_ACT,
+                                    gact, 4 * W, h->h_pre[sl], nullptr))) return rc;
         }
         {
             PROF("gemm_fc2_fwd", 2.0 * M * W * 4 * W, 0);
-            if ((rc = linear_fwd<T>(h, s, h->g_act, 4 * W, M, W, 4 * W, y.w_proj, y.w_proj_nk, y.b_proj,
+            if ((rc = linear_fwd<T>(h, s, gact, 4 * W, M, W, 4 * W, y.w_proj, y.w_proj_nk, y.b_proj,
                                     EPI_F32_RESID, x_out, W, nullptr, x_mid))) return rc;
         }
     }
@@ -389,7 +401,7 @@ static int forward_impl(rvlm_vit* h, const float* x, const float* delta, int B, 
             if ((rc = l2_normalize_fwd(h->emb_raw, out_emb, h->inv_norm, B, D, s))) return rc;
         }
     }
-    if (save) { h->saved_B = B; h->saved_norm = normalize != 0; }
+    if (save) { h->saved_B = B; h->saved_norm = normalize != 0; h->saved_mode = save; }
     return RVLM_OK;
 }
 
@@ -488,6 +500,124 @@ static int backward_impl(rvlm_vit* h, const float* d_emb, int B, float* grad_x, 
     return RVLM_OK;
 }
 
+// ---- weight gradients ------------------------------------------------------------------------------
+// dW[N,K] (+)= dY[M,N]^T @ X[M,K]
+template <typename T>
+static int wgrad(rvlm_vit* h, hipStream_t s, const void* dY, long lddy, const void* X, long ldx, int M, int N, int K,
+                 float* dW, long lddw, int accumulate);
+template <>
+int wgrad<bf16_t>(rvlm_vit* h, hipStream_t s, const void* dY, long lddy, const void* X, long ldx, int M, int N,
+                  int K, float* dW, long lddw, int accumulate) {
+    // contraction over the token dimension: both operands are transposed so that it is the contiguous
+    // (MFMA k) dimension, zero-padded to a multiple of 64, then the NT MFMA GEMM runs as usual
+    const int Mk = (int)round_up(M, 64);
+    int rc;
+    if ((rc = transpose_pad<bf16_t>((const bf16_t*)dY, lddy, M, N, (bf16_t*)h->tA, h->Mpt, Mk, s))) return rc;
+    if ((rc = transpose_pad<bf16_t>((const bf16_t*)X, ldx, M, K, (bf16_t*)h->tB, h->Mpt, Mk, s))) return rc;
+    GemmBf16 g;
+    g.A = (const bf16_t*)h->tA; g.lda = h->Mpt; g.Bw = (const bf16_t*)h->tB; g.ldb = h->Mpt;
+    g.M = N; g.N = K; g.K = Mk; g.a_rows = 4 * h->W;
+    g.epi = accumulate ? EPI_F32_RESID : EPI_F32; g.residual = accumulate ? dW : nullptr;
+    g.out = dW; g.ldo = lddw;
+    return gemm_bf16_nt(g, s);
+}
+template <>
+int wgrad<float>(rvlm_vit*, hipStream_t s, const void* dY, long lddy, const void* X, long ldx, int M, int N, int K,
+                 float* dW, long lddw, int accumulate) {
+    GemmF32 g;
+    g.A = (const float*)dY; g.sam = 1; g.sak = lddy;      // (m_out = n, k = token)
+    g.B = (const float*)X; g.sbn = 1; g.sbk = ldx;        // (n_out = k, k = token)
+    g.C = dW; g.scm = lddw; g.scn = 1;
+    g.M = N; g.N = K; g.K = M;
+    g.residual = accumulate ? dW : nullptr;
+    return gemm_f32(g, s);
+}
+
+template <typename T>
+static int backward_params_impl(rvlm_vit* h, const float* d_emb, int B, const rvlm_vit_weights* gw, int acc,
+                                hipStream_t s) {
+    const int S = h->S, W = h->W, L = h->L, D = h->D, M = B * S, M0 = B * h->G * h->G;
+    constexpr bool LP = !std::is_same<T, float>::value;
+    auto G = [](const float* p) { return const_cast<float*>(p); };
+    int rc;
+    // ---- head ----
+    const float* d_raw = d_emb;
+    if (h->saved_norm) {
+        if ((rc = l2_normalize_bwd(d_emb, h->emb_raw, h->inv_norm, h->d_raw, B, D, s))) return rc;
+        d_raw = h->d_raw;
+    }
+    {   // dproj[W,D] (+)= pooled^T d_raw
+        GemmF32 g;
+        g.A = h->pooled; g.sam = 1; g.sak = W;
+        g.B = d_raw; g.sbn = 1; g.sbk = D;
+        g.C = G(gw->proj); g.scm = D; g.scn = 1;
+        g.M = W; g.N = D; g.K = B;
+        g.residual = acc ? gw->proj : nullptr;
+        if ((rc = gemm_f32(g, s))) return rc;
+    }
+    {   // d_pooled = d_raw @ proj^T
+        GemmF32 g;
+        g.A = d_raw; g.sam = D; g.sak = 1;
+        g.B = h->proj; g.sbn = D; g.sbk = 1;
+        g.C = h->d_pooled; g.scm = W; g.scn = 1;
+        g.M = B; g.N = W; g.K = D;
+        if ((rc = gemm_f32(g, s))) return rc;
+    }
+    if ((rc = ln_param_grad<float>(h->d_pooled, W, h->xs[2 * L], (long)S * W, h->mean_at(2 * L + 1),
+                                   h->rstd_at(2 * L + 1), B, W, G(gw->ln_post_weight), G(gw->ln_post_bias), acc, s)))
+        return rc;
+    RVLM_HIP(hipMemsetAsync(h->dres, 0, (size_t)h->Mp * W * 4, s));
+    if (LP) RVLM_HIP(hipMemsetAsync(h->dres_lp, 0, (size_t)h->Mp * W * sizeof(T), s));
+    if ((rc = layernorm_bwd<float, T>(h->d_pooled, W, h->xs[2 * L], (long)S * W, h->lnpost_w, h->mean_at(2 * L + 1),
+                                      h->rstd_at(2 * L + 1), h->dres, (long)S * W, LP ? (T*)h->dres_lp : nullptr,
+                                      (long)S * W, 0, B, W, s))) return rc;
+    const void* dres_A = LP ? (const void*)h->dres_lp : (const void*)h->dres;
+    for (int l = L - 1; l >= 0; --l) {
+        Layer& y = h->layers[l];
+        const rvlm_vit_block_weights& gb = gw->blocks_host[l];
+        // fc2 (c_proj): dY = d(residual), X = act(fc1)
+        if ((rc = wgrad<T>(h, s, dres_A, W, h->g_act_l[l], 4 * W, M, W, 4 * W, G(gb.mlp_c_proj_weight), 4 * W, acc))) return rc;
+        if ((rc = colsum<T>((const T*)dres_A, W, M, W, G(gb.mlp_c_proj_bias), acc, s))) return rc;
+        if ((rc = linear_dgrad<T>(h, s, dres_A, W, M, W, 4 * W, y.w_proj, 4 * W, y.w_proj_t, EPI_BF16_DACT, h->dh,
+                                  4 * W, h->h_pre[l]))) return rc;
+        // fc1 (c_fc)
+        if ((rc = wgrad<T>(h, s, h->dh, 4 * W, h->ln2_out[l], W, M, 4 * W, W, G(gb.mlp_c_fc_weight), W, acc))) return rc;
+        if ((rc = colsum<T>((const T*)h->dh, 4 * W, M, 4 * W, G(gb.mlp_c_fc_bias), acc, s))) return rc;
+        if ((rc = linear_dgrad<T>(h, s, h->dh, 4 * W, M, 4 * W, W, y.w_fc, W, y.w_fc_t, EPI_BF16, h->d_ln, W, nullptr)))
+            return rc;
+        if ((rc = ln_param_grad<T>((const T*)h->d_ln, W, h->xs[2 * l + 1], W, h->mean_at(2 + 2 * l),
+                                   h->rstd_at(2 + 2 * l), M, W, G(gb.ln_2_weight), G(gb.ln_2_bias), acc, s))) return rc;
+        if ((rc = layernorm_bwd<T, T>((const T*)h->d_ln, W, h->xs[2 * l + 1], W, y.ln2_w, h->mean_at(2 + 2 * l),
+                                      h->rstd_at(2 + 2 * l), h->dres, W, LP ? (T*)h->dres_lp : nullptr, W, 1, M, W, s)))
+            return rc;
+        // attention out-proj
+        if ((rc = wgrad<T>(h, s, dres_A, W, h->attn_o[l], W, M, W, W, G(gb.attn_out_proj_weight), W, acc))) return rc;
+        if ((rc = colsum<T>((const T*)dres_A, W, M, W, G(gb.attn_out_proj_bias), acc, s))) return rc;
+        if ((rc = linear_dgrad<T>(h, s, dres_A, W, M, W, W, y.w_out, W, y.w_out_t, EPI_BF16, h->d_o, W, nullptr))) return rc;
+        if ((rc = attention_bwd<T>(h, s, h->qkv[l], h->attn_o[l], h->d_o, h->lse[l], h->dqkv, B))) return rc;
+        // qkv in-proj
+        if ((rc = wgrad<T>(h, s, h->dqkv, 3 * W, h->ln1_out[l], W, M, 3 * W, W, G(gb.attn_in_proj_weight), W, acc))) return rc;
+        if ((rc = colsum<T>((const T*)h->dqkv, 3 * W, M, 3 * W, G(gb.attn_in_proj_bias), acc, s))) return rc;
+        if ((rc = linear_dgrad<T>(h, s, h->dqkv, 3 * W, M, 3 * W, W, y.w_in, W, y.w_in_t, EPI_BF16, h->d_ln, W, nullptr)))
+            return rc;
+        if ((rc = ln_param_grad<T>((const T*)h->d_ln, W, h->xs[2 * l], W, h->mean_at(1 + 2 * l), h->rstd_at(1 + 2 * l),
+                                   M, W, G(gb.ln_1_weight), G(gb.ln_1_bias), acc, s))) return rc;
+        if ((rc = layernorm_bwd<T, T>((const T*)h->d_ln, W, h->xs[2 * l], W, y.ln1_w, h->mean_at(1 + 2 * l),
+                                      h->rstd_at(1 + 2 * l), h->dres, W, LP ? (T*)h->dres_lp : nullptr, W, 1, M, W, s)))
+            return rc;
+    }
+    // ---- embeddings: ln_pre, positional / class embedding, conv1 ----
+    if ((rc = ln_param_grad<float>(h->dres, W, h->tokens, W, h->mean_at(0), h->rstd_at(0), M, W, G(gw->ln_pre_weight),
+                                   G(gw->ln_pre_bias), acc, s))) return rc;
+    if ((rc = layernorm_bwd<float, float>(h->dres, W, h->tokens, W, h->lnpre_w, h->mean_at(0), h->rstd_at(0), h->dtok,
+                                          W, nullptr, W, 0, M, W, s))) return rc;
+    if ((rc = pos_cls_grad(h->dtok, W, B, S, W, G(gw->positional_embedding), G(gw->class_embedding), acc, s))) return rc;
+    if ((rc = gather_patch_rows<T>(h->dtok, W, B, S, W, (T*)h->d_patch, W, s))) return rc;
+    // conv1.weight [W, 3*P*P] (+)= d_patch^T A0   (A0 has Kpad >= Kp columns; only Kp are weights)
+    if ((rc = wgrad<T>(h, s, h->d_patch, W, h->A0, h->Kpad, M0, W, h->Kp, G(gw->conv1_weight), h->Kp, acc))) return rc;
+    return RVLM_OK;
+}
+
 static int vit_forward(rvlm_vit* h, const float* x, const float* delta, int B, int normalize, int save,
                        float* out_emb, hipStream_t s) {
     return h->bf16 ? forward_impl<bf16_t>(h, x, delta, B, normalize, save, out_emb, s)
@@ -550,14 +680,23 @@ extern "C" int rvlm_vit_create(const rvlm_vit_config* cfg, const rvlm_vit_weight
 #define ALLOC_OR_DIE(ptr, bytes) do { rc = dev_alloc(h, (void**)&(ptr), (bytes)); if (rc) { rvlm_vit_destroy(h); return rc; } } while (0)
     ALLOC_OR_DIE(h->A0, Mp0 * h->Kpad * e);
     ALLOC_OR_DIE(h->patch_out, Mp0 * W * 4);
+    const bool inference_only = cfg->trainable < 0;   // no backward of any kind: one slot per buffer kind
+    h->inference_only = inference_only;
     h->xs.resize(2 * L + 1);
-    for (auto& p : h->xs) ALLOC_OR_DIE(p, Mp * W * 4);
+    for (size_t i = 0; i < h->xs.size(); ++i) {
+        if (inference_only && i > 0) { h->xs[i] = h->xs[0]; continue; }
+        ALLOC_OR_DIE(h->xs[i], Mp * W * 4);
+    }
     ALLOC_OR_DIE(h->st_mean, (size_t)(2 * L + 2) * Mp * 4);
     ALLOC_OR_DIE(h->st_rstd, (size_t)(2 * L + 2) * Mp * 4);
     ALLOC_OR_DIE(h->ln_out, Mp * W * e);
     h->qkv.resize(L); h->attn_o.resize(L); h->lse.resize(L); h->h_pre.resize(L);
     const size_t Sp = round_up(S, 32);
     for (int l = 0; l < L; ++l) {
+        if (inference_only && l > 0) {
+            h->qkv[l] = h->qkv[0]; h->attn_o[l] = h->attn_o[0]; h->lse[l] = h->lse[0]; h->h_pre[l] = h->h_pre[0];
+            continue;
+        }
         ALLOC_OR_DIE(h->qkv[l], Mp * 3 * W * e);
         ALLOC_OR_DIE(h->attn_o[l], Mp * W * e);
         ALLOC_OR_DIE(h->lse[l], (size_t)B * h->H * Sp * 4);
@@ -582,6 +721,24 @@ extern "C" int rvlm_vit_create(const rvlm_vit_config* cfg, const rvlm_vit_weight
         ALLOC_OR_DIE(h->scores, (size_t)B * h->H * S * S * 4);
         ALLOC_OR_DIE(h->dscores, (size_t)B * h->H * S * S * 4);
     } else { h->scores = h->dscores = nullptr; }
+    h->trainable = cfg->trainable > 0;
+    h->tokens = h->dtok = nullptr; h->tA = h->tB = nullptr;
+    if (h->trainable) {
+        h->ln1_out.resize(L); h->ln2_out.resize(L); h->g_act_l.resize(L);
+        for (int l = 0; l < L; ++l) {
+            ALLOC_OR_DIE(h->ln1_out[l], Mp * W * e);
+            ALLOC_OR_DIE(h->ln2_out[l], Mp * W * e);
+            ALLOC_OR_DIE(h->g_act_l[l], Mp * 4 * W * e);
+        }
+        ALLOC_OR_DIE(h->tokens, Mp * W * 4);
+        ALLOC_OR_DIE(h->dtok, Mp * W * 4);
+        if (h->bf16) {
+            h->Mpt = (long)Mp;
+            const size_t rows = (size_t)std::max(4 * W, h->Kpad);
+            ALLOC_OR_DIE(h->tA, rows * h->Mpt * 2);
+            ALLOC_OR_DIE(h->tB, rows * h->Mpt * 2);
+        }
+    }
     {
         const size_t sk = (size_t)8 * 256 * 4 * W * sizeof(float);   // 8 slabs x <=256 rows x 4W columns
         ALLOC_OR_DIE(h->splitk_scratch, sk);
@@ -629,6 +786,8 @@ extern "C" int rvlm_vit_forward(rvlm_vit* h, const float* x, const float* delta,
                                 int save_for_backward, float* out_emb, rvlm_stream_t stream) {
     RVLM_REQUIRE(h && x && out_emb, "rvlm_vit_forward: null argument");
     RVLM_REQUIRE(B > 0 && B <= h->maxB, "rvlm_vit_forward: batch exceeds max_batch");
+    RVLM_REQUIRE(save_for_backward != 2 || h->trainable, "rvlm_vit_forward: save_for_backward == 2 needs a trainable handle");
+    RVLM_REQUIRE(save_for_backward == 0 || !h->inference_only, "rvlm_vit_forward: inference-only handle cannot save activations");
     return vit_forward(h, x, delta, B, output_normalize, save_for_backward, out_emb, (hipStream_t)stream);
 }
 
@@ -638,6 +797,17 @@ extern "C" int rvlm_vit_backward_input(rvlm_vit* h, const float* d_emb, int B, f
     if (h->saved_B != B || B <= 0)
         return fail(RVLM_ERR_STATE, "rvlm_vit_backward_input: no saved forward for this batch size");
     return vit_backward(h, d_emb, B, grad_x, (hipStream_t)stream);
+}
+
+extern "C" int rvlm_vit_backward_params(rvlm_vit* h, const float* d_emb, int B, const rvlm_vit_weights* grads,
+                                        int accumulate, rvlm_stream_t stream) {
+    RVLM_REQUIRE(h && d_emb && grads && grads->blocks_host, "rvlm_vit_backward_params: null argument");
+    if (!h->trainable) return fail(RVLM_ERR_STATE, "rvlm_vit_backward_params: handle was not created trainable");
+    if (h->saved_B != B || B <= 0 || h->saved_mode != 2)
+        return fail(RVLM_ERR_STATE, "rvlm_vit_backward_params: needs a forward with save_for_backward == 2 for this batch");
+    hipStream_t s = (hipStream_t)stream;
+    return h->bf16 ? backward_params_impl<bf16_t>(h, d_emb, B, grads, accumulate, s)
+                   : backward_params_impl<float>(h, d_emb, B, grads, accumulate, s);
 }
 
 static int loss_step(rvlm_vit* h, const rvlm_loss_spec* ls, int B, int reduction, float* loss_scalar,

@@ -81,7 +81,7 @@ int col2im_grad(const T* dA0, long lda, int B, int img, int P, const float* std3
 template <typename T>
 int embed_lnpre_fwd(const T* patch_out, long ldp, const float* cls, const float* pos,
                     const float* gamma, const float* beta, float* x0, long ldx, float* mean,
-                    float* rstd, int B, int S, int W, hipStream_t s);
+                    float* rstd, int B, int S, int W, hipStream_t s, float* tokens_out = nullptr);
 // d_patch[b*(S-1)+s-1,:] = LN'(dx0[b*S+s,:]) for s >= 1
 template <typename T>
 int embed_lnpre_bwd(const float* dx0, long lddx, const float* patch_out, long ldp, const float* cls,
@@ -120,5 +120,20 @@ int convert_f32_to_bf16(const float* src, long lds_, bf16_t* dst, long ldd, int 
                         int transpose, hipStream_t s);  // dst[c,r] if transpose
 int scale_copy_f32(const float* src, float* dst, size_t n, float alpha, hipStream_t s);
 int fill_f32(float* dst, size_t n, float v, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// training-step support (train_kernels.hip)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+int transpose_pad(const T* in, long ldi, int R, int C, T* out, long ldo, int Rp, hipStream_t s);
+template <typename T>
+int colsum(const T* in, long ld, int R, int C, float* out, int accumulate, hipStream_t s);
+template <typename T>
+int ln_param_grad(const T* dy, long lddy, const float* x, long ldx, const float* mean, const float* rstd, int R,
+                  int C, float* dgamma, float* dbeta, int accumulate, hipStream_t s);
+int pos_cls_grad(const float* dtok, long ld, int B, int S, int W, float* dpos, float* dcls, int accumulate,
+                 hipStream_t s);
+template <typename T>
+int gather_patch_rows(const float* dtok, long ld, int B, int S, int W, T* d_patch, long ldp, hipStream_t s);
 
 }  // namespace rvlm

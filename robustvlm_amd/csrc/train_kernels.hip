@@ -1,0 +1,182 @@
+// Kernels of the outer training step (train_one_epoch's
+// loss.backward() / optimizer.step(), train/adversarial_training_clip.py:356-364): weight-gradient
+// support (transposes feeding the NT MFMA GEMM, column sums for biases, LayerNorm affine gradients,
+// positional / class-embedding gradients) and the AdamW update.  HBM-bound helpers; the wgrad FLOPs
+// themselves run on gemm_bf16_nt (contraction over the token dimension on transposed operands).
+#include "kernels.h"
+
+namespace rvlm {
+
+// out[c, r] = in[r, c] for r < R, zero for R <= r < Rp (the GEMM's K padding).  64x64 tiles via LDS.
+template <typename T>
+__global__ void __launch_bounds__(256)
+transpose_kernel(const T* __restrict__ in, long ldi, int R, int C, T* __restrict__ out, long ldo, int Rp) {
+    __shared__ T tile[64][64 + 2];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = r0 + ty * 16 + i, c = c0 + tx;
+        tile[ty * 16 + i][tx] = (r < R && c < C) ? in[(long)r * ldi + c] : from_f32<T>(0.0f);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = c0 + ty * 16 + i, r = r0 + tx;
+        if (c < C && r < Rp) out[(long)c * ldo + r] = tile[tx][ty * 16 + i];
+    }
+}
+template <typename T>
+int transpose_pad(const T* in, long ldi, int R, int C, T* out, long ldo, int Rp, hipStream_t s) {
+    hipLaunchKernelGGL((transpose_kernel<T>), dim3(cdiv(C, 64), cdiv(Rp, 64)), dim3(256), 0, s, in, ldi, R, C, out,
+                       ldo, Rp);
+    RVLM_CHECK_LAUNCH();
+    return RVLM_OK;
+}
+template int transpose_pad<bf16_t>(const bf16_t*, long, int, int, bf16_t*, long, int, hipStream_t);
+
+// out[c] (+)= sum_r in[r, c]      block = 64 columns x 4 row lanes, rows strided by 4
+template <typename T>
+__global__ void __launch_bounds__(256)
+colsum_kernel(const T* __restrict__ in, long ld, int R, int C, float* __restrict__ out, int accumulate) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    float acc = 0.0f;
+    if (c < C)
+        for (int r = rl; r < R; r += 4) acc += to_f32(in[(long)r * ld + c]);
+    red[rl][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        out[c] = (accumulate ? out[c] : 0.0f) + v;
+    }
+}
+template <typename T>
+int colsum(const T* in, long ld, int R, int C, float* out, int accumulate, hipStream_t s) {
+    hipLaunchKernelGGL((colsum_kernel<T>), dim3(cdiv(C, 64)), dim3(256), 0, s, in, ld, R, C, out, accumulate);
+    RVLM_CHECK_LAUNCH();
+    return RVLM_OK;
+}
+template int colsum<float>(const float*, long, int, int, float*, int, hipStream_t);
+template int colsum<bf16_t>(const bf16_t*, long, int, int, float*, int, hipStream_t);
+
+// LayerNorm affine gradients: dgamma[c] (+)= sum_r dy[r,c] * (x[r,c]-mean[r])*rstd[r]; dbeta[c] (+)= sum_r dy[r,c]
+template <typename T>
+__global__ void __launch_bounds__(256)
+ln_param_grad_kernel(const T* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx,
+                     const float* __restrict__ mean, const float* __restrict__ rstd, int R, int C,
+                     float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
+    __shared__ float rg[4][64], rb[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    float ag = 0.0f, ab = 0.0f;
+    if (c < C)
+        for (int r = rl; r < R; r += 4) {
+            const float d = to_f32(dy[(long)r * lddy + c]);
+            const float xh = (x[(long)r * ldx + c] - mean[r]) * rstd[r];
+            ag = fmaf(d, xh, ag);
+            ab += d;
+        }
+    rg[rl][threadIdx.x & 63] = ag;
+    rb[rl][threadIdx.x & 63] = ab;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        const int t = threadIdx.x;
+        dgamma[c] = (accumulate ? dgamma[c] : 0.0f) + ((rg[0][t] + rg[1][t]) + (rg[2][t] + rg[3][t]));
+        dbeta[c] = (accumulate ? dbeta[c] : 0.0f) + ((rb[0][t] + rb[1][t]) + (rb[2][t] + rb[3][t]));
+    }
+}
+template <typename T>
+int ln_param_grad(const T* dy, long lddy, const float* x, long ldx, const float* mean, const float* rstd, int R,
+                  int C, float* dgamma, float* dbeta, int accumulate, hipStream_t s) {
+    hipLaunchKernelGGL((ln_param_grad_kernel<T>), dim3(cdiv(C, 64)), dim3(256), 0, s, dy, lddy, x, ldx, mean, rstd, R,
+                       C, dgamma, dbeta, accumulate);
+    RVLM_CHECK_LAUNCH();
+    return RVLM_OK;
+}
+template int ln_param_grad<float>(const float*, long, const float*, long, const float*, const float*, int, int,
+                                  float*, float*, int, hipStream_t);
+template int ln_param_grad<bf16_t>(const bf16_t*, long, const float*, long, const float*, const float*, int, int,
+                                   float*, float*, int, hipStream_t);
+
+// positional-embedding gradient: dpos[s, c] (+)= sum_b dtok[b*S + s, c]; class embedding = row s = 0
+__global__ void __launch_bounds__(256)
+pos_grad_kernel(const float* __restrict__ dtok, long ld, int B, int S, int W, float* __restrict__ dpos,
+                float* __restrict__ dcls, int accumulate) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)S * W) return;
+    const int sidx = (int)(idx / W), c = (int)(idx - (long)sidx * W);
+    float acc = 0.0f;
+    for (int b = 0; b < B; ++b) acc += dtok[((long)b * S + sidx) * ld + c];
+    dpos[idx] = (accumulate ? dpos[idx] : 0.0f) + acc;
+    if (sidx == 0) dcls[c] = (accumulate ? dcls[c] : 0.0f) + acc;
+}
+int pos_cls_grad(const float* dtok, long ld, int B, int S, int W, float* dpos, float* dcls, int accumulate,
+                 hipStream_t s) {
+    hipLaunchKernelGGL(pos_grad_kernel, dim3(cdiv((long)S * W, 256)), dim3(256), 0, s, dtok, ld, B, S, W, dpos, dcls,
+                       accumulate);
+    RVLM_CHECK_LAUNCH();
+    return RVLM_OK;
+}
+
+// d_patch[b*(S-1) + s-1, :] = (T) dtok[b*S + s, :]   (drop the CLS rows, cast for the conv wgrad / dgrad GEMM)
+template <typename T>
+__global__ void __launch_bounds__(256)
+gather_patch_rows_kernel(const float* __restrict__ dtok, long ld, int B, int S, int W, T* __restrict__ d_patch,
+                         long ldp) {
+    const long total = (long)B * (S - 1) * W;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long prow = idx / W;
+        const int c = (int)(idx - prow * W);
+        const long b = prow / (S - 1), sidx = prow - b * (S - 1) + 1;
+        d_patch[prow * ldp + c] = from_f32<T>(dtok[(b * S + sidx) * ld + c]);
+    }
+}
+template <typename T>
+int gather_patch_rows(const float* dtok, long ld, int B, int S, int W, T* d_patch, long ldp, hipStream_t s) {
+    const long total = (long)B * (S - 1) * W;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL((gather_patch_rows_kernel<T>), dim3(grid), dim3(256), 0, s, dtok, ld, B, S, W, d_patch, ldp);
+    RVLM_CHECK_LAUNCH();
+    return RVLM_OK;
+}
+template int gather_patch_rows<float>(const float*, long, int, int, int, float*, long, hipStream_t);
+template int gather_patch_rows<bf16_t>(const float*, long, int, int, int, bf16_t*, long, hipStream_t);
+
+// torch.optim.AdamW single-tensor update (decoupled weight decay), fp32 master weights:
+//   p *= 1 - lr*wd;  m = b1*m + (1-b1)*g;  v = b2*v + (1-b2)*g*g;
+//   p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+__global__ void __launch_bounds__(256)
+adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+             size_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+             float grad_scale) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * grad_scale;
+        float pi = p[i];
+        pi = pi * (1.0f - lr * wd);
+        const float mi = m[i] + (gi - m[i]) * (1.0f - b1);          // lerp form used by torch
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        pi = pi - (lr / bc1) * (mi / denom);
+        p[i] = pi; m[i] = mi; v[i] = vi;
+    }
+}
+
+}  // namespace rvlm
+
+using namespace rvlm;
+
+extern "C" int rvlm_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n,
+                               float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                               float grad_scale, rvlm_stream_t stream) {
+    RVLM_REQUIRE(params && grads && exp_avg && exp_avg_sq && step >= 1, "rvlm_adamw_step: bad arguments");
+    const float bc1 = 1.0f - powf(beta1, (float)step);
+    const float bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
+    size_t blocks = (n + 1023) / 1024;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(adamw_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
+                       exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_scale);
+    RVLM_CHECK_LAUNCH();
+    return RVLM_OK;
+}

@@ -243,7 +243,8 @@ __global__ void __launch_bounds__(256)
 embed_lnpre_fwd_kernel(const T* __restrict__ patch_out, long ldp, const float* __restrict__ cls,
                        const float* __restrict__ pos, const float* __restrict__ gamma,
                        const float* __restrict__ beta, float* __restrict__ x0, long ldx,
-                       float* __restrict__ mean, float* __restrict__ rstd, int B, int S, int W) {
+                       float* __restrict__ mean, float* __restrict__ rstd, int B, int S, int W,
+                       float* __restrict__ tokens_out) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= B * S) return;
@@ -260,6 +261,7 @@ embed_lnpre_fwd_kernel(const T* __restrict__ patch_out, long ldp, const float* _
             load4(pos + (long)sidx * W + c, p);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[it][e] = a[e] + p[e]; sum += v[it][e]; }
+            if (tokens_out) store4(tokens_out + (long)row * ldx + c, v[it]);
         }
     }
     const float mu = wave_sum(sum) / (float)W;
@@ -290,16 +292,16 @@ embed_lnpre_fwd_kernel(const T* __restrict__ patch_out, long ldp, const float* _
 template <typename T>
 int embed_lnpre_fwd(const T* patch_out, long ldp, const float* cls, const float* pos,
                     const float* gamma, const float* beta, float* x0, long ldx, float* mean,
-                    float* rstd, int B, int S, int W, hipStream_t s) {
+                    float* rstd, int B, int S, int W, hipStream_t s, float* tokens_out) {
     if (W % 4 != 0 || W > LN_MAXV * 256) return fail(RVLM_ERR_UNSUPPORTED, "embed: width");
     hipLaunchKernelGGL((embed_lnpre_fwd_kernel<T>), dim3(cdiv((long)B * S, 4)), dim3(256), 0, s,
-                       patch_out, ldp, cls, pos, gamma, beta, x0, ldx, mean, rstd, B, S, W);
+                       patch_out, ldp, cls, pos, gamma, beta, x0, ldx, mean, rstd, B, S, W, tokens_out);
     RVLM_CHECK_LAUNCH();
     return RVLM_OK;
 }
 template int embed_lnpre_fwd<float>(const float*, long, const float*, const float*, const float*,
                                     const float*, float*, long, float*, float*, int, int, int,
-                                    hipStream_t);
+                                    hipStream_t, float*);
 
 template <typename TP, typename T>
 __global__ void __launch_bounds__(256)

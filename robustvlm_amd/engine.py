@@ -25,7 +25,8 @@ class VitEngine:
     precision: 'bf16' (MFMA throughput path) or 'fp32' (parity path, config C1)."""
 
     def __init__(self, cfg, state_dict: dict, precision: str = "bf16", max_batch: int = 128,
-                 mean=CLIP_MEAN, std=CLIP_STD, device=None):
+                 mean=CLIP_MEAN, std=CLIP_STD, device=None, trainable: bool = False,
+                 inference_only: bool = False):
         if isinstance(cfg, str):
             cfg = CONFIGS[cfg]
         if not torch.cuda.is_available():
@@ -46,6 +47,8 @@ class VitEngine:
         if precision not in ("bf16", "fp32"):
             raise ValueError(f"precision {precision!r} not supported")
         c.max_batch = self.max_batch
+        c.trainable = 1 if trainable else (-1 if inference_only else 0)
+        self.trainable = bool(trainable)
         c.mean = (C.c_float * 3)(*self.mean)
         c.std = (C.c_float * 3)(*self.std)
         with torch.cuda.device(self.device):
@@ -55,14 +58,21 @@ class VitEngine:
         del keep
 
     # ---- weights ------------------------------------------------------------------------------
-    def _weights_struct(self, sd: dict):
+    def _weights_struct(self, sd: dict, inplace: bool = False):
+        """ctypes view of a state-dict-shaped collection of fp32 device tensors.  inplace=True requires the
+        tensors themselves (contiguous fp32 on this device) - used for gradient OUTPUT buffers."""
         cfg = self.cfg
         shapes = state_dict_shapes(cfg)
         keep = {}
         for k, shp in shapes.items():
             if k not in sd:
                 raise KeyError(f"state_dict is missing {k!r}")
-            t = _f32c(sd[k]).to(self.device)
+            if inplace:
+                t = sd[k]
+                if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                    raise ValueError(f"{k}: gradient buffers must be contiguous fp32 CUDA tensors")
+            else:
+                t = _f32c(sd[k]).to(self.device)
             if tuple(t.shape) != tuple(shp):
                 raise ValueError(f"{k}: shape {tuple(t.shape)} != {tuple(shp)}")
             keep[k] = t
@@ -102,11 +112,23 @@ class VitEngine:
         out = torch.empty(B, self.cfg.out_dim, device=x.device, dtype=torch.float32)
         with torch.cuda.device(x.device):
             L.check(self.lib.rvlm_vit_forward(self._h, x.data_ptr(), L.ptr(d), B, int(bool(output_normalize)),
-                                              int(bool(save)), out.data_ptr(), L.stream_ptr()),
+                                              int(save), out.data_ptr(), L.stream_ptr()),
                     "rvlm_vit_forward")
         if save:
             self.generation += 1
         return out
+
+    def backward_params(self, d_emb, grads: dict, accumulate: bool = False):
+        """Weight gradients of the last ``forward(..., save=2)`` into the fp32 tensors of ``grads``
+        (state_dict keys / shapes); rvlm_vit_backward_params."""
+        _require_cuda(d_emb, "d_emb")
+        d = _f32c(d_emb)
+        with torch.cuda.device(d.device):
+            w, keep = self._weights_struct(grads, inplace=True)
+            L.check(self.lib.rvlm_vit_backward_params(self._h, d.data_ptr(), d.shape[0], C.byref(w),
+                                                      int(bool(accumulate)), L.stream_ptr()),
+                    "rvlm_vit_backward_params")
+        del keep
 
     def backward_input(self, d_emb) -> torch.Tensor:
         _require_cuda(d_emb, "d_emb")
