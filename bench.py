@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--attack", default="pgd", choices=["pgd", "apgd", "autopgd"],
                     help="pgd: BASELINE configs 2/4 (FARE); apgd: config 3 (TeCoA apgd_train); autopgd: config 5 "
                          "(APGDAttack CE on the zero-shot head, use --iterations 100 --batch 256)")
+    ap.add_argument("--mode", default="attack", choices=["attack", "train"],
+                    help="attack (default, the BASELINE metric): one pgd()/apgd call per step; train: one full "
+                         "FARE/TeCoA optimizer step per step (e0 + attack + fwd + wgrad backward + grad all-reduce + AdamW)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -76,6 +79,48 @@ def cpu_baseline(iterations_full=10):
                       f"host has {os.cpu_count()} hardware threads"}
 
 
+def bench_train(args, R, cfg, sd, dev, dist, world, rank):
+    """Full training step (the 'next' row of SURVEY.md 8(f)): reported separately from the headline metric."""
+    from robustvlm_amd.trainer import AdversarialTrainer
+    B = args.batch
+    tr = AdversarialTrainer(cfg, sd, batch_size=B, precision=args.precision, attack=args.attack if args.attack != "autopgd" else "pgd",
+                            iterations_adv=args.iterations, device=dev)
+    g = torch.Generator(device=dev).manual_seed(1000 + rank)
+    x = torch.rand(B, 3, cfg.image_size, cfg.image_size, generator=g, device=dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        tr.train_step(x, None)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = tr.train_step(x, None)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    barrier()
+    if rank == 0:
+        print(json.dumps({
+            "metric": f"FARE training images/sec ({args.model}, {args.iterations}-step {args.attack} + optimizer step)",
+            "value": world * B * args.steps / el, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"full train_one_epoch step: e0 + {args.attack} {args.iterations}-step + adv forward + "
+                                   f"weight-gradient backward + flat-buffer all-reduce + AdamW, {args.model} {args.precision}, "
+                                   f"batch={B} per GPU", "global_batch": world * B,
+                       "parallelism": f"dp{world} (1 RCCL all-reduce of {tr.params.numel} fp32 grads per step)"},
+            "final_loss": float(out["loss"])}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -96,10 +141,12 @@ def main():
     import robustvlm_amd as R
     cfg = R.CONFIGS[args.model]
     sd = R.random_state_dict(cfg, seed=0, device=dev)           # same weights on every rank
+    B = args.batch
+    if args.mode == "train":
+        return bench_train(args, R, cfg, sd, dev, dist, world, rank)
     eng = R.VitEngine(cfg, sd, precision=args.precision, max_batch=args.batch, device=dev)
     del sd
     model = R.ClipVisionModel(eng).eval()
-    B = args.batch
     g = torch.Generator(device=dev).manual_seed(1000 + rank)   # each rank its own shard of images
     x = torch.rand(B, 3, cfg.image_size, cfg.image_size, generator=g, device=dev)
     eps, stepsize = 4 / 255, 1 / 255

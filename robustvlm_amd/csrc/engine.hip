@@ -15,6 +15,7 @@
 namespace rvlm {
 void attn_set_use_tr(int on);
 void gemm_set_splitk_scratch(float* ptr, size_t bytes);
+void set_reduce_scratch(float* p, size_t floats);
 
 struct Layer {
     float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *b_in, *b_out, *b_fc, *b_proj;
@@ -740,9 +741,18 @@ extern "C" int rvlm_vit_create(const rvlm_vit_config* cfg, const rvlm_vit_weight
         }
     }
     {
-        const size_t sk = (size_t)8 * 256 * 4 * W * sizeof(float);   // 8 slabs x <=256 rows x 4W columns
+        // split-K slabs: 8 x <=256 rows x 4W columns for the remainder GEMMs; trainable handles also run
+        // the weight-gradient GEMMs split-K (few output tiles, K = all tokens): up to 3 x [3W, W] slabs
+        size_t sk = (size_t)8 * 256 * 4 * W * sizeof(float);
+        if (cfg->trainable > 0) sk = std::max(sk, (size_t)16 * W * W * sizeof(float));
         ALLOC_OR_DIE(h->splitk_scratch, sk);
         gemm_set_splitk_scratch(h->splitk_scratch, sk);
+        if (cfg->trainable > 0) {
+            const size_t rf = (size_t)2 * 128 * 4 * W;      // [2][RED_NCH][4W] partial column sums
+            float* rs = nullptr;
+            ALLOC_OR_DIE(rs, rf * sizeof(float));
+            set_reduce_scratch(rs, rf);
+        }
     }
     const size_t npix = (size_t)B * 3 * h->img * h->img;
     for (int i = 0; i < 5; ++i) ALLOC_OR_DIE(h->img_buf[i], npix * 4);

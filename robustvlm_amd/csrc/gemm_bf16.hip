@@ -237,6 +237,36 @@ int gemm_bf16_nt(const GemmBf16& p, hipStream_t s) {
         return fail(RVLM_ERR_UNSUPPORTED, "gemm_bf16_nt: need K%64==0, N%4==0, lda/ldb%8==0, ldo%4==0");
     if (p.epi == EPI_BF16_ACT && !p.out_pre) return fail(RVLM_ERR_ARG, "gemm_bf16_nt: out_pre");
     if (p.epi == EPI_BF16_DACT && !p.h_pre) return fail(RVLM_ERR_ARG, "gemm_bf16_nt: h_pre");
+    // deep-K, few-tile problems (the weight-gradient GEMMs: K = all tokens, <= 256 output tiles): split K so
+    // that >= 2 workgroups per CU are busy, fp32 slabs + deterministic reduce/epilogue kernel
+    if (p.K >= 8192 && (p.epi == EPI_F32 || p.epi == EPI_F32_RESID) && g_splitk_scratch) {
+        const int tiles = cdiv(p.M, GB_M) * cdiv(p.N, GB_N);
+        int splitk = 1;
+        const int nk64 = p.K / GB_K;
+        for (int cand : {2, 3, 4, 6, 12}) {
+            if (nk64 % cand == 0 && (size_t)cand * p.M * p.N * sizeof(float) <= g_splitk_bytes) {
+                splitk = cand;
+                if (tiles * cand >= 512) break;
+            }
+        }
+        if (splitk > 1) {
+            GemmBf16 part = p;
+            part.epi = EPI_F32; part.bias = nullptr; part.residual = nullptr; part.out = g_splitk_scratch;
+            part.ldo = p.N; part.out_pre = nullptr; part.h_pre = nullptr;
+            part.a_rows = p.a_rows > 0 ? p.a_rows : p.M;
+            const int tiles_m = cdiv(p.M, GB_M), tiles_n = cdiv(p.N, GB_N);
+            hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI_F32>), dim3(tiles_m * tiles_n, splitk), dim3(256), 0, s, part,
+                               tiles_m, tiles_n, part.a_rows, 0);
+            RVLM_CHECK_LAUNCH();
+            const int rb = cdiv((long)p.M * (p.N / 4), 256);
+            if (p.epi == EPI_F32_RESID)
+                hipLaunchKernelGGL((splitk_reduce_kernel<EPI_F32_RESID>), dim3(rb), dim3(256), 0, s, g_splitk_scratch, splitk, p);
+            else
+                hipLaunchKernelGGL((splitk_reduce_kernel<EPI_F32>), dim3(rb), dim3(256), 0, s, g_splitk_scratch, splitk, p);
+            RVLM_CHECK_LAUNCH();
+            return RVLM_OK;
+        }
+    }
     int done = 0;
     const int variant = gemm_variant();
     const bool big = variant == 1 || (variant == 2 && (p.epi == EPI_BF16 || p.K >= 2048));

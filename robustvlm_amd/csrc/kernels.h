@@ -126,6 +126,7 @@ int fill_f32(float* dst, size_t n, float v, hipStream_t s);
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 int transpose_pad(const T* in, long ldi, int R, int C, T* out, long ldo, int Rp, hipStream_t s);
+void set_reduce_scratch(float* p, size_t floats);
 template <typename T>
 int colsum(const T* in, long ld, int R, int C, float* out, int accumulate, hipStream_t s);
 template <typename T>
