@@ -69,7 +69,8 @@ typedef struct {
     int32_t max_batch;  /* workspace is sized for this many images */
     float mean[3];      /* Normalize constants, …clip.py:116 */
     float std[3];
-    int32_t trainable;  /* != 0: also keep what the weight-gradient backward needs (rvlm_vit_backward_params) */
+    int32_t trainable;  /* > 0: also keep what the weight-gradient backward needs (rvlm_vit_backward_params);
+                           < 0: inference only (frozen model_orig copy): no per-layer activation storage */
 } rvlm_vit_config;
 
 /* fp32 device pointers in `visual.state_dict()` layout (…clip.py:239,470; Appendix B key list). */
