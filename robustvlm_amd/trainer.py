@@ -155,4 +155,21 @@ class AdversarialTrainer:
         return dict(loss=loss, loss_clean=loss_clean, lr=lr_used)
 
     def state_dict(self):
+        """open_clip ``visual.state_dict()`` of the fine-tuned tower (what …clip.py:239,470 saves)."""
         return self.params.state_dict()
+
+    def optimizer_state_dict(self):
+        """AdamW state keyed by parameter name (see robustvlm_amd/checkpoint.py)."""
+        def split(flat):
+            return {k: flat[o:o + c].view(self.params.shapes[k]).clone() for k, (o, c) in self.params.offsets.items()}
+        return {"step": self.step_total, "exp_avg": split(self.exp_avg), "exp_avg_sq": split(self.exp_avg_sq),
+                "lr": self.lr, "wd": self.wd, "betas": self.betas, "eps": self.adam_eps}
+
+    def load_optimizer_state_dict(self, sd, start_step=None):
+        """Resume (…clip.py:207-208,219): restores the moments and the step counter; the LR schedule is a pure
+        function of the step."""
+        for k, (o, c) in self.params.offsets.items():
+            self.exp_avg[o:o + c].copy_(sd["exp_avg"][k].reshape(-1).to(self.device))
+            self.exp_avg_sq[o:o + c].copy_(sd["exp_avg_sq"][k].reshape(-1).to(self.device))
+        self.step_total = int(sd["step"] if start_step is None else start_step)
+        self.cur_lr = cosine_lr_value(self.step_total, self.lr, self.warmup, self.steps)

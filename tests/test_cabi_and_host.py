@@ -116,3 +116,30 @@ def test_two_rank_gloo(tmp_path):
     for p in procs:
         out, _ = p.communicate(timeout=120)
         assert p.returncode == 0, out.decode()
+
+
+def test_checkpoint_layout_and_formats(tmp_path):
+    """File names / cadence of …clip.py:239-244,467-479 and the two on-disk model formats."""
+    import torch
+    from robustvlm_amd import CheckpointWriter, load_visual_state_dict, resume_paths, VitConfig, state_dict_shapes
+    cfg = VitConfig(32, 8, 64, 1, 1, 16)
+    sd = {k: torch.zeros(s) for k, s in state_dict_shapes(cfg).items()}
+    out = str(tmp_path / "run_temp")
+    w = CheckpointWriter(out, steps=1000)
+    for step in (100, 200, 300, 400):
+        w.after_step(step, lambda: sd, lambda: {"step": step})
+    files = sorted(os.listdir(os.path.join(out, "checkpoints")))
+    assert files == ["fallback_400.pt", "fallback_400_opt.pt", "step_100.pt", "step_100_opt.pt", "step_200.pt",
+                     "step_200_opt.pt", "step_300.pt", "step_300_opt.pt", "step_400.pt", "step_400_opt.pt"]
+    final_dir = w.final(sd, {"step": 1000})
+    assert final_dir.endswith("run") and os.path.exists(os.path.join(final_dir, "checkpoints", "final_opt.pt"))
+    model_file, opt_file = resume_paths(os.path.join(final_dir, "checkpoints", "step_300_opt.pt"), 300)
+    assert model_file.endswith("step_300.pt")
+    got = load_visual_state_dict(model_file, cfg)
+    assert set(got) == set(sd)
+    tecoa = tmp_path / "tecoa.pt"
+    torch.save({"vision_encoder_state_dict": sd}, tecoa)                 # CLIP_eval/eval_utils.py:45-46
+    assert set(load_visual_state_dict(str(tecoa), cfg)) == set(sd)
+    bad = dict(sd); bad.pop("proj")
+    with pytest.raises(KeyError):
+        load_visual_state_dict(bad, cfg)
