@@ -30,6 +30,12 @@ int rvlm_k_attn_bwd_bf16(const uint16_t* qkv, const uint16_t* o, const uint16_t*
 int rvlm_k_attn_set_use_tr(int on);
 /* 0: 128x128 GEMM kernel only; 1: 256x256 4-stage kernel (+128x128 on remainder rows); -1: env RVLM_GEMM_VARIANT */
 int rvlm_k_gemm_set_variant(int v);
+/* persistent 256x256 kernel: device buffer of 256*8*4 uint64 receiving per-tile s_memtime stamps (tile start, first
+ * K-step done, mainloop done, epilogue issued); NULL switches tracing off */
+int rvlm_k_gemm_set_trace(void* ptr);
+/* persistent kernel timing experiments (results become garbage): bit 0 no operand DMA, bit 1 no MFMA, bit 2 no LDS
+ * fragment reads; 0 = normal */
+int rvlm_k_gemm_set_ablate(int v);
 /* workgroups per CU reported by the runtime for attn fwd (96-VGPR build), attn fwd (default), attn dq */
 int rvlm_k_attn_occupancy(int S, int* out3);
 int rvlm_k_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y,

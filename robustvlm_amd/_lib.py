@@ -128,6 +128,8 @@ _SIGS = {
                                        C.c_void_p, C.c_int, C.c_int, C.c_int, c_stream]),
     "rvlm_k_attn_set_use_tr": (C.c_int, [C.c_int]),
     "rvlm_k_gemm_set_variant": (C.c_int, [C.c_int]),
+    "rvlm_k_gemm_set_trace": (C.c_int, [C.c_void_p]),
+    "rvlm_k_gemm_set_ablate": (C.c_int, [C.c_int]),
     "rvlm_k_attn_occupancy": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
     "rvlm_k_layernorm_fwd_f32": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int,
                                            C.c_int, c_stream]),

@@ -181,6 +181,13 @@ static size_t g_splitk_bytes = 0;
 void gemm_set_splitk_scratch(float* ptr, size_t bytes) { g_splitk_scratch = ptr; g_splitk_bytes = bytes; }
 
 int gemm_bf16_nt_256(const GemmBf16& p, int* rows_done, hipStream_t s);
+int gemm_bf16_nt_256p(const GemmBf16& p, int* rows_done, hipStream_t s);
+
+static int g_persist = -1;
+static int gemm_persist() {
+    if (g_persist < 0) { const char* e = getenv("RVLM_GEMM_PERSIST"); g_persist = e ? atoi(e) : 0; }
+    return g_persist;
+}
 
 // 0: 128x128 kernel only; 1: 256x256 kernel (+128x128 on the remainder rows) wherever it applies;
 // 2 (default): per-shape choice measured on MI355X (scripts/gemm_bench.py): the 256x256 4-stage kernel
@@ -271,7 +278,10 @@ int gemm_bf16_nt(const GemmBf16& p, hipStream_t s) {
     const int variant = gemm_variant();
     const bool big = variant == 1 || (variant == 2 && (p.epi == EPI_BF16 || p.K >= 2048));
     if (big) {
-        int rc = gemm_bf16_nt_256(p, &done, s);
+        int rc = RVLM_OK;
+        if (gemm_persist()) rc = gemm_bf16_nt_256p(p, &done, s);
+        if (rc) return rc;
+        if (done == 0) rc = gemm_bf16_nt_256(p, &done, s);
         if (rc) return rc;
         if (done >= p.M) return RVLM_OK;
     }

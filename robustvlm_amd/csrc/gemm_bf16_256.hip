@@ -324,6 +324,136 @@ gemm_bf16_nt_256s_kernel(GemmBf16 p, int tiles_m, int tiles_n) {
     gemm_epilogue<EPI, 4, 2>(acc, p, m0 + wm * 128, n0 + wn * 64, lane, lds + w * EPI_LDS_BYTES_PER_WAVE);
 }
 
+
+// =================================================================================================
+// BK = 64 schedule ("k64").  Same 256x256 tile and wave layout, but LDS rows are 128 B (one full L2
+// line per operand row per K-step) and the ring is 2 x 64 KiB.  Motivation (PMC, cube 8192): the BK=32
+// kernel above and the 128x128x64 kernel issue the SAME number of TCC requests per second (~136 G/s)
+// although the latter moves twice the bytes -- the 64-B rows of BK=32 halve the payload per request.
+// One barrier per 64-deep K-step, placed between the last fragment read of the step and its last MFMA
+// group: after it (a) stage kt+1 (issued a full K-step earlier) is visible to every wave and (b) the slot
+// of stage kt is free, so stage kt+2 is issued and the first fragments of stage kt+1 are fetched while the
+// last 8 MFMAs of stage kt run.  Only one stage is ever in flight at the wait, so it is a plain vmcnt(0).
+// =================================================================================================
+constexpr int K64_OPER_BYTES = L_M * 64 * 2;       // 32 KiB per operand per stage
+constexpr int K64_STAGE_BYTES = 2 * K64_OPER_BYTES;
+
+template <int EPI>
+__global__ void __launch_bounds__(512)
+gemm_bf16_nt_256k_kernel(GemmBf16 p, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int nwg = gridDim.x, pid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = pid & 7, loc = pid >> 3;
+    const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+    const int group_size = 8 * tiles_n;
+    const int first_m = (t / group_size) * 8;
+    const int gm = min(tiles_m - first_m, 8);
+    const int tm = first_m + (t % group_size) % gm;
+    const int tn = (t % group_size) / gm;
+    const int m0 = tm * L_M, n0 = tn * L_N;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 2, wn = w & 3;
+
+    // ---- staging: wave w loads rows [32w, 32w+32) of both operand tiles, 8 rows x 128 B per DMA ----
+    const bf16_t* a_src[4];
+    const bf16_t* b_src[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = w * 32 + j * 8 + (lane >> 3);
+        const int clog = (lane & 7) ^ ((r >> 1) & 7);
+        a_src[j] = p.A + (long)(m0 + r) * p.lda + clog * 8;
+        b_src[j] = p.Bw + (long)(n0 + r) * p.ldb + clog * 8;
+    }
+    const int stage_wave_off = (w * 32) * 128;
+
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int swz = (l31 >> 1) & 7;
+    int koff[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) koff[kk] = ((kk * 2 + hi) ^ swz) << 4;
+    const int a_row_off = (wm * 128 + l31) * 128;
+    const int b_row_off = K64_OPER_BYTES + (wn * 64 + l31) * 128;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int nk = p.K / 64;
+    auto issue = [&](int kt) {
+        char* dst = lds + (kt & 1) * K64_STAGE_BYTES + stage_wave_off;
+        const int ko = kt * 64;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            glds16b(a_src[j] + ko, dst + j * 1024);
+            glds16b(b_src[j] + ko, dst + K64_OPER_BYTES + j * 1024);
+        }
+    };
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+    auto load_frags = [&](int kt, int kk, i32x4 (&a)[4], i32x4 (&b)[2]) {
+        const unsigned st = lds_base + (kt & 1) * K64_STAGE_BYTES + koff[kk];
+        const unsigned aa = st + a_row_off, bb = st + b_row_off;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(a[0]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(a[1]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(a[2]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(a[3]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(b[0]) : "v"(bb));
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(b[1]) : "v"(bb));
+    };
+    auto mma = [&](const i32x4 (&a)[4], const i32x4 (&b)[2]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b[j]),
+                                                                    __builtin_bit_cast(bf16x8, a[i]), acc[i][j],
+                                                                    0, 0, 0);
+    };
+
+    i32x4 a0[4], b0[2], a1[4], b1[2];
+    issue(0);
+    if (nk > 1) { issue(1); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    load_frags(0, 0, a0, b0);
+    for (int kt = 0; kt < nk; ++kt) {
+        load_frags(kt, 1, a1, b1);
+        asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags(kt, 2, a0, b0);
+        asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags(kt, 3, a1, b1);
+        asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        // last reads of stage kt landed + own DMA of stage kt+1 landed -> publish / free the slot
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 2 < nk) issue(kt + 2);
+        if (kt + 1 < nk) load_frags(kt + 1, 0, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    __builtin_amdgcn_s_barrier();   // every wave is done with the ring
+    gemm_epilogue<EPI, 4, 2>(acc, p, m0 + wm * 128, n0 + wn * 64, lane, lds + w * EPI_LDS_BYTES_PER_WAVE);
+}
+
 template <int EPI>
 static int launch_256(const GemmBf16& p, int tiles_m, int tiles_n, hipStream_t s) {
     static bool attr_set = false;
@@ -339,7 +469,17 @@ static int launch_256(const GemmBf16& p, int tiles_m, int tiles_n, hipStream_t s
         if (e != hipSuccess) return fail(RVLM_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
         attr_set = true;
     }
-    if (prio == 2) {
+    if (prio == 3 && p.K % 64 == 0) {
+        static bool attr3 = false;
+        if (!attr3) {
+            hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_nt_256k_kernel<EPI>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * K64_STAGE_BYTES);
+            if (e != hipSuccess) return fail(RVLM_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
+            attr3 = true;
+        }
+        hipLaunchKernelGGL((gemm_bf16_nt_256k_kernel<EPI>), dim3(tiles_m * tiles_n), dim3(512), 2 * K64_STAGE_BYTES, s, p,
+                           tiles_m, tiles_n);
+    } else if (prio == 2) {
         static bool attr2 = false;
         if (!attr2) {
             hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_nt_256s_kernel<EPI>,

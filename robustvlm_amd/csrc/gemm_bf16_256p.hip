@@ -1,0 +1,532 @@
+// bf16 MFMA GEMM for gfx950, PERSISTENT 256x256 variant ("256p").
+//
+// Why: with one 256x256 workgroup per CU and one tile per workgroup, every CU of the chip runs its
+// pipeline fill and its epilogue at the same moment.  Measured on the encoder's shapes (M = 32 896,
+// K = 1024) the per-tile fixed cost was 13 us (plain bf16 store) to 33 us (fp32 residual read + write) on a
+// 28 us mainloop: the residual loads sat on a load -> wait -> store chain four times per wave, the DMA
+// prologue waited a full HBM round trip, and a new workgroup had to be dispatched per tile.
+//
+// Structure:
+//   * 256 workgroups (one per CU, 128 KiB of LDS each) walk the tile list; tile -> (m, n) keeps the
+//     XCD-aware grouped order of the other kernels.
+//   * mainloop = the BK = 64 schedule of gemm_bf16_256.hip ("k64": 128-B LDS rows, 2 x 64 KiB ring, one
+//     barrier per K-step, fragments double-buffered in registers).  The operand stream is CONTINUOUS
+//     across tiles: stage 0 of the next tile is issued two K-steps before the current tile ends.
+//   * the fp32 residual is not read in the epilogue: the accumulators of the NEXT tile are initialised
+//     with it (loads in the MFMA D layout, issued as soon as a 32-row group of the current tile has been
+//     staged for storing), so its latency hides under the epilogue stores and the DMA of stage 1; the
+//     bias is added to the start values at the tile seam (its registers are only live while the fragment
+//     registers are not).
+//   * every global address is an SGPR base + a 32-bit per-lane offset that is constant for the whole
+//     kernel (nothing lane-dependent is recomputed or spilled around the tile loop).
+//   * epilogue = wave-private LDS transpose (8 KiB per wave in the ring slot that the last K-step
+//     freed) -> full-line 16-B-per-lane stores, fire and forget; the only VMEM wait at the tile seam is
+//     the counted vmcnt(8) that also guards stage 0 of the next tile.
+//
+// Requirements: M % 256 == 0 rows handled here, N % 256 == 0, K % 128 == 0 (even number of stages, so
+// every tile starts in ring slot 0).
+#include "kernels.h"
+#include "gemm_epilogue.h"
+
+namespace rvlm {
+
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+constexpr int P_M = 256, P_N = 256, P_K = 64;
+constexpr int P_OPER_BYTES = P_M * P_K * 2;      // 32 KiB per operand per stage
+constexpr int P_STAGE_BYTES = 2 * P_OPER_BYTES;  // 64 KiB
+constexpr int P_EPI_WAVE = 4096;                 // epilogue staging bytes per wave (static LDS next to the ring)
+
+__device__ __forceinline__ void glds16p(const void* gptr, void* lds_ptr) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                     (__attribute__((address_space(3))) void*)lds_ptr, 16, 0, 0);
+}
+
+template <int ACT>
+__device__ __forceinline__ float actp_fwd(float h) {
+    if (ACT == RVLM_ACT_QUICK_GELU) return h * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * h));
+    return 0.5f * h * (1.0f + erff(h * 0.70710678118654752f));
+}
+template <int ACT>
+__device__ __forceinline__ float actp_bwd(float h) {
+    if (ACT == RVLM_ACT_QUICK_GELU) {
+        const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * h));
+        return s * (1.0f + 1.702f * h * (1.0f - s));
+    }
+    const float cdf = 0.5f * (1.0f + erff(h * 0.70710678118654752f));
+    const float pdf = 0.3989422804014327f * __expf(-0.5f * h * h);
+    return cdf + h * pdf;
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// Epilogue staging goes through inline-asm DS instructions: hipcc cannot prove that its own ds_write does not
+// alias the LDS-DMA destinations and would drain the operand stream (vmcnt(0)) in front of the first staging write.
+// DS operations of one wave execute in order, so a read needs no wait after the write it depends on; the values
+// read are waited for with lds_wait() before their first use.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void lds_w64(unsigned addr, u32x2 v) { asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_w128(unsigned addr, u32x4 v) { asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_r128(unsigned addr) {
+    u32x4 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "i"(OFF) : "memory");
+    return r;
+}
+__device__ __forceinline__ void lds_wait() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// 16-byte buffer store with the whole offset in the VGPR operand and soffset = 0.  With an SGPR soffset hipcc's hazard
+// recogniser assumes that a >8-byte store's data registers may be overwritten by the next VALU instruction; on gfx950
+// that corrupted the upper dwords of stores that were followed by dense VALU code (measured: EPI_BF16_ACT / _DACT).
+__device__ __forceinline__ void store16(u32x4 v, __amdgpu_buffer_rsrc_t rs, int lane_off, int scalar_off) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, lane_off + scalar_off, 0, 0);
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* ptr, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, bytes, 0x00020000);
+}
+
+template <int EPI, int ACT, int ABL>
+__global__ void __launch_bounds__(512)
+gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];            // operand ring, 2 x 64 KiB
+    __shared__ __attribute__((aligned(1024))) char epi_lds[8 * P_EPI_WAVE];  // epilogue staging, 4 KiB per wave
+    const int ntiles = tiles_m * tiles_n;
+    constexpr bool OUT_F32 = (EPI == EPI_F32_RESID || EPI == EPI_F32);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 2, wn = w & 3;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int lda = (int)p.lda, ldb = (int)p.ldb, ldo = (int)p.ldo;   // byte offsets fit 31 bits (host check)
+
+    // buffer descriptors (wave-uniform, built from kernel arguments only): every global access below is
+    // descriptor + 32-bit lane offset (VGPR, constant for the whole kernel) + 32-bit scalar offset
+    const auto a_rs = make_rsrc(p.A, (unsigned)((p.M - 1) * lda + p.K) * 2u);
+    const auto b_rs = make_rsrc(p.Bw, (unsigned)((p.N - 1) * ldb + p.K) * 2u);
+    const unsigned out_elems = (unsigned)((p.M - 1) * ldo + p.N);
+    const auto o_rs = make_rsrc(p.out, out_elems * (OUT_F32 ? 4u : 2u));
+    const auto pre_rs = make_rsrc(EPI == EPI_BF16_ACT ? (const void*)p.out_pre : (const void*)p.out, out_elems * 2u);
+    const auto h_rs = make_rsrc(EPI == EPI_BF16_DACT ? (const void*)p.h_pre : (const void*)p.out, out_elems * 2u);
+    const auto bias_rs = make_rsrc(p.bias ? (const void*)p.bias : (const void*)p.out, p.bias ? (unsigned)p.N * 4u : 0u);
+    const auto r_rs = make_rsrc(EPI == EPI_F32_RESID ? (const void*)p.residual : (const void*)p.out, out_elems * 4u);
+
+    auto tile_origin = [&](int tile, int& m0, int& n0) {
+        const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = tile & 7, loc = tile >> 3;
+        const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+        const int group_size = 8 * tiles_n;
+        const int first_m = (t / group_size) * 8;
+        const int gm = min(tiles_m - first_m, 8);
+        m0 = __builtin_amdgcn_readfirstlane((first_m + (t % group_size) % gm) * P_M);
+        n0 = __builtin_amdgcn_readfirstlane(((t % group_size) / gm) * P_N);
+    };
+
+    // ---- staging: wave w loads rows [32w, 32w+32) of both operand tiles, 8 rows x 128 B per DMA.  Row of
+    // piece j: 32w + 8j + (lane>>3); its 16-B chunk (lane&7) holds logical chunk (lane&7) ^ ((row>>1)&7),
+    // which only depends on the parity of j -> two lane offsets per operand.
+    int a_loff[2], b_loff[2];
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+        const int clog = (lane & 7) ^ (((jp * 8 + (lane >> 3)) >> 1) & 7);
+        a_loff[jp] = ((lane >> 3) * lda + clog * 8) * 2;
+        b_loff[jp] = ((lane >> 3) * ldb + clog * 8) * 2;
+        if (ABL & 32) {   // experiment: 64-byte rows (16 rows per piece), as a BK = 32 stage would request them
+            a_loff[jp] = ((jp * 16 + (lane >> 2)) * lda + (lane & 3) * 8) * 2;
+            b_loff[jp] = ((jp * 16 + (lane >> 2)) * ldb + (lane & 3) * 8) * 2;
+        }
+    }
+    const int stage_wave_off = (w * 32) * 128;
+    int a_soff, b_soff;   // scalar byte offsets of the wave's first row of the current stream tile
+    auto set_src = [&](int m0, int n0) {
+        a_soff = (m0 + w * 32) * lda * 2;
+        b_soff = (n0 + w * 32) * ldb * 2;
+    };
+    // ABL: timing experiments only (results are garbage): 1 no DMA, 2 no MFMA, 4 no fragment reads
+    auto issue = [&](int kt) {
+        if (ABL & 1) return;
+        __attribute__((address_space(3))) char* dst =
+            (__attribute__((address_space(3))) char*)lds + ((kt & 1) * P_STAGE_BYTES + stage_wave_off);
+        const int ko = kt * (P_K * 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_ptr_t)(dst + j * 1024), 16, a_loff[j & 1],
+                                                     __builtin_amdgcn_readfirstlane(a_soff + ko + j * 16 * lda), 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, (lds_ptr_t)(dst + P_OPER_BYTES + j * 1024), 16,
+                                                     b_loff[j & 1],
+                                                     __builtin_amdgcn_readfirstlane(b_soff + ko + j * 16 * ldb), 0, 0);
+        }
+    };
+
+    // ---- fragment offsets ----
+    const int swz = (l31 >> 1) & 7;
+    int koff[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) koff[kk] = ((kk * 2 + hi) ^ swz) << 4;
+    // fragment address = fa[kk] (per lane, A operand) + ring slot offset (+ ab_delta for the B operand, wave-uniform).
+    // The slot offset is made opaque to the optimiser: otherwise it precomputes all 16 (slot, kk, operand) sums into
+    // VGPRs that stay live over the whole tile loop (and spill around it).
+    unsigned fa[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+        fa[kk] = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds + (wm * 128 + l31) * 128 + koff[kk];
+    const int ab_delta = P_OPER_BYTES + (wn * 64 - wm * 128) * 128;
+    auto load_frags = [&](int kt, int kk, i32x4 (&a)[4], i32x4 (&b)[2]) {
+        if (ABL & 4) return;
+        int slot_off = (kt & 1) * P_STAGE_BYTES;
+        asm volatile("" : "+s"(slot_off));
+        const unsigned aa = fa[kk] + slot_off, bb = aa + ab_delta;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(a[0]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(a[1]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(a[2]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(a[3]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(b[0]) : "v"(bb));
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(b[1]) : "v"(bb));
+    };
+
+    f32x16 acc[4][2];
+    auto mma = [&](const i32x4 (&a)[4], const i32x4 (&b)[2]) {
+        if (ABL & 2) return;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b[j]),
+                                                                    __builtin_bit_cast(bf16x8, a[i]), acc[i][j],
+                                                                    0, 0, 0);
+    };
+    auto init_acc = [&](int mi, int ni) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.0f;
+    };
+
+    const int nk = p.K / P_K;
+    int tile = blockIdx.x;
+    int m0, n0;
+    tile_origin(tile, m0, n0);
+    set_src(m0, n0);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) { init_acc(mi, 0); init_acc(mi, 1); }
+    issue(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    issue(1);
+
+    i32x4 a0[4], b0[2], a1[4], b1[2];
+    const unsigned ebuf = (unsigned)(size_t)(__attribute__((address_space(3))) char*)epi_lds + w * P_EPI_WAVE;
+    // staging write addresses: row l31 (128-B rows); chunk index = (constant per register group) ^ (lane part)
+    const unsigned w16_pre = ebuf + l31 * 128 + ((hi ^ (l31 & 15)) << 3);   // bf16: 8-B chunk (ni*8 + 2g + hi) ^ (row & 15)
+    const unsigned w32_pre = ebuf + l31 * 128 + ((hi ^ (l31 & 7)) << 4);    // fp32: 16-B chunk (2g + hi) ^ (row & 7)
+    const int r0 = lane >> 3;                                               // flush: row r0 + 8*it, 16-B slot lane & 7
+    const unsigned r16_a = ebuf + r0 * 128 + (((lane & 7) ^ (r0 >> 1)) << 4);       // bf16, it even
+    const unsigned r16_b = ebuf + r0 * 128 + (((lane & 7) ^ (r0 >> 1) ^ 4) << 4);   // bf16, it odd ((row & 15) >> 1 flips bit 2)
+    const unsigned r32 = ebuf + r0 * 128 + (((lane & 7) ^ r0) << 4);                // fp32 ((r0 + 8*it) & 7 == r0)
+    // lane offsets of the epilogue's coalesced accesses (bytes); one instruction = 8 rows
+    const int st16_loff = ((lane >> 3) * ldo + (lane & 7) * 8) * 2;   // bf16: 128 B (64 columns) per row
+    const int st32_loff = ((lane >> 3) * ldo + (lane & 7) * 4) * 4;   // fp32: 128 B (32 columns) per row
+    const int h16_loff = ((lane >> 2) * ldo + (lane & 3) * 8) * 2;    // bf16 next to a 32-column sub-tile: 64 B per row
+
+    int tile_iter = 0;
+    auto stamp = [&](int k) {   // optional per-tile timeline (test hook rvlm_k_gemm_set_trace), wave 0 only
+        if (p.trace && w == 0 && tile_iter < 7) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (lane == 0) p.trace[((long)blockIdx.x * 8 + tile_iter) * 4 + k] = t;
+        }
+    };
+    if (p.trace && w == 0 && lane == 0) {   // clock calibration: s_memtime vs the constant 100 MHz s_memrealtime
+        p.trace[((long)blockIdx.x * 8 + 7) * 4 + 0] = __builtin_amdgcn_s_memtime();
+        p.trace[((long)blockIdx.x * 8 + 7) * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+    while (true) {
+        const int next_tile = tile + gridDim.x;
+        const bool has_next = next_tile < ntiles;
+        int nm0 = m0, nn0 = n0;
+        stamp(0);
+        load_frags(0, 0, a0, b0);
+
+        // K-steps 0 .. nk-2.  At the barrier stage kt+1 has landed for every wave and every wave is done reading
+        // stage kt, whose ring slot is refilled right away (in step nk-2: with stage 0 of the NEXT tile).
+        for (int kt = 0; kt < nk - 1; ++kt) {
+            load_frags(kt, 1, a1, b1);
+            asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_frags(kt, 2, a0, b0);
+            asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            load_frags(kt, 3, a1, b1);
+            asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ABL & 16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");      // experiment: 3 stages in flight
+            else if (ABL & 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");   // experiment: 2 stages in flight
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt == 0) stamp(1);
+            if (kt + 2 < nk) {
+                issue(kt + 2);
+            } else if (has_next) {   // the operand stream moves on to the next tile
+                tile_origin(next_tile, nm0, nn0);
+                set_src(nm0, nn0);
+                issue(0);
+            }
+            load_frags(kt + 1, 0, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // last K-step: its barrier publishes stage 0 of the next tile and frees ring slot 1 for that tile's stage 1
+        float4 bv[2][4];
+        // Side input of the epilogue (fp32 residual / bf16 h_pre), read in the SAME coalesced pattern as the output is
+        // stored (after the LDS transpose) and prefetched SIDE_DEPTH 32x32 sub-tiles ahead: sub-tile s = 2*mi + ni lives
+        // in side[s % SIDE_DEPTH].  The first ones are requested under the last MFMAs of the tile.
+        const int m_base = m0 + wm * 128, n_base = n0 + wn * 64;
+        constexpr int SIDE_DEPTH = 4;
+        u32x4 side[SIDE_DEPTH][4];
+        auto load_side = [&](int sub) {
+            const int mi = sub >> 1, ni = sub & 1;
+            if (EPI == EPI_F32_RESID) {    // 32 rows x 128 B: 4 loads of 8 rows
+                const int so = __builtin_amdgcn_readfirstlane(((m_base + mi * 32) * ldo + n_base + ni * 32) * 4);
+#pragma unroll
+                for (int it = 0; it < 4; ++it)
+                    side[sub % SIDE_DEPTH][it] = __builtin_amdgcn_raw_buffer_load_b128(r_rs, st32_loff, so + it * 32 * ldo, 0);
+            } else {                        // 32 rows x 64 B: 2 loads of 16 rows
+                const int so = __builtin_amdgcn_readfirstlane(((m_base + mi * 32) * ldo + n_base + ni * 32) * 2);
+                side[sub % SIDE_DEPTH][0] = __builtin_amdgcn_raw_buffer_load_b128(h_rs, h16_loff, so, 0);
+                side[sub % SIDE_DEPTH][1] = __builtin_amdgcn_raw_buffer_load_b128(h_rs, h16_loff, so + 32 * ldo, 0);
+            }
+        };
+        {
+            const int kt = nk - 1;
+            load_frags(kt, 1, a1, b1);
+            asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_frags(kt, 2, a0, b0);
+            asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            load_frags(kt, 3, a1, b1);
+            asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (has_next) issue(1);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    // (a null bias has a zero-length descriptor: out-of-range buffer loads return 0)
+                    bv[ni][g] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                        bias_rs, hi * 16, __builtin_amdgcn_readfirstlane((n0 + wn * 64 + ni * 32 + 8 * g) * 4), 0));
+                }
+            if (EPI == EPI_F32_RESID) load_side(0);                            // a0/b0 are dead
+            if (EPI == EPI_BF16_DACT) { load_side(0); load_side(1); load_side(2); load_side(3); }
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            // bias joins the accumulators here, so that its registers are free for the side-input prefetch
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        acc[mi][ni][g * 4 + 0] += bv[ni][g].x; acc[mi][ni][g * 4 + 1] += bv[ni][g].y;
+                        acc[mi][ni][g * 4 + 2] += bv[ni][g].z; acc[mi][ni][g * 4 + 3] += bv[ni][g].w;
+                    }
+            __builtin_amdgcn_sched_barrier(0);
+            if (EPI == EPI_F32_RESID) { load_side(1); load_side(2); load_side(3); }
+        }
+
+        stamp(2);
+        // ---- epilogue of (m0, n0); the accumulators are re-initialised for (nm0, nn0) sub-tile by sub-tile ----
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            if (!OUT_F32 && EPI != EPI_BF16_DACT) {
+                // bf16 output(s): stage 32 rows x 64 columns (128-B rows, 8-B chunk index XOR (row & 15)), then 4
+                // stores of 8 full 128-B rows each.  A lane's 16 B cover two chunks, swapped when its row is odd.
+                const int so = __builtin_amdgcn_readfirstlane(((m_base + mi * 32) * ldo + n_base) * 2);
+                auto stage_flush = [&](__amdgpu_buffer_rsrc_t rs, bool activated) {
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            float v[4] = {acc[mi][ni][g * 4 + 0], acc[mi][ni][g * 4 + 1], acc[mi][ni][g * 4 + 2],
+                                          acc[mi][ni][g * 4 + 3]};
+                            bf16x4 o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(activated ? actp_fwd<ACT>(v[e]) : v[e]);
+                            lds_w64(w16_pre ^ ((ni * 8 + 2 * g) << 3), __builtin_bit_cast(u32x2, o));
+                        }
+                    u32x4 t0 = lds_r128<0>(r16_a), t1 = lds_r128<8 * 128>(r16_b), t2 = lds_r128<16 * 128>(r16_a),
+                          t3 = lds_r128<24 * 128>(r16_b);
+                    lds_wait();
+                    if (r0 & 1) {   // a lane's 16 B cover two 8-B chunks, swapped when its row is odd
+                        t0 = __builtin_shufflevector(t0, t0, 2, 3, 0, 1); t1 = __builtin_shufflevector(t1, t1, 2, 3, 0, 1);
+                        t2 = __builtin_shufflevector(t2, t2, 2, 3, 0, 1); t3 = __builtin_shufflevector(t3, t3, 2, 3, 0, 1);
+                    }
+                    store16(t0, rs, st16_loff, so);
+                    store16(t1, rs, st16_loff, so + 16 * ldo);
+                    store16(t2, rs, st16_loff, so + 32 * ldo);
+                    store16(t3, rs, st16_loff, so + 48 * ldo);
+                };
+                stage_flush(EPI == EPI_BF16_ACT ? pre_rs : o_rs, false);
+                if (EPI == EPI_BF16_ACT) stage_flush(o_rs, true);
+                init_acc(mi, 0);
+                init_acc(mi, 1);
+            } else {
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    // fp32 staging of one 32x32 sub-tile: 128-B rows, 16-B chunk index XOR (row & 7)
+                    const int sub = mi * 2 + ni;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 v = make_float4(acc[mi][ni][g * 4 + 0], acc[mi][ni][g * 4 + 1],
+                                                     acc[mi][ni][g * 4 + 2], acc[mi][ni][g * 4 + 3]);
+                        lds_w128(w32_pre ^ (g << 5), __builtin_bit_cast(u32x4, v));
+                    }
+                    init_acc(mi, ni);
+                    if (EPI == EPI_BF16_DACT) {
+                        const int so = __builtin_amdgcn_readfirstlane(((m_base + mi * 32) * ldo + n_base + ni * 32) * 2);
+                        // lane: row half*16 + (lane>>2), 8 columns (lane&3)*8.. = 16-B chunks q, q+1 of its staged row
+                        const int drow = lane >> 2, dq = (lane & 3) * 2;
+                        const unsigned dA = ebuf + drow * 128 + ((dq ^ (drow & 7)) << 4);
+                        const unsigned dB = ebuf + drow * 128 + (((dq + 1) ^ (drow & 7)) << 4);
+                        const u32x4 fa0 = lds_r128<0>(dA), fb0 = lds_r128<0>(dB), fa1 = lds_r128<16 * 128>(dA),
+                                    fb1 = lds_r128<16 * 128>(dB);
+                        lds_wait();
+#pragma unroll
+                        for (int half = 0; half < 2; ++half) {
+                            const float4 a = __builtin_bit_cast(float4, half ? fa1 : fa0);
+                            const float4 b = __builtin_bit_cast(float4, half ? fb1 : fb0);
+                            const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                            const bf16x8 h8 = __builtin_bit_cast(bf16x8, side[sub % SIDE_DEPTH][half]);
+                            bf16x8 o;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(f[e] * actp_bwd<ACT>((float)h8[e]));
+                            store16(__builtin_bit_cast(u32x4, o), o_rs, h16_loff, so + half * 32 * ldo);
+                        }
+                    } else {
+                        const int so = __builtin_amdgcn_readfirstlane(((m_base + mi * 32) * ldo + n_base + ni * 32) * 4);
+                        u32x4 t[4] = {lds_r128<0>(r32), lds_r128<8 * 128>(r32), lds_r128<16 * 128>(r32),
+                                      lds_r128<24 * 128>(r32)};
+                        lds_wait();
+#pragma unroll
+                        for (int it = 0; it < 4; ++it) {
+                            if (EPI == EPI_F32_RESID) {
+                                const float4 x = __builtin_bit_cast(float4, t[it]);
+                                const float4 r = __builtin_bit_cast(float4, side[sub % SIDE_DEPTH][it]);
+                                t[it] = __builtin_bit_cast(u32x4, make_float4(x.x + r.x, x.y + r.y, x.z + r.z, x.w + r.w));
+                            }
+                            store16(t[it], o_rs, st32_loff, so + it * 32 * ldo);
+                        }
+                    }
+                    if ((EPI == EPI_F32_RESID || EPI == EPI_BF16_DACT) && sub + SIDE_DEPTH < 8) load_side(sub + SIDE_DEPTH);
+                }
+            }
+        }
+        stamp(3);
+        ++tile_iter;
+        if (!has_next) {
+            if (p.trace && w == 0 && lane == 0) {
+                p.trace[((long)blockIdx.x * 8 + 7) * 4 + 2] = __builtin_amdgcn_s_memtime();
+                p.trace[((long)blockIdx.x * 8 + 7) * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+            }
+            break;
+        }
+        tile = next_tile;
+        m0 = nm0;
+        n0 = nn0;
+    }
+}
+
+static int g_ablate = 0;
+void gemm_set_ablate(int v) { g_ablate = v; }
+static unsigned long long* g_trace = nullptr;   // [256 workgroups][8 tiles][4 stamps] or null
+void gemm_set_trace(unsigned long long* ptr) { g_trace = ptr; }
+
+template <int EPI, int ACT, int ABL>
+static int launch_256p_abl(const GemmBf16& p, int tiles_m, int tiles_n, hipStream_t s) {
+    static bool attr_set = false;
+    const int lds_bytes = 2 * P_STAGE_BYTES;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_nt_256p_kernel<EPI, ACT, ABL>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return fail(RVLM_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
+        attr_set = true;
+    }
+    const int grid = std::min(tiles_m * tiles_n, 256);
+    GemmBf16 q = p;
+    q.trace = g_trace;
+    hipLaunchKernelGGL((gemm_bf16_nt_256p_kernel<EPI, ACT, ABL>), dim3(grid), dim3(512), lds_bytes, s, q, tiles_m, tiles_n);
+    RVLM_CHECK_LAUNCH();
+    return RVLM_OK;
+}
+template <int EPI, int ACT>
+static int launch_256p_act(const GemmBf16& p, int tiles_m, int tiles_n, hipStream_t s) {
+    if constexpr (EPI == EPI_BF16) {   // the timing experiments exist for the plain epilogue only
+        switch (g_ablate) {
+            case 1: return launch_256p_abl<EPI, ACT, 1>(p, tiles_m, tiles_n, s);
+            case 2: return launch_256p_abl<EPI, ACT, 2>(p, tiles_m, tiles_n, s);
+            case 4: return launch_256p_abl<EPI, ACT, 4>(p, tiles_m, tiles_n, s);
+            case 5: return launch_256p_abl<EPI, ACT, 5>(p, tiles_m, tiles_n, s);
+            case 6: return launch_256p_abl<EPI, ACT, 6>(p, tiles_m, tiles_n, s);
+            case 14: return launch_256p_abl<EPI, ACT, 14>(p, tiles_m, tiles_n, s);
+            case 22: return launch_256p_abl<EPI, ACT, 22>(p, tiles_m, tiles_n, s);
+            case 38: return launch_256p_abl<EPI, ACT, 38>(p, tiles_m, tiles_n, s);
+            case 46: return launch_256p_abl<EPI, ACT, 46>(p, tiles_m, tiles_n, s);
+            case 54: return launch_256p_abl<EPI, ACT, 54>(p, tiles_m, tiles_n, s);
+            default: break;
+        }
+    }
+    return launch_256p_abl<EPI, ACT, 0>(p, tiles_m, tiles_n, s);
+}
+template <int EPI>
+static int launch_256p(const GemmBf16& p, int tiles_m, int tiles_n, hipStream_t s) {
+    if constexpr (EPI == EPI_BF16_ACT || EPI == EPI_BF16_DACT) {
+        if (p.act != RVLM_ACT_QUICK_GELU) return launch_256p_act<EPI, RVLM_ACT_GELU>(p, tiles_m, tiles_n, s);
+    }
+    return launch_256p_act<EPI, RVLM_ACT_QUICK_GELU>(p, tiles_m, tiles_n, s);
+}
+
+// rows [0, 256*floor(M/256)) of the problem; *rows_done = 0 when the shape does not qualify
+int gemm_bf16_nt_256p(const GemmBf16& p, int* rows_done, hipStream_t s) {
+    *rows_done = 0;
+    if (p.M < P_M || p.N % P_N != 0 || p.K % (2 * P_K) != 0 || p.K < 2 * P_K) return RVLM_OK;
+    // buffer descriptors address with 32-bit offsets
+    const long lim = 1L << 31;
+    if ((long)p.M * p.lda * 2 >= lim || (long)p.N * p.ldb * 2 >= lim || (long)p.M * p.ldo * 4 >= lim) return RVLM_OK;
+    GemmBf16 q = p;
+    const int tiles_m = p.M / P_M, tiles_n = p.N / P_N;
+    q.M = tiles_m * P_M;
+    if (q.epi == EPI_F32_RESID && !q.residual) q.epi = EPI_F32;
+    int rc;
+    switch (q.epi) {
+        case EPI_BF16: rc = launch_256p<EPI_BF16>(q, tiles_m, tiles_n, s); break;
+        case EPI_F32_RESID: rc = launch_256p<EPI_F32_RESID>(q, tiles_m, tiles_n, s); break;
+        case EPI_BF16_ACT: rc = launch_256p<EPI_BF16_ACT>(q, tiles_m, tiles_n, s); break;
+        case EPI_BF16_DACT: rc = launch_256p<EPI_BF16_DACT>(q, tiles_m, tiles_n, s); break;
+        case EPI_F32: rc = launch_256p<EPI_F32>(q, tiles_m, tiles_n, s); break;
+        default: return fail(RVLM_ERR_ARG, "gemm_bf16_nt_256p: unknown epilogue");
+    }
+    if (rc) return rc;
+    *rows_done = q.M;
+    return RVLM_OK;
+}
+
+}  // namespace rvlm

@@ -49,6 +49,7 @@ struct GemmBf16 {
     const bf16_t* h_pre = nullptr;      // EPI_BF16_DACT (ld = ldo)
     const float* residual = nullptr;    // EPI_F32_RESID (ld = ldo)
     int act = RVLM_ACT_QUICK_GELU;
+    unsigned long long* trace = nullptr;   // persistent kernel only: per-tile s_memtime stamps (test hook)
 };
 int gemm_bf16_nt(const GemmBf16& p, hipStream_t s);
 

@@ -13,21 +13,37 @@ shapes = [("qkv", M, 3072, 1024, 0), ("out", M, 1024, 1024, 1), ("fc1", M, 4096,
           ("fc2_dgrad", M, 4096, 1024, 3), ("fc1_dgrad", M, 1024, 4096, 0), ("cube4k", 4096, 4096, 4096, 0),
           ("cube8k", 8192, 8192, 8192, 0)]
 variants = [int(v) for v in (sys.argv[1:] or ["0", "1"])]
+if os.environ.get("GEMM_ABLATE"):
+    lib.rvlm_k_gemm_set_ablate(int(os.environ["GEMM_ABLATE"]))
 g = torch.Generator(device=dev).manual_seed(0)
 for name, m, n, k, epi in shapes:
     mp = (m + 255) // 256 * 256
-    A = torch.randn(mp, k, generator=g, device=dev).bfloat16()
-    Bw = (torch.randn(n, k, generator=g, device=dev) * k ** -0.5).bfloat16()
+    pad = int(os.environ.get("GEMM_LDPAD", "0"))     # leading-dimension padding experiment (elements)
+    A = torch.randn(mp, k + pad, generator=g, device=dev).bfloat16()
+    Bw = (torch.randn(n, k + pad, generator=g, device=dev) * k ** -0.5).bfloat16()
     bias = torch.randn(n, generator=g, device=dev)
     res = torch.randn(m, n, generator=g, device=dev) if epi == 1 else None
     hp = torch.randn(m, n, generator=g, device=dev).bfloat16() if epi == 3 else None
     out = torch.empty(m, n, dtype=torch.float32 if epi in (1, 4) else torch.bfloat16, device=dev)
     pre = torch.empty(m, n, dtype=torch.bfloat16, device=dev) if epi == 2 else None
+    if os.environ.get("GEMM_BENCH_TORCH"):      # calibration only: what the vendor library reaches on this box
+        Wt = Bw[:, :k].t()
+        for _ in range(3):
+            torch.matmul(A[:m, :k], Wt)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            torch.matmul(A[:m, :k], Wt)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+        print(f"{name:10s} M={m} N={n} K={k} torch.matmul (no epilogue): {ms*1e3:8.1f} us  {2.0*m*n*k/ms/1e9:8.1f} TFLOP/s", flush=True)
     for v in variants:
         lib.rvlm_k_gemm_set_variant(v)
 
         def run():
-            L.check(lib.rvlm_k_gemm_bf16_nt(A.data_ptr(), k, Bw.data_ptr(), k, m, n, k, mp, epi, bias.data_ptr(),
+            L.check(lib.rvlm_k_gemm_bf16_nt(A.data_ptr(), k + pad, Bw.data_ptr(), k + pad, m, n, k, mp, epi, bias.data_ptr(),
                                             out.data_ptr(), n, L.ptr(pre), L.ptr(hp), L.ptr(res), 0, L.stream_ptr()))
         for _ in range(3):
             run()

@@ -171,6 +171,45 @@ def test_layernorm_f32(M, W):
     assert rel_max(dres - 1, gx) < 1e-4
 
 
+@pytest.mark.parametrize("K", [128, 256, 1024])
+def test_gemm_bf16_many_tiles_all_epilogues(K):
+    """More 256x256 tiles than CUs (the persistent kernel walks >1 tile per workgroup) + a 128-row remainder,
+    every epilogue, residual added IN PLACE (out aliases residual, as the weight-gradient accumulation does)."""
+    lib().rvlm_k_gemm_set_variant(1)
+    try:
+        M, N = 256 * 10 + 128, 256 * 30
+        g = torch.Generator(device="cuda").manual_seed(K)
+        A = torch.randn(M, K, generator=g, device=dev()).bfloat16()
+        Bw = (torch.randn(N, K, generator=g, device=dev()) * K ** -0.5).bfloat16()
+        bias = torch.randn(N, generator=g, device=dev())
+        res = torch.randn(M, N, generator=g, device=dev())
+        hp = torch.randn(M, N, generator=g, device=dev()).bfloat16()
+        acc = (A.float() @ Bw.float().t()).double()
+        out, _ = gemm_bf16(A, Bw, epi=4, bias=bias)
+        assert rel_max(out, acc + bias.double()) < 3e-5
+        out, _ = gemm_bf16(A, Bw, epi=4)
+        assert rel_max(out, acc) < 3e-5
+        out, _ = gemm_bf16(A, Bw, epi=1, bias=bias, residual=res)
+        assert rel_max(out, acc + bias.double() + res.double()) < 3e-5
+        inplace = res.clone()
+        Ap = torch.zeros((M + 255) // 256 * 256, K, dtype=torch.bfloat16, device=dev())
+        Ap[:M] = A
+        L.check(lib().rvlm_k_gemm_bf16_nt(Ap.data_ptr(), K, Bw.data_ptr(), K, M, N, K, Ap.shape[0], 1, bias.data_ptr(),
+                                          inplace.data_ptr(), N, None, None, inplace.data_ptr(), 0, st()), "gemm")
+        torch.cuda.synchronize()
+        assert rel_max(inplace, acc + bias.double() + res.double()) < 3e-5
+        out, _ = gemm_bf16(A, Bw, epi=0, bias=bias)
+        assert rel_max(out.float(), acc + bias.double()) < 1e-2
+        for act in (0, 1):
+            out, pre = gemm_bf16(A, Bw, epi=2, bias=bias, act=act)
+            assert rel_max(pre.float(), acc + bias.double()) < 1e-2
+            assert rel_max(out.float(), act_ref(acc + bias.double(), act)) < 1.5e-2
+            out, _ = gemm_bf16(A, Bw, epi=3, h_pre=hp, act=act)
+            assert rel_max(out.float(), acc * dact_ref(hp.double(), act)) < 1.5e-2
+    finally:
+        lib().rvlm_k_gemm_set_variant(-1)
+
+
 @pytest.mark.parametrize("K", [2048, 3072, 4096])
 def test_gemm_bf16_splitk_remainder(K):
     """M = 256*q + r rows: the r remainder rows take the split-K path (K >= 2048) for every epilogue."""
