@@ -185,14 +185,14 @@ int gemm_bf16_nt_256p(const GemmBf16& p, int* rows_done, hipStream_t s);
 
 static int g_persist = -1;
 static int gemm_persist() {
-    if (g_persist < 0) { const char* e = getenv("RVLM_GEMM_PERSIST"); g_persist = e ? atoi(e) : 0; }
+    if (g_persist < 0) { const char* e = getenv("RVLM_GEMM_PERSIST"); g_persist = e ? atoi(e) : 1; }
     return g_persist;
 }
 
-// 0: 128x128 kernel only; 1: 256x256 kernel (+128x128 on the remainder rows) wherever it applies;
-// 2 (default): per-shape choice measured on MI355X (scripts/gemm_bench.py): the 256x256 4-stage kernel
-// wins when the mainloop dominates (plain bf16 epilogue or K >= 2048), the 128x128 kernel (2 workgroups
-// per CU) when a heavy epilogue (fp32 residual, activation pair, act' multiply) rides on a K=1024 mainloop.
+// 0: 128x128 kernel only; 1: 256x256 kernels (+128x128 on the remainder rows) wherever they apply;
+// 2 (default): persistent 256x256 kernel where the shape qualifies, else (or with RVLM_GEMM_PERSIST=0) the older
+// per-shape choice: one-tile-per-workgroup 256x256 kernel when the mainloop dominates (plain bf16 epilogue or
+// K >= 2048), 128x128 kernel (2 workgroups per CU) under a heavy epilogue on a K=1024 mainloop.
 static int g_gemm_variant = -1;
 void gemm_set_variant(int v) { g_gemm_variant = v; }
 static int gemm_variant() {
@@ -276,12 +276,17 @@ int gemm_bf16_nt(const GemmBf16& p, hipStream_t s) {
     }
     int done = 0;
     const int variant = gemm_variant();
-    const bool big = variant == 1 || (variant == 2 && (p.epi == EPI_BF16 || p.K >= 2048));
-    if (big) {
-        int rc = RVLM_OK;
-        if (gemm_persist()) rc = gemm_bf16_nt_256p(p, &done, s);
+    // 1 or 2 (default): the persistent 256x256 kernel wherever the shape qualifies (N % 256 == 0, K % 128 == 0); it
+    // beats both older kernels on every encoder shape (scripts/gemm_bench.py, profiles/).  RVLM_GEMM_PERSIST=0
+    // restores the per-shape choice between the one-tile-per-workgroup 256x256 kernel and the 128x128 kernel.
+    if (variant != 0 && gemm_persist()) {
+        int rc = gemm_bf16_nt_256p(p, &done, s);
         if (rc) return rc;
-        if (done == 0) rc = gemm_bf16_nt_256(p, &done, s);
+        if (done >= p.M) return RVLM_OK;
+    }
+    const bool big = variant == 1 || (variant == 2 && (p.epi == EPI_BF16 || p.K >= 2048));
+    if (done == 0 && big) {
+        int rc = gemm_bf16_nt_256(p, &done, s);
         if (rc) return rc;
         if (done >= p.M) return RVLM_OK;
     }

@@ -35,7 +35,9 @@ typedef __attribute__((ext_vector_type(4))) int i32x4;
 constexpr int P_M = 256, P_N = 256, P_K = 64;
 constexpr int P_OPER_BYTES = P_M * P_K * 2;      // 32 KiB per operand per stage
 constexpr int P_STAGE_BYTES = 2 * P_OPER_BYTES;  // 64 KiB
-constexpr int P_EPI_WAVE = 4096;                 // epilogue staging bytes per wave (static LDS next to the ring)
+constexpr int P_EPI_WAVE = 4096;                 // epilogue staging bytes per wave
+constexpr int PA_SLOT = P_OPER_BYTES, PB_SLOT = P_OPER_BYTES;   // ring slots: one operand half of one stage
+constexpr int PB_BASE = 3 * PA_SLOT;             // A ring (3 slots) | B ring (2 slots) = 160 KiB
 
 __device__ __forceinline__ void glds16p(const void* gptr, void* lds_ptr) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
@@ -93,8 +95,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* ptr, uns
 template <int EPI, int ACT, int ABL>
 __global__ void __launch_bounds__(512)
 gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];            // operand ring, 2 x 64 KiB
-    __shared__ __attribute__((aligned(1024))) char epi_lds[8 * P_EPI_WAVE];  // epilogue staging, 4 KiB per wave
+    // 160 KiB: A ring 3 x 32 KiB | B ring 2 x 32 KiB (the B slot a tile's last K-step frees doubles as the
+    // epilogue staging buffer, 4 KiB per wave)
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
     const int ntiles = tiles_m * tiles_n;
     constexpr bool OUT_F32 = (EPI == EPI_F32_RESID || EPI == EPI_F32);
 
@@ -124,61 +127,90 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n) {
         m0 = __builtin_amdgcn_readfirstlane((first_m + (t % group_size) % gm) * P_M);
         n0 = __builtin_amdgcn_readfirstlane(((t % group_size) / gm) * P_N);
     };
+    const int nk = p.K / P_K;
+    const int ntw = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // tiles of this workgroup
 
-    // ---- staging: wave w loads rows [32w, 32w+32) of both operand tiles, 8 rows x 128 B per DMA.  Row of
-    // piece j: 32w + 8j + (lane>>3); its 16-B chunk (lane&7) holds logical chunk (lane&7) ^ ((row>>1)&7),
-    // which only depends on the parity of j -> two lane offsets per operand.
+    // ---- operand streams.  Stage g (global K-step counter over all tiles of this workgroup) has its A half in A
+    // slot g % 3 and its B half in B slot g % 2; A runs three stages ahead of the MFMAs, B two.  Wave w loads rows
+    // [32w, 32w+32) of each half, 8 rows x 128 B per DMA; row of piece j: 32w + 8j + (lane>>3); its 16-B chunk
+    // (lane&7) holds logical chunk (lane&7) ^ ((row>>1)&7), which only depends on the parity of j.
     int a_loff[2], b_loff[2];
 #pragma unroll
     for (int jp = 0; jp < 2; ++jp) {
         const int clog = (lane & 7) ^ (((jp * 8 + (lane >> 3)) >> 1) & 7);
         a_loff[jp] = ((lane >> 3) * lda + clog * 8) * 2;
         b_loff[jp] = ((lane >> 3) * ldb + clog * 8) * 2;
-        if (ABL & 32) {   // experiment: 64-byte rows (16 rows per piece), as a BK = 32 stage would request them
-            a_loff[jp] = ((jp * 16 + (lane >> 2)) * lda + (lane & 3) * 8) * 2;
-            b_loff[jp] = ((jp * 16 + (lane >> 2)) * ldb + (lane & 3) * 8) * 2;
-        }
     }
     const int stage_wave_off = (w * 32) * 128;
-    int a_soff, b_soff;   // scalar byte offsets of the wave's first row of the current stream tile
-    auto set_src = [&](int m0, int n0) {
+    // cursors: next stage to request = K-step a_kt of this workgroup's tile number a_ti (likewise b_*)
+    int a_ti = 0, a_kt = 0, a_soff = 0, a_slot = 0;
+    int b_ti = 0, b_kt = 0, b_soff = 0, b_slot = 0;
+    {
+        int m0, n0;
+        tile_origin(blockIdx.x, m0, n0);
         a_soff = (m0 + w * 32) * lda * 2;
         b_soff = (n0 + w * 32) * ldb * 2;
-    };
-    // ABL: timing experiments only (results are garbage): 1 no DMA, 2 no MFMA, 4 no fragment reads
-    auto issue = [&](int kt) {
-        if (ABL & 1) return;
-        __attribute__((address_space(3))) char* dst =
-            (__attribute__((address_space(3))) char*)lds + ((kt & 1) * P_STAGE_BYTES + stage_wave_off);
-        const int ko = kt * (P_K * 2);
+    }
+    auto issue_a = [&]() -> bool {
+        if (a_ti >= ntw) return false;
+        if (!(ABL & 1)) {
+            __attribute__((address_space(3))) char* dst =
+                (__attribute__((address_space(3))) char*)lds + (a_slot * PA_SLOT + stage_wave_off);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_ptr_t)(dst + j * 1024), 16, a_loff[j & 1],
-                                                     __builtin_amdgcn_readfirstlane(a_soff + ko + j * 16 * lda), 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, (lds_ptr_t)(dst + P_OPER_BYTES + j * 1024), 16,
-                                                     b_loff[j & 1],
-                                                     __builtin_amdgcn_readfirstlane(b_soff + ko + j * 16 * ldb), 0, 0);
+            for (int j = 0; j < 4; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    a_rs, (lds_ptr_t)(dst + j * 1024), 16, a_loff[j & 1],
+                    __builtin_amdgcn_readfirstlane(a_soff + a_kt * (P_K * 2) + j * 16 * lda), 0, 0);
         }
+        a_slot = (a_slot == 2) ? 0 : a_slot + 1;
+        if (++a_kt == nk) {
+            a_kt = 0;
+            if (++a_ti < ntw) {
+                int m0, n0;
+                tile_origin(blockIdx.x + a_ti * gridDim.x, m0, n0);
+                a_soff = (m0 + w * 32) * lda * 2;
+            }
+        }
+        return true;
+    };
+    auto issue_b = [&]() -> bool {
+        if (b_ti >= ntw) return false;
+        if (!(ABL & 1)) {
+            __attribute__((address_space(3))) char* dst =
+                (__attribute__((address_space(3))) char*)lds + (PB_BASE + b_slot * PB_SLOT + stage_wave_off);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    b_rs, (lds_ptr_t)(dst + j * 1024), 16, b_loff[j & 1],
+                    __builtin_amdgcn_readfirstlane(b_soff + b_kt * (P_K * 2) + j * 16 * ldb), 0, 0);
+        }
+        b_slot ^= 1;
+        if (++b_kt == nk) {
+            b_kt = 0;
+            if (++b_ti < ntw) {
+                int m0, n0;
+                tile_origin(blockIdx.x + b_ti * gridDim.x, m0, n0);
+                b_soff = (n0 + w * 32) * ldb * 2;
+            }
+        }
+        return true;
     };
 
-    // ---- fragment offsets ----
+    // ---- fragment addresses = per-lane part (fa / fb, by k-slice) + ring slot offset.  The slot offsets are kept
+    // opaque to the optimiser: otherwise it precomputes every (slot, kk, operand) sum into VGPRs that stay live over the
+    // whole tile loop (and spill around it).
     const int swz = (l31 >> 1) & 7;
-    int koff[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) koff[kk] = ((kk * 2 + hi) ^ swz) << 4;
-    // fragment address = fa[kk] (per lane, A operand) + ring slot offset (+ ab_delta for the B operand, wave-uniform).
-    // The slot offset is made opaque to the optimiser: otherwise it precomputes all 16 (slot, kk, operand) sums into
-    // VGPRs that stay live over the whole tile loop (and spill around it).
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
     unsigned fa[4];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
-        fa[kk] = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds + (wm * 128 + l31) * 128 + koff[kk];
-    const int ab_delta = P_OPER_BYTES + (wn * 64 - wm * 128) * 128;
-    auto load_frags = [&](int kt, int kk, i32x4 (&a)[4], i32x4 (&b)[2]) {
+    for (int kk = 0; kk < 4; ++kk) fa[kk] = lds_base + (wm * 128 + l31) * 128 + (((kk * 2 + hi) ^ swz) << 4);
+    const int ab_delta = PB_BASE + (wn * 64 - wm * 128) * 128;   // B row block of this wave relative to its A rows
+    int ca_slot = 0, cb_slot = 0;                                 // slots of the stage being consumed
+    auto load_frags = [&](int sa, int sb, int kk, i32x4 (&a)[4], i32x4 (&b)[2]) {
         if (ABL & 4) return;
-        int slot_off = (kt & 1) * P_STAGE_BYTES;
-        asm volatile("" : "+s"(slot_off));
-        const unsigned aa = fa[kk] + slot_off, bb = aa + ab_delta;
+        int oa = sa * PA_SLOT, ob = sb * PB_SLOT + ab_delta;
+        asm volatile("" : "+s"(oa), "+s"(ob));
+        const unsigned aa = fa[kk] + oa, bb = fa[kk] + ob;
         asm volatile("ds_read_b128 %0, %1" : "=v"(a[0]) : "v"(aa));
         asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(a[1]) : "v"(aa));
         asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(a[2]) : "v"(aa));
@@ -202,90 +234,95 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.0f;
     };
-
-    const int nk = p.K / P_K;
-    int tile = blockIdx.x;
-    int m0, n0;
-    tile_origin(tile, m0, n0);
-    set_src(m0, n0);
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) { init_acc(mi, 0); init_acc(mi, 1); }
-    issue(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- prologue: stages 0 and 1 complete, A of stage 2 ----
+    issue_a(); issue_b();
+    issue_a(); issue_b();
+    bool a_ahead = issue_a();       // was the A half of stage g+2 requested at the previous barrier?
+    if (a_ahead) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // (a single tile with two K-steps)
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    issue(1);
 
     i32x4 a0[4], b0[2], a1[4], b1[2];
-    const unsigned ebuf = (unsigned)(size_t)(__attribute__((address_space(3))) char*)epi_lds + w * P_EPI_WAVE;
-    // staging write addresses: row l31 (128-B rows); chunk index = (constant per register group) ^ (lane part)
-    const unsigned w16_pre = ebuf + l31 * 128 + ((hi ^ (l31 & 15)) << 3);   // bf16: 8-B chunk (ni*8 + 2g + hi) ^ (row & 15)
-    const unsigned w32_pre = ebuf + l31 * 128 + ((hi ^ (l31 & 7)) << 4);    // fp32: 16-B chunk (2g + hi) ^ (row & 7)
-    const int r0 = lane >> 3;                                               // flush: row r0 + 8*it, 16-B slot lane & 7
-    const unsigned r16_a = ebuf + r0 * 128 + (((lane & 7) ^ (r0 >> 1)) << 4);       // bf16, it even
-    const unsigned r16_b = ebuf + r0 * 128 + (((lane & 7) ^ (r0 >> 1) ^ 4) << 4);   // bf16, it odd ((row & 15) >> 1 flips bit 2)
-    const unsigned r32 = ebuf + r0 * 128 + (((lane & 7) ^ r0) << 4);                // fp32 ((r0 + 8*it) & 7 == r0)
-    // lane offsets of the epilogue's coalesced accesses (bytes); one instruction = 8 rows
+    // lane offsets of the epilogue's coalesced accesses (bytes); one instruction = 8 rows (16 for the 64-B rows)
     const int st16_loff = ((lane >> 3) * ldo + (lane & 7) * 8) * 2;   // bf16: 128 B (64 columns) per row
     const int st32_loff = ((lane >> 3) * ldo + (lane & 7) * 4) * 4;   // fp32: 128 B (32 columns) per row
     const int h16_loff = ((lane >> 2) * ldo + (lane & 3) * 8) * 2;    // bf16 next to a 32-column sub-tile: 64 B per row
+    const int r0 = lane >> 3;                                         // flush: row r0 + 8*it, 16-B slot lane & 7
 
-    int tile_iter = 0;
-    auto stamp = [&](int k) {   // optional per-tile timeline (test hook rvlm_k_gemm_set_trace), wave 0 only
-        if (p.trace && w == 0 && tile_iter < 7) {
+    auto stamp = [&](int ti, int k) {   // optional per-tile timeline (test hook rvlm_k_gemm_set_trace), wave 0 only
+        if (p.trace && w == 0 && ti < 7) {
             const unsigned long long t = __builtin_amdgcn_s_memtime();
-            if (lane == 0) p.trace[((long)blockIdx.x * 8 + tile_iter) * 4 + k] = t;
+            if (lane == 0) p.trace[((long)blockIdx.x * 8 + ti) * 4 + k] = t;
         }
     };
     if (p.trace && w == 0 && lane == 0) {   // clock calibration: s_memtime vs the constant 100 MHz s_memrealtime
         p.trace[((long)blockIdx.x * 8 + 7) * 4 + 0] = __builtin_amdgcn_s_memtime();
         p.trace[((long)blockIdx.x * 8 + 7) * 4 + 1] = __builtin_amdgcn_s_memrealtime();
     }
-    while (true) {
-        const int next_tile = tile + gridDim.x;
-        const bool has_next = next_tile < ntiles;
-        int nm0 = m0, nn0 = n0;
-        stamp(0);
-        load_frags(0, 0, a0, b0);
 
-        // K-steps 0 .. nk-2.  At the barrier stage kt+1 has landed for every wave and every wave is done reading
-        // stage kt, whose ring slot is refilled right away (in step nk-2: with stage 0 of the NEXT tile).
-        for (int kt = 0; kt < nk - 1; ++kt) {
-            load_frags(kt, 1, a1, b1);
+    for (int ti = 0; ti < ntw; ++ti) {
+        int m0, n0;
+        tile_origin(blockIdx.x + ti * gridDim.x, m0, n0);
+        const bool last_tile = (ti + 1 == ntw);
+        stamp(ti, 0);
+        load_frags(ca_slot, cb_slot, 0, a0, b0);
+
+        // One K-step.  At its barrier the next stage has landed for every wave and every wave is done reading this
+        // stage, whose two slots are refilled right away: B of stage g+2, then A of stage g+3 (in that order: the
+        // next step may leave exactly the 4 youngest pieces, the A half, in flight).
+        auto k_step = [&](bool first_of_tile, bool last_of_tile) {
+            const int na_slot = (ca_slot == 2) ? 0 : ca_slot + 1, nb_slot = cb_slot ^ 1;
+            load_frags(ca_slot, cb_slot, 1, a1, b1);
             asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             mma(a0, b0);
             __builtin_amdgcn_sched_barrier(0);
-            load_frags(kt, 2, a0, b0);
+            load_frags(ca_slot, cb_slot, 2, a0, b0);
             asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             mma(a1, b1);
             __builtin_amdgcn_sched_barrier(0);
-            load_frags(kt, 3, a1, b1);
+            load_frags(ca_slot, cb_slot, 3, a1, b1);
             asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             mma(a0, b0);
             __builtin_amdgcn_sched_barrier(0);
-            if (ABL & 16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");      // experiment: 3 stages in flight
-            else if (ABL & 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");   // experiment: 2 stages in flight
+            // first step of a later tile: the B half of the next stage was requested AFTER the epilogue's stores
+            if (a_ahead && !(first_of_tile && ti > 0)) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            if (kt == 0) stamp(1);
-            if (kt + 2 < nk) {
-                issue(kt + 2);
-            } else if (has_next) {   // the operand stream moves on to the next tile
-                tile_origin(next_tile, nm0, nn0);
-                set_src(nm0, nn0);
-                issue(0);
-            }
-            load_frags(kt + 1, 0, a0, b0);
+            if (first_of_tile) stamp(ti, 1);
+            if (!last_of_tile) issue_b();     // (deferred past the epilogue in a tile's last step: staging uses that slot)
+            a_ahead = issue_a();
+            if (!last_of_tile) load_frags(na_slot, nb_slot, 0, a0, b0);
+            ca_slot = na_slot;
+            cb_slot = nb_slot;
+        };
+        k_step(true, false);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int kt = 1; kt < nk - 1; ++kt) {
+            k_step(false, false);
             __builtin_amdgcn_sched_barrier(0);
             mma(a1, b1);
             __builtin_amdgcn_sched_barrier(0);
         }
-        // last K-step: its barrier publishes stage 0 of the next tile and frees ring slot 1 for that tile's stage 1
+        const int stage_slot = cb_slot;   // B slot of the tile's last stage = epilogue staging area after its barrier
+        k_step(false, true);
+
         float4 bv[2][4];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)   // (a null bias has a zero-length descriptor: out-of-range loads return 0)
+                bv[ni][g] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                    bias_rs, hi * 16, __builtin_amdgcn_readfirstlane((n0 + wn * 64 + ni * 32 + 8 * g) * 4), 0));
         // Side input of the epilogue (fp32 residual / bf16 h_pre), read in the SAME coalesced pattern as the output is
         // stored (after the LDS transpose) and prefetched SIDE_DEPTH 32x32 sub-tiles ahead: sub-tile s = 2*mi + ni lives
         // in side[s % SIDE_DEPTH].  The first ones are requested under the last MFMAs of the tile.
@@ -305,61 +342,38 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n) {
                 side[sub % SIDE_DEPTH][1] = __builtin_amdgcn_raw_buffer_load_b128(h_rs, h16_loff, so + 32 * ldo, 0);
             }
         };
-        {
-            const int kt = nk - 1;
-            load_frags(kt, 1, a1, b1);
-            asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            mma(a0, b0);
-            __builtin_amdgcn_sched_barrier(0);
-            load_frags(kt, 2, a0, b0);
-            asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            mma(a1, b1);
-            __builtin_amdgcn_sched_barrier(0);
-            load_frags(kt, 3, a1, b1);
-            asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            mma(a0, b0);
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            if (has_next) issue(1);
+        if (EPI == EPI_F32_RESID) load_side(0);                            // a0/b0 are dead
+        if (EPI == EPI_BF16_DACT) { load_side(0); load_side(1); load_side(2); load_side(3); }
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        // bias joins the accumulators here, so that its registers are free for the side-input prefetch
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    // (a null bias has a zero-length descriptor: out-of-range buffer loads return 0)
-                    bv[ni][g] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
-                        bias_rs, hi * 16, __builtin_amdgcn_readfirstlane((n0 + wn * 64 + ni * 32 + 8 * g) * 4), 0));
+                    acc[mi][ni][g * 4 + 0] += bv[ni][g].x; acc[mi][ni][g * 4 + 1] += bv[ni][g].y;
+                    acc[mi][ni][g * 4 + 2] += bv[ni][g].z; acc[mi][ni][g * 4 + 3] += bv[ni][g].w;
                 }
-            if (EPI == EPI_F32_RESID) load_side(0);                            // a0/b0 are dead
-            if (EPI == EPI_BF16_DACT) { load_side(0); load_side(1); load_side(2); load_side(3); }
-            __builtin_amdgcn_sched_barrier(0);
-            mma(a1, b1);
-            __builtin_amdgcn_sched_barrier(0);
-            // bias joins the accumulators here, so that its registers are free for the side-input prefetch
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        acc[mi][ni][g * 4 + 0] += bv[ni][g].x; acc[mi][ni][g * 4 + 1] += bv[ni][g].y;
-                        acc[mi][ni][g * 4 + 2] += bv[ni][g].z; acc[mi][ni][g * 4 + 3] += bv[ni][g].w;
-                    }
-            __builtin_amdgcn_sched_barrier(0);
-            if (EPI == EPI_F32_RESID) { load_side(1); load_side(2); load_side(3); }
-        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (EPI == EPI_F32_RESID) { load_side(1); load_side(2); load_side(3); }
+        stamp(ti, 2);
 
-        stamp(2);
-        // ---- epilogue of (m0, n0); the accumulators are re-initialised for (nm0, nn0) sub-tile by sub-tile ----
+        // ---- epilogue of (m0, n0): staging through the freed B slot, accumulators re-zeroed sub-tile by sub-tile ----
+        const unsigned ebuf = lds_base + PB_BASE + stage_slot * PB_SLOT + w * P_EPI_WAVE;
+        // staging write addresses: row l31 (128-B rows); chunk index = (constant per register group) ^ (lane part)
+        const unsigned w16_pre = ebuf + l31 * 128 + ((hi ^ (l31 & 15)) << 3);   // bf16: 8-B chunk (ni*8 + 2g + hi) ^ (row & 15)
+        const unsigned w32_pre = ebuf + l31 * 128 + ((hi ^ (l31 & 7)) << 4);    // fp32: 16-B chunk (2g + hi) ^ (row & 7)
+        const unsigned r16_a = ebuf + r0 * 128 + (((lane & 7) ^ (r0 >> 1)) << 4);       // bf16, it even
+        const unsigned r16_b = ebuf + r0 * 128 + (((lane & 7) ^ (r0 >> 1) ^ 4) << 4);   // bf16, it odd ((row & 15) >> 1 flips bit 2)
+        const unsigned r32 = ebuf + r0 * 128 + (((lane & 7) ^ r0) << 4);                // fp32 ((r0 + 8*it) & 7 == r0)
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
             if (!OUT_F32 && EPI != EPI_BF16_DACT) {
                 // bf16 output(s): stage 32 rows x 64 columns (128-B rows, 8-B chunk index XOR (row & 15)), then 4
-                // stores of 8 full 128-B rows each.  A lane's 16 B cover two chunks, swapped when its row is odd.
+                // stores of 8 full 128-B rows each.
                 const int so = __builtin_amdgcn_readfirstlane(((m_base + mi * 32) * ldo + n_base) * 2);
                 auto stage_flush = [&](__amdgpu_buffer_rsrc_t rs, bool activated) {
 #pragma unroll
@@ -440,18 +454,18 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n) {
                 }
             }
         }
-        stamp(3);
-        ++tile_iter;
-        if (!has_next) {
-            if (p.trace && w == 0 && lane == 0) {
-                p.trace[((long)blockIdx.x * 8 + 7) * 4 + 2] = __builtin_amdgcn_s_memtime();
-                p.trace[((long)blockIdx.x * 8 + 7) * 4 + 3] = __builtin_amdgcn_s_memrealtime();
-            }
-            break;
+        stamp(ti, 3);
+        if (!last_tile) {
+            // every wave is done with the staging slot: request the B half that was held back, fetch the first fragments
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            issue_b();
         }
-        tile = next_tile;
-        m0 = nm0;
-        n0 = nn0;
+    }
+    if (p.trace && w == 0 && lane == 0) {
+        p.trace[((long)blockIdx.x * 8 + 7) * 4 + 2] = __builtin_amdgcn_s_memtime();
+        p.trace[((long)blockIdx.x * 8 + 7) * 4 + 3] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -463,7 +477,7 @@ void gemm_set_trace(unsigned long long* ptr) { g_trace = ptr; }
 template <int EPI, int ACT, int ABL>
 static int launch_256p_abl(const GemmBf16& p, int tiles_m, int tiles_n, hipStream_t s) {
     static bool attr_set = false;
-    const int lds_bytes = 2 * P_STAGE_BYTES;
+    const int lds_bytes = 3 * PA_SLOT + 2 * PB_SLOT;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_nt_256p_kernel<EPI, ACT, ABL>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -486,11 +500,6 @@ static int launch_256p_act(const GemmBf16& p, int tiles_m, int tiles_n, hipStrea
             case 4: return launch_256p_abl<EPI, ACT, 4>(p, tiles_m, tiles_n, s);
             case 5: return launch_256p_abl<EPI, ACT, 5>(p, tiles_m, tiles_n, s);
             case 6: return launch_256p_abl<EPI, ACT, 6>(p, tiles_m, tiles_n, s);
-            case 14: return launch_256p_abl<EPI, ACT, 14>(p, tiles_m, tiles_n, s);
-            case 22: return launch_256p_abl<EPI, ACT, 22>(p, tiles_m, tiles_n, s);
-            case 38: return launch_256p_abl<EPI, ACT, 38>(p, tiles_m, tiles_n, s);
-            case 46: return launch_256p_abl<EPI, ACT, 46>(p, tiles_m, tiles_n, s);
-            case 54: return launch_256p_abl<EPI, ACT, 54>(p, tiles_m, tiles_n, s);
             default: break;
         }
     }

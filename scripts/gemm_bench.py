@@ -16,6 +16,11 @@ variants = [int(v) for v in (sys.argv[1:] or ["0", "1"])]
 if os.environ.get("GEMM_ABLATE"):
     lib.rvlm_k_gemm_set_ablate(int(os.environ["GEMM_ABLATE"]))
 g = torch.Generator(device=dev).manual_seed(0)
+# the GPU leaves idle at a low clock and ramps up over many milliseconds: burn ~0.5 s before the first measurement
+_wa = torch.randn(8192, 8192, device=dev).bfloat16()
+for _ in range(400):
+    torch.matmul(_wa, _wa)
+torch.cuda.synchronize()
 for name, m, n, k, epi in shapes:
     mp = (m + 255) // 256 * 256
     pad = int(os.environ.get("GEMM_LDPAD", "0"))     # leading-dimension padding experiment (elements)
@@ -45,11 +50,11 @@ for name, m, n, k, epi in shapes:
         def run():
             L.check(lib.rvlm_k_gemm_bf16_nt(A.data_ptr(), k + pad, Bw.data_ptr(), k + pad, m, n, k, mp, epi, bias.data_ptr(),
                                             out.data_ptr(), n, L.ptr(pre), L.ptr(hp), L.ptr(res), 0, L.stream_ptr()))
-        for _ in range(3):
+        for _ in range(20):
             run()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 20
+        reps = 50
         e0.record()
         for _ in range(reps):
             run()
