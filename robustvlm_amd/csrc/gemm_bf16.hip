@@ -182,6 +182,13 @@ void gemm_set_splitk_scratch(float* ptr, size_t bytes) { g_splitk_scratch = ptr;
 
 int gemm_bf16_nt_256(const GemmBf16& p, int* rows_done, hipStream_t s);
 int gemm_bf16_nt_256p(const GemmBf16& p, int* rows_done, hipStream_t s);
+int gemm_bf16_nt_256q(const GemmBf16& p, int* rows_done, hipStream_t s);
+
+static int g_waves = -1;   // persistent kernel flavour: 8 waves x 128x64 (default) or 4 waves x 128x128
+static int gemm_waves() {
+    if (g_waves < 0) { const char* e = getenv("RVLM_GEMM_WAVES"); g_waves = e ? atoi(e) : 8; }
+    return g_waves;
+}
 
 static int g_persist = -1;
 static int gemm_persist() {
@@ -280,7 +287,7 @@ int gemm_bf16_nt(const GemmBf16& p, hipStream_t s) {
     // beats both older kernels on every encoder shape (scripts/gemm_bench.py, profiles/).  RVLM_GEMM_PERSIST=0
     // restores the per-shape choice between the one-tile-per-workgroup 256x256 kernel and the 128x128 kernel.
     if (variant != 0 && gemm_persist()) {
-        int rc = gemm_bf16_nt_256p(p, &done, s);
+        int rc = gemm_waves() == 4 ? gemm_bf16_nt_256q(p, &done, s) : gemm_bf16_nt_256p(p, &done, s);
         if (rc) return rc;
         if (done >= p.M) return RVLM_OK;
     }

@@ -1,96 +1,29 @@
-// bf16 MFMA GEMM for gfx950, PERSISTENT 256x256 variant ("256p").
+// bf16 MFMA GEMM for gfx950, PERSISTENT 256x256 variant ("256p", 8 waves x 128x64 wave tiles).
 //
-// Why: with one 256x256 workgroup per CU and one tile per workgroup, every CU of the chip runs its
-// pipeline fill and its epilogue at the same moment.  Measured on the encoder's shapes (M = 32 896,
-// K = 1024) the per-tile fixed cost was 13 us (plain bf16 store) to 33 us (fp32 residual read + write) on a
-// 28 us mainloop: the residual loads sat on a load -> wait -> store chain four times per wave, the DMA
-// prologue waited a full HBM round trip, and a new workgroup had to be dispatched per tile.
+// Why: with one 256x256 workgroup per CU and one tile per workgroup, every CU of the chip runs its pipeline fill and
+// its epilogue at the same moment.  Measured on the encoder's shapes (M = 32 896, K = 1024) the per-tile fixed cost
+// was 13 us (plain bf16 store) to 33 us (fp32 residual read + write) on a 28 us mainloop.
 //
 // Structure:
-//   * 256 workgroups (one per CU, 128 KiB of LDS each) walk the tile list; tile -> (m, n) keeps the
-//     XCD-aware grouped order of the other kernels.
-//   * mainloop = the BK = 64 schedule of gemm_bf16_256.hip ("k64": 128-B LDS rows, 2 x 64 KiB ring, one
-//     barrier per K-step, fragments double-buffered in registers).  The operand stream is CONTINUOUS
-//     across tiles: stage 0 of the next tile is issued two K-steps before the current tile ends.
-//   * the fp32 residual is not read in the epilogue: the accumulators of the NEXT tile are initialised
-//     with it (loads in the MFMA D layout, issued as soon as a 32-row group of the current tile has been
-//     staged for storing), so its latency hides under the epilogue stores and the DMA of stage 1; the
-//     bias is added to the start values at the tile seam (its registers are only live while the fragment
-//     registers are not).
-//   * every global address is an SGPR base + a 32-bit per-lane offset that is constant for the whole
-//     kernel (nothing lane-dependent is recomputed or spilled around the tile loop).
-//   * epilogue = wave-private LDS transpose (8 KiB per wave in the ring slot that the last K-step
-//     freed) -> full-line 16-B-per-lane stores, fire and forget; the only VMEM wait at the tile seam is
-//     the counted vmcnt(8) that also guards stage 0 of the next tile.
+//   * <= 256 workgroups (one per CU, 160 KiB of LDS each) walk the tile list; tile -> (m, n) keeps the XCD-aware
+//     grouped order of the other kernels.
+//   * BK = 64 (128-B LDS rows = one full L2 line per operand row per K-step; 64-B rows halve the payload per request
+//     and measured 10 TB/s against 15 TB/s of operand DMA).  LDS = A ring of 3 half-stage slots + B ring of 2: the A
+//     halves run three K-steps ahead of the MFMAs, the B halves two, continuously across tile seams.  One barrier
+//     per K-step, fragments double-buffered in registers, counted vmcnt (the 4 youngest DMA pieces stay in flight).
+//   * epilogue = wave-private LDS transpose (in the B slot the tile's last K-step freed, through inline-asm DS ops so
+//     that hipcc does not drain the operand stream) -> full-line 16-B-per-lane buffer stores; fp32 residual / h_pre
+//     are read in the same coalesced pattern, prefetched four 32x32 sub-tiles ahead; bias joins the accumulators
+//     before the staging; accumulators are re-zeroed sub-tile by sub-tile.
+//   * every global address is a buffer descriptor + a 32-bit per-lane offset that is constant for the whole kernel
+//     (nothing lane-dependent is recomputed or spilled around the tile loop).
 //
-// Requirements: M % 256 == 0 rows handled here, N % 256 == 0, K % 128 == 0 (even number of stages, so
-// every tile starts in ring slot 0).
+// Requirements: M % 256 == 0 rows handled here, N % 256 == 0, K % 128 == 0, all byte extents < 2 GiB.
 #include "kernels.h"
 #include "gemm_epilogue.h"
+#include "gemm_persist.h"
 
 namespace rvlm {
-
-typedef __attribute__((ext_vector_type(4))) int i32x4;
-
-constexpr int P_M = 256, P_N = 256, P_K = 64;
-constexpr int P_OPER_BYTES = P_M * P_K * 2;      // 32 KiB per operand per stage
-constexpr int P_STAGE_BYTES = 2 * P_OPER_BYTES;  // 64 KiB
-constexpr int P_EPI_WAVE = 4096;                 // epilogue staging bytes per wave
-constexpr int PA_SLOT = P_OPER_BYTES, PB_SLOT = P_OPER_BYTES;   // ring slots: one operand half of one stage
-constexpr int PB_BASE = 3 * PA_SLOT;             // A ring (3 slots) | B ring (2 slots) = 160 KiB
-
-__device__ __forceinline__ void glds16p(const void* gptr, void* lds_ptr) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
-                                     (__attribute__((address_space(3))) void*)lds_ptr, 16, 0, 0);
-}
-
-template <int ACT>
-__device__ __forceinline__ float actp_fwd(float h) {
-    if (ACT == RVLM_ACT_QUICK_GELU) return h * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * h));
-    return 0.5f * h * (1.0f + erff(h * 0.70710678118654752f));
-}
-template <int ACT>
-__device__ __forceinline__ float actp_bwd(float h) {
-    if (ACT == RVLM_ACT_QUICK_GELU) {
-        const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * h));
-        return s * (1.0f + 1.702f * h * (1.0f - s));
-    }
-    const float cdf = 0.5f * (1.0f + erff(h * 0.70710678118654752f));
-    const float pdf = 0.3989422804014327f * __expf(-0.5f * h * h);
-    return cdf + h * pdf;
-}
-
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-
-// Epilogue staging goes through inline-asm DS instructions: hipcc cannot prove that its own ds_write does not
-// alias the LDS-DMA destinations and would drain the operand stream (vmcnt(0)) in front of the first staging write.
-// DS operations of one wave execute in order, so a read needs no wait after the write it depends on; the values
-// read are waited for with lds_wait() before their first use.
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void lds_w64(unsigned addr, u32x2 v) { asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
-__device__ __forceinline__ void lds_w128(unsigned addr, u32x4 v) { asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
-template <int OFF>
-__device__ __forceinline__ u32x4 lds_r128(unsigned addr) {
-    u32x4 r;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "i"(OFF) : "memory");
-    return r;
-}
-__device__ __forceinline__ void lds_wait() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-// 16-byte buffer store with the whole offset in the VGPR operand and soffset = 0.  With an SGPR soffset hipcc's hazard
-// recogniser assumes that a >8-byte store's data registers may be overwritten by the next VALU instruction; on gfx950
-// that corrupted the upper dwords of stores that were followed by dense VALU code (measured: EPI_BF16_ACT / _DACT).
-__device__ __forceinline__ void store16(u32x4 v, __amdgpu_buffer_rsrc_t rs, int lane_off, int scalar_off) {
-    __builtin_amdgcn_raw_buffer_store_b128(v, rs, lane_off + scalar_off, 0, 0);
-}
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* ptr, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, bytes, 0x00020000);
-}
 
 template <int EPI, int ACT, int ABL>
 __global__ void __launch_bounds__(512)
@@ -469,10 +402,10 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n) {
     }
 }
 
-static int g_ablate = 0;
-void gemm_set_ablate(int v) { g_ablate = v; }
-static unsigned long long* g_trace = nullptr;   // [256 workgroups][8 tiles][4 stamps] or null
-void gemm_set_trace(unsigned long long* ptr) { g_trace = ptr; }
+int g_persist_ablate = 0;
+void gemm_set_ablate(int v) { g_persist_ablate = v; }
+unsigned long long* g_persist_trace = nullptr;   // [256 workgroups][8 tiles][4 stamps] or null
+void gemm_set_trace(unsigned long long* ptr) { g_persist_trace = ptr; }
 
 template <int EPI, int ACT, int ABL>
 static int launch_256p_abl(const GemmBf16& p, int tiles_m, int tiles_n, hipStream_t s) {
@@ -486,7 +419,7 @@ static int launch_256p_abl(const GemmBf16& p, int tiles_m, int tiles_n, hipStrea
     }
     const int grid = std::min(tiles_m * tiles_n, 256);
     GemmBf16 q = p;
-    q.trace = g_trace;
+    q.trace = g_persist_trace;
     hipLaunchKernelGGL((gemm_bf16_nt_256p_kernel<EPI, ACT, ABL>), dim3(grid), dim3(512), lds_bytes, s, q, tiles_m, tiles_n);
     RVLM_CHECK_LAUNCH();
     return RVLM_OK;
@@ -494,7 +427,7 @@ static int launch_256p_abl(const GemmBf16& p, int tiles_m, int tiles_n, hipStrea
 template <int EPI, int ACT>
 static int launch_256p_act(const GemmBf16& p, int tiles_m, int tiles_n, hipStream_t s) {
     if constexpr (EPI == EPI_BF16) {   // the timing experiments exist for the plain epilogue only
-        switch (g_ablate) {
+        switch (g_persist_ablate) {
             case 1: return launch_256p_abl<EPI, ACT, 1>(p, tiles_m, tiles_n, s);
             case 2: return launch_256p_abl<EPI, ACT, 2>(p, tiles_m, tiles_n, s);
             case 4: return launch_256p_abl<EPI, ACT, 4>(p, tiles_m, tiles_n, s);

@@ -1,0 +1,71 @@
+// Shared pieces of the persistent 256x256 bf16 GEMM kernels (gemm_bf16_256p.hip: 8 waves, 128x64 wave tiles;
+// gemm_bf16_256q.hip: 4 waves, 128x128 wave tiles): ring geometry, activation helpers, inline-asm LDS staging
+// accessors, buffer-descriptor helpers.
+#pragma once
+#include "kernels.h"
+
+namespace rvlm {
+
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+constexpr int P_M = 256, P_N = 256, P_K = 64;
+constexpr int P_OPER_BYTES = P_M * P_K * 2;      // 32 KiB per operand per stage
+constexpr int P_STAGE_BYTES = 2 * P_OPER_BYTES;  // 64 KiB
+constexpr int P_EPI_WAVE = 4096;                 // epilogue staging bytes per wave
+constexpr int PA_SLOT = P_OPER_BYTES, PB_SLOT = P_OPER_BYTES;   // ring slots: one operand half of one stage
+constexpr int PB_BASE = 3 * PA_SLOT;             // A ring (3 slots) | B ring (2 slots) = 160 KiB
+
+__device__ __forceinline__ void glds16p(const void* gptr, void* lds_ptr) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                     (__attribute__((address_space(3))) void*)lds_ptr, 16, 0, 0);
+}
+
+template <int ACT>
+__device__ __forceinline__ float actp_fwd(float h) {
+    if (ACT == RVLM_ACT_QUICK_GELU) return h * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * h));
+    return 0.5f * h * (1.0f + erff(h * 0.70710678118654752f));
+}
+template <int ACT>
+__device__ __forceinline__ float actp_bwd(float h) {
+    if (ACT == RVLM_ACT_QUICK_GELU) {
+        const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * h));
+        return s * (1.0f + 1.702f * h * (1.0f - s));
+    }
+    const float cdf = 0.5f * (1.0f + erff(h * 0.70710678118654752f));
+    const float pdf = 0.3989422804014327f * __expf(-0.5f * h * h);
+    return cdf + h * pdf;
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// Epilogue staging goes through inline-asm DS instructions: hipcc cannot prove that its own ds_write does not
+// alias the LDS-DMA destinations and would drain the operand stream (vmcnt(0)) in front of the first staging write.
+// DS operations of one wave execute in order, so a read needs no wait after the write it depends on; the values
+// read are waited for with lds_wait() before their first use.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void lds_w64(unsigned addr, u32x2 v) { asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_w128(unsigned addr, u32x4 v) { asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_r128(unsigned addr) {
+    u32x4 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "i"(OFF) : "memory");
+    return r;
+}
+__device__ __forceinline__ void lds_wait() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// 16-byte buffer store with the whole offset in the VGPR operand and soffset = 0.  With an SGPR soffset hipcc's hazard
+// recogniser assumes that a >8-byte store's data registers may be overwritten by the next VALU instruction; on gfx950
+// that corrupted the upper dwords of stores that were followed by dense VALU code (measured: EPI_BF16_ACT / _DACT).
+__device__ __forceinline__ void store16(u32x4 v, __amdgpu_buffer_rsrc_t rs, int lane_off, int scalar_off) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, lane_off + scalar_off, 0, 0);
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* ptr, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, bytes, 0x00020000);
+}
+
+}  // namespace rvlm

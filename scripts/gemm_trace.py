@@ -13,6 +13,11 @@ M = 128 * 257
 shapes = [("qkv", M, 3072, 1024, 0), ("out", M, 1024, 1024, 1), ("fc1", M, 4096, 1024, 2), ("fc2", M, 1024, 4096, 1),
           ("fc2_dgrad", M, 4096, 1024, 3), ("plain_f32", M, 1024, 1024, 4), ("cube8k", 8192, 8192, 8192, 0)]
 lib.rvlm_k_gemm_set_variant(1)
+if os.environ.get("GEMM_ABLATE"):
+    lib.rvlm_k_gemm_set_ablate(int(os.environ["GEMM_ABLATE"]))
+only = os.environ.get("TRACE_ONLY")
+if only:
+    shapes = [s for s in shapes if s[0] in only.split(",")]
 g = torch.Generator(device=dev).manual_seed(0)
 trace = torch.zeros(256 * 8 * 4, dtype=torch.int64, device=dev)
 for name, m, n, k, epi in shapes:
