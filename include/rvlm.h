@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RVLM_VERSION 100
+#define RVLM_VERSION 101
 
 typedef void* rvlm_stream_t; /* hipStream_t */
 typedef struct rvlm_vit rvlm_vit;
@@ -40,7 +40,8 @@ typedef enum {
 
 enum { RVLM_PREC_F32 = 0, RVLM_PREC_BF16 = 1 };       /* GEMM/attention operand precision */
 enum { RVLM_ACT_QUICK_GELU = 0, RVLM_ACT_GELU = 1 };  /* open_clip QuickGELU / exact erf GELU */
-enum { RVLM_LOSS_L2 = 0, RVLM_LOSS_CE = 1 };          /* FARE l2 / TeCoA ce (…clip.py:495-528) */
+enum { RVLM_LOSS_L2 = 0, RVLM_LOSS_CE = 1,             /* FARE l2 / TeCoA ce (…clip.py:495-528) */
+       RVLM_LOSS_DLR = 2, RVLM_LOSS_DLR_TARGETED = 3 }; /* AutoAttack DLR losses (autopgd_base.py:195-201, 613-618) */
 enum { RVLM_RED_MEAN = 0, RVLM_RED_NONE = 1 };        /* reduction='mean' | 'none' (grad of sum) */
 
 /* bits of the device-side flag word written by the attack kernels (replaces the reference's
@@ -136,11 +137,15 @@ int rvlm_adamw_step(float* params, const float* grads, float* exp_avg, float* ex
  *   L2:  ref = embedding_orig [B,D];  per_sample = sum_d (emb-ref)^2
  *   CE:  ref = text head T [D,C] (column-normalised); logits = emb @ (logit_scale*T)
  * reduction MEAN: *loss_scalar = mean_b, d_emb carries the 1/B; NONE: d_emb = grad of the sum.
- * pred_eq (optional, u8[B]) = argmax_c(logits) == targets (CE only).  scratch: CE needs
- * B*C + D*C floats (may be NULL for L2).
+ *   DLR / DLR_TARGETED (APGD-DLR, APGD-T): same logits; per_sample =
+ *        -(z_y - max_{c != y} z_c) / (z_(1) - z_(3) + 1e-12)            resp.
+ *        -(z_y - z_t) / (z_(1) - (z_(3) + z_(4)) / 2 + 1e-12),  t = y_target[b],  z_(k) = k-th largest logit
+ * reduction MEAN: *loss_scalar = mean_b, d_emb carries the 1/B; NONE: d_emb = grad of the sum.
+ * pred_eq (optional, u8[B]) = argmax_c(logits) == targets (head losses only).  scratch: the head losses need
+ * B*C + D*C floats (may be NULL for L2).  y_target: DLR_TARGETED only (else NULL).
  * ------------------------------------------------------------------------------------------- */
 int rvlm_loss_grad(int loss_kind, int reduction, const float* emb, const float* ref,
-                   const int64_t* targets, int B, int D, int C, float logit_scale,
+                   const int64_t* targets, const int64_t* y_target, int B, int D, int C, float logit_scale,
                    float* loss_per_sample, float* loss_scalar, float* d_emb, uint8_t* pred_eq,
                    float* scratch, rvlm_stream_t stream);
 /* out[b] = (argmax_j logits[b,j] == targets[b]); ties -> first index (…clip.py:490,
@@ -193,6 +198,7 @@ typedef struct {
     float logit_scale;        /* 100. */
     const float* ref;         /* L2: embedding_orig [B,D];  CE: T [D,C] */
     const int64_t* targets;   /* [B] (CE, and the argmax test of apgd); may be NULL for pgd+L2 */
+    const int64_t* y_target;  /* [B] target classes, RVLM_LOSS_DLR_TARGETED only (else NULL) */
 } rvlm_loss_spec;
 
 /* x_adv_out = pgd(...) ; delta0 may be NULL (zeros).  flags: see RVLM_FLAG_*.
@@ -228,7 +234,7 @@ int rvlm_vit_get_profile(rvlm_vit* h, rvlm_profile_entry* out, int* n);
 int rvlm_vit_reset_profile(rvlm_vit* h);
 
 const char* rvlm_last_error(void);
-int rvlm_version(void);
+int rvlm_version(void);   /* 101: rvlm_loss_spec.y_target, rvlm_loss_grad(y_target), DLR losses */
 
 #ifdef __cplusplus
 }

@@ -244,11 +244,32 @@ class APGDAttackRef:
     def __init__(self, predict, n_iter=100, norm="Linf", n_restarts=1, eps=None, seed=0, loss="ce",
                  eot_iter=1, rho=.75, topk=None, verbose=False, device=None, use_largereps=False,
                  is_tf_model=False, logger=None, alpha=None, use_rs=True):
-        assert norm == "Linf" and loss == "ce" and eot_iter == 1 and not use_largereps \
-            and not is_tf_model, "oracle restates the Linf/CE path only (SURVEY.md 8(a12))"
+        assert norm == "Linf" and loss in ("ce", "dlr", "dlr-targeted") and eot_iter == 1 and not use_largereps \
+            and not is_tf_model, "oracle restates the Linf path with the CE / DLR / targeted-DLR losses (SURVEY.md 8(a12), 8(f3))"
         assert eps is not None
         self.model, self.n_iter, self.eps, self.n_restarts = predict, n_iter, eps, n_restarts
         self.seed, self.thr_decr, self.alpha, self.use_rs = seed, rho, alpha, use_rs
+        self.loss, self.y_target = loss, None
+
+    def dlr_loss(self, x, y):
+        # autopgd_base.py:195-201
+        x_sorted, ind_sorted = x.sort(dim=1)
+        ind = (ind_sorted[:, -1] == y).float()
+        u = torch.arange(x.shape[0])
+        return -(x[u, y] - x_sorted[:, -2] * ind - x_sorted[:, -1] * (1. - ind)) / (
+            x_sorted[:, -1] - x_sorted[:, -3] + 1e-12)
+
+    def dlr_loss_targeted(self, x, y):
+        # autopgd_base.py:613-618
+        x_sorted, _ = x.sort(dim=1)
+        u = torch.arange(x.shape[0])
+        return -(x[u, y] - x[u, self.y_target]) / (x_sorted[:, -1] - .5 * (x_sorted[:, -3] + x_sorted[:, -4]) + 1e-12)
+
+    def _criterion(self):
+        # autopgd_base.py:243-254
+        if self.loss == "ce":
+            return lambda lg, yy: torch.nn.functional.cross_entropy(lg, yy, reduction="none")
+        return self.dlr_loss if self.loss == "dlr" else self.dlr_loss_targeted
 
     def _random_start(self, xn):
         # autopgd_base.py:210-214 + normalize() :180-183: x + eps * t / (max|t| + 1e-12), t~U(-1,1)
@@ -265,7 +286,7 @@ class APGDAttackRef:
             x_adv = x_init.detach().cpu().numpy().astype(F32).copy()
         x_adv = np.minimum(np.maximum(x_adv, F32(0)), F32(1))                     # :233
         x_best, x_best_adv = x_adv.copy(), x_adv.copy()
-        ce = lambda lg, yy: torch.nn.functional.cross_entropy(lg, yy, reduction="none")  # noqa
+        ce = self._criterion()
         logits, loss_indiv, grad = _fwd_bwd(self.model, ce, x_adv, y)             # :267-286
         grad_best = grad.copy()
         acc = (logits.max(1)[1] == y).numpy()

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "librvlm.so")
 RVLM_OK, RVLM_ERR_ARG, RVLM_ERR_HIP, RVLM_ERR_STATE, RVLM_ERR_UNSUPPORTED = 0, 1, 2, 3, 4
 PREC_F32, PREC_BF16 = 0, 1
 ACT_QUICK_GELU, ACT_GELU = 0, 1
-LOSS_L2, LOSS_CE = 0, 1
+LOSS_L2, LOSS_CE, LOSS_DLR, LOSS_DLR_TARGETED = 0, 1, 2, 3
 RED_MEAN, RED_NONE = 0, 1
 FLAG_INPUT_RANGE, FLAG_NAN_GRAD, FLAG_NAN_DELTA, FLAG_ADV_RANGE = 1, 2, 4, 8
 
@@ -61,7 +61,7 @@ class VitWeightsC(C.Structure):
 class LossSpecC(C.Structure):
     _fields_ = [("loss_kind", C.c_int32), ("reduction", C.c_int32), ("output_normalize", C.c_int32),
                 ("n_classes", C.c_int32), ("logit_scale", C.c_float), ("ref", C.c_void_p),
-                ("targets", C.c_void_p)]
+                ("targets", C.c_void_p), ("y_target", C.c_void_p)]
 
 
 class ProfileEntryC(C.Structure):
@@ -90,7 +90,7 @@ _SIGS = {
     "rvlm_vit_backward_params": (C.c_int, [C.c_void_p, c_f32p, C.c_int, C.POINTER(VitWeightsC), C.c_int, c_stream]),
     "rvlm_adamw_step": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_size_t, C.c_float, C.c_float, C.c_float,
                                   C.c_float, C.c_float, C.c_int, C.c_float, c_stream]),
-    "rvlm_loss_grad": (C.c_int, [C.c_int, C.c_int, c_f32p, c_f32p, C.c_void_p, C.c_int, C.c_int,
+    "rvlm_loss_grad": (C.c_int, [C.c_int, C.c_int, c_f32p, c_f32p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                  C.c_int, C.c_float, c_f32p, c_f32p, c_f32p, C.c_void_p, c_f32p,
                                  c_stream]),
     "rvlm_argmax_eq": (C.c_int, [c_f32p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, c_stream]),

@@ -1,10 +1,10 @@
-"""Drop-in ``APGDAttack`` (autoattack/autopgd_base.py:89-582) for BASELINE config 5:
-L-inf, CE loss, random start, restarts over still-correct points.
+"""Drop-in ``APGDAttack`` / ``APGDAttack_targeted`` (autoattack/autopgd_base.py:89-582, 584-707) for BASELINE
+config 5: L-inf, CE / DLR / targeted-DLR losses, random start, restarts over still-correct points.
 
 Native routes as in apgd_train.py: fused (predict is a :class:`ClassificationModel` over the
-engine -> rvlm_apgd_run with the zero-shot head on the device) or generic (any ``predict``).
-Branches the repo's configs never select (DLR / targeted / L1 / L2 / TF adapters /
-use_largereps) raise NotImplementedError.
+engine -> rvlm_apgd_run with the zero-shot head and the loss on the device) or generic (any ``predict``).
+Branches the repo's configs never select (L1 / L2 / TF adapters / use_largereps / EOT) raise NotImplementedError
+(SURVEY.md section 2, row 7).
 """
 from __future__ import annotations
 
@@ -70,10 +70,24 @@ class APGDAttack():
                                                out.data_ptr(), L.stream_ptr()))
         return out
 
+    # ---- the DLR losses for the generic (arbitrary ``predict``) route; same values as autopgd_base.py:195-201 and
+    # :613-618, written with top-k instead of a full sort
+    def dlr_loss(self, x, y):
+        top, idx = x.topk(3, dim=1)
+        zy = x.gather(1, y.view(-1, 1)).squeeze(1)
+        ind = (idx[:, 0] == y).float()
+        return -(zy - top[:, 1] * ind - top[:, 0] * (1. - ind)) / (top[:, 0] - top[:, 2] + 1e-12)
+
+    def dlr_loss_targeted(self, x, y):
+        top, _ = x.topk(4, dim=1)
+        zy = x.gather(1, y.view(-1, 1)).squeeze(1)
+        zt = x.gather(1, self.y_target.view(-1, 1)).squeeze(1)
+        return -(zy - zt) / (top[:, 0] - .5 * (top[:, 2] + top[:, 3]) + 1e-12)
+
     def attack_single_run(self, x, y, x_init=None):
         """Returns (x_best, acc, loss_best, x_best_adv) like autopgd_base.py:205-451."""
-        if self.loss != 'ce':
-            raise NotImplementedError(f"native APGDAttack covers loss='ce' (got {self.loss})")
+        if self.loss not in ('ce', 'dlr', 'dlr-targeted'):
+            raise ValueError('unknowkn loss')                                 # autopgd_base.py:253-254
         x = _f32c(x)
         start = self._random_start(x) if self.use_rs else None
         if x_init is not None:
@@ -83,11 +97,15 @@ class APGDAttack():
         m = self.model
         if isinstance(m, ClassificationModel) and x.shape[0] > 1 and m.logit_scale and m._identity_resizer:
             x_best_adv, x_best, loss_best, acc = m.model.apgd_run(
-                x, start, "ce", m.text_embedding, y, True, self.eps, self.n_iter, step0,
-                train_variant=False, logits_from_head=True, logit_scale=m.logit_scale_value, want_extra=True)
+                x, start, self.loss, m.text_embedding, y, True, self.eps, self.n_iter, step0,
+                train_variant=False, logits_from_head=True, logit_scale=m.logit_scale_value, want_extra=True,
+                y_target=self.y_target if self.loss == 'dlr-targeted' else None)
             return x_best, acc.bool(), loss_best, x_best_adv
-        ce = lambda lg, yy: torch.nn.functional.cross_entropy(lg, yy, reduction='none')   # noqa: E731
-        return _apgd_linf_generic(self.model, ce, x, y, self.eps, self.n_iter, step0, False, x_init=start)
+        if self.loss == 'ce':
+            crit = lambda lg, yy: torch.nn.functional.cross_entropy(lg, yy, reduction='none')   # noqa: E731
+        else:
+            crit = self.dlr_loss if self.loss == 'dlr' else self.dlr_loss_targeted
+        return _apgd_linf_generic(self.model, crit, x, y, self.eps, self.n_iter, step0, False, x_init=start)
 
     def perturb(self, x, y=None, best_loss=False, x_init=None):
         """:param best_loss: if True the points attaining highest loss are returned, otherwise
@@ -135,3 +153,57 @@ class APGDAttack():
             if self.verbose:
                 print('restart {} - loss: {:.5f}'.format(counter, loss_best.sum()))
         return adv_best
+
+
+class APGDAttack_targeted(APGDAttack):
+    """AutoPGD on the targeted DLR loss (autopgd_base.py:584-707): for each of the ``n_target_classes`` most likely
+    wrong classes, one run over the points that are still classified correctly."""
+
+    def __init__(self, predict, n_iter=100, norm='Linf', n_restarts=1, eps=None, seed=0, eot_iter=1, rho=.75,
+                 topk=None, n_target_classes=9, verbose=False, device=None, use_largereps=False, is_tf_model=False,
+                 logger=None, alpha=None, use_rs=True):
+        super().__init__(predict, n_iter=n_iter, norm=norm, n_restarts=n_restarts, eps=eps, seed=seed,
+                         loss='dlr-targeted', eot_iter=eot_iter, rho=rho, topk=topk, verbose=verbose, device=device,
+                         use_largereps=use_largereps, is_tf_model=is_tf_model, logger=logger, alpha=alpha, use_rs=use_rs)
+        self.y_target = None
+        self.n_target_classes = n_target_classes
+
+    def perturb(self, x, y=None, x_init=None):
+        """:param x: clean images  :param y: clean labels, if None we use the predicted labels"""
+        assert self.loss in ['dlr-targeted']
+        _require_cuda(x, "x")
+        if y is not None and len(y.shape) == 0:
+            x.unsqueeze_(0)
+            y.unsqueeze_(0)
+        self.init_hyperparam(x)
+        x = x.detach().clone().float().to(self.device)
+        with torch.no_grad():
+            y_pred = self.model(x).max(1)[1]
+        y = y_pred.detach().clone().long().to(self.device) if y is None \
+            else y.detach().clone().long().to(self.device)
+        adv = x.clone()
+        acc = y_pred == y
+        if self.verbose:
+            print('-------------------------- ', 'running {}-attack with epsilon {:.5f}'.format(
+                self.norm, self.eps), '--------------------------')
+            print('initial accuracy: {:.2%}'.format(acc.float().mean()))
+        startt = time.time()
+        torch.random.manual_seed(self.seed)
+        torch.cuda.random.manual_seed(self.seed)
+        for target_class in range(2, self.n_target_classes + 2):
+            for counter in range(self.n_restarts):
+                ind_to_fool = acc.nonzero().squeeze(1)
+                if ind_to_fool.numel() != 0:
+                    x_to_fool, y_to_fool = x[ind_to_fool].clone(), y[ind_to_fool].clone()
+                    with torch.no_grad():
+                        output = self.model(x_to_fool)
+                    self.y_target = output.sort(dim=1)[1][:, -target_class]
+                    _, acc_curr, _, adv_curr = self.attack_single_run(x_to_fool, y_to_fool)
+                    ind_curr = (acc_curr == 0).nonzero().squeeze(1)
+                    acc[ind_to_fool[ind_curr]] = 0
+                    adv[ind_to_fool[ind_curr]] = adv_curr[ind_curr].clone()
+                    if self.verbose:
+                        print('target class {}'.format(target_class),
+                              '- restart {} - robust accuracy: {:.2%}'.format(counter, acc.float().mean()),
+                              '- cum. time: {:.1f} s'.format(time.time() - startt))
+        return adv

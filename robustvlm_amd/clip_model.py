@@ -81,7 +81,7 @@ class _LossFn(torch.autograd.Function):
         scratch = torch.empty(B * Ccls + D * Ccls, dtype=torch.float32, device=e.device) if Ccls else None
         tg = targets.detach().to(torch.int64).contiguous() if kind == L.LOSS_CE else None
         with torch.cuda.device(e.device):
-            L.check(lib.rvlm_loss_grad(kind, reduction, e.data_ptr(), r.data_ptr(), L.ptr(tg), B, D, Ccls,
+            L.check(lib.rvlm_loss_grad(kind, reduction, e.data_ptr(), r.data_ptr(), L.ptr(tg), None, B, D, Ccls,
                                        float(logit_scale), per.data_ptr(), scalar.data_ptr(),
                                        d_emb.data_ptr(), None, L.ptr(scratch), L.stream_ptr()),
                     "rvlm_loss_grad")

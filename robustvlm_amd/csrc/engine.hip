@@ -822,12 +822,12 @@ extern "C" int rvlm_vit_backward_params(rvlm_vit* h, const float* d_emb, int B, 
 
 static int loss_step(rvlm_vit* h, const rvlm_loss_spec* ls, int B, int reduction, float* loss_scalar,
                      uint8_t* pred_eq, hipStream_t s) {
-    if (ls->loss_kind == RVLM_LOSS_CE) {
+    if (ls->loss_kind != RVLM_LOSS_L2) {
         RVLM_REQUIRE(ls->n_classes > 0 && ls->n_classes <= 1024, "loss: n_classes must be in 1..1024");
-        RVLM_REQUIRE(ls->targets, "loss: ce needs targets");
+        RVLM_REQUIRE(ls->targets, "loss: head losses need targets");
     }
     PROF("loss", 0, 0);
-    return rvlm_loss_grad(ls->loss_kind, reduction, h->emb, ls->ref, ls->targets, B, h->D, ls->n_classes,
+    return rvlm_loss_grad(ls->loss_kind, reduction, h->emb, ls->ref, ls->targets, ls->y_target, B, h->D, ls->n_classes,
                           ls->logit_scale, h->loss_ps, loss_scalar, h->d_emb, pred_eq, h->loss_scratch, s);
 }
 
@@ -872,7 +872,9 @@ extern "C" int rvlm_apgd_run(rvlm_vit* h, const float* x, const float* x_init, i
     RVLM_REQUIRE(x_best_adv, "rvlm_apgd_run: x_best_adv output required");
     RVLM_REQUIRE(B > 1 && B <= h->maxB, "rvlm_apgd_run: need 1 < B <= max_batch");
     RVLM_REQUIRE(n_iter >= 1 && n_iter <= 1024, "rvlm_apgd_run: n_iter must be in 1..1024");
-    RVLM_REQUIRE(!logits_from_head || loss->loss_kind == RVLM_LOSS_CE, "rvlm_apgd_run: head logits need the ce loss");
+    RVLM_REQUIRE(!logits_from_head || loss->loss_kind != RVLM_LOSS_L2, "rvlm_apgd_run: head logits need a head loss (ce / dlr)");
+    RVLM_REQUIRE(loss->loss_kind == RVLM_LOSS_L2 || loss->loss_kind == RVLM_LOSS_CE || logits_from_head,
+                 "rvlm_apgd_run: the DLR losses run on the classification head (logits_from_head = 1)");
     hipStream_t s = (hipStream_t)stream;
     const size_t npix = (size_t)3 * h->img * h->img, n = npix * B;
     float *x_adv = h->img_buf[0], *x_adv_old = h->img_buf[1], *x_best = h->img_buf[2], *grad = h->img_buf[3],

@@ -58,6 +58,86 @@ ce_loss_kernel(float* __restrict__ logits, const int64_t* __restrict__ targets, 
     }
 }
 
+// DLR losses of AutoAttack on a logits row (autopgd_base.py:195-201 untargeted, :613-618 targeted), one wave per row:
+// top-4 selection (4 rounds of wave arg-max over per-lane candidates), the loss with the reference's operation order,
+// and d loss / d logits written in place (autograd of the same expression: the sort routes gradient to the elements
+// holding ranks 1, 3 (and 4 / 2)).  pred_eq = (arg-max == y).
+__global__ void __launch_bounds__(256)
+dlr_loss_kernel(float* __restrict__ logits, const int64_t* __restrict__ targets, const int64_t* __restrict__ y_target,
+                int B, int C, float gscale, float* __restrict__ per_sample, uint8_t* __restrict__ pred_eq,
+                int write_grad) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B) return;
+    float* l = logits + (long)row * C;
+    const int y = (int)targets[row];
+    const int yt = y_target ? (int)y_target[row] : -1;
+    // per-lane top-4 of the elements lane, lane+64, ... (descending; ties keep the smaller index first)
+    float v[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int ix[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+    for (int c = lane; c < C; c += 64) {
+        float x = l[c];
+        int xi = c;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (x > v[k]) {
+                const float tv = v[k]; const int ti = ix[k];
+                v[k] = x; ix[k] = xi; x = tv; xi = ti;
+            }
+        }
+    }
+    float z[4];
+    int zi[4];
+    int head = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float m = -INFINITY;
+        int mi = 0x7fffffff;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (head == k) { m = v[k]; mi = ix[k]; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float om = __shfl_xor(m, o, 64);
+            const int oi = __shfl_xor(mi, o, 64);
+            if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+        }
+        z[r] = m; zi[r] = mi;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (head == k && ix[k] == mi) { head = k + 1; break; }
+    }
+    const float zy = l[y];
+    float num, den, g_y, g_1, g_2 = 0.0f, g_3, g_4 = 0.0f, g_t = 0.0f;
+    if (yt < 0) {
+        const float ind = (zi[0] == y) ? 1.0f : 0.0f;
+        num = -((zy - z[1] * ind) - z[0] * (1.0f - ind));
+        den = (z[0] - z[2]) + 1e-12f;
+        const float gn = 1.0f / den, gd = -num / (den * den);
+        g_y = -gn; g_2 = ind * gn; g_1 = (1.0f - ind) * gn + gd; g_3 = -gd;
+    } else {
+        num = -(zy - l[yt]);
+        den = (z[0] - 0.5f * (z[2] + z[3])) + 1e-12f;
+        const float gn = 1.0f / den, gd = -num / (den * den);
+        g_y = -gn; g_t = gn; g_1 = gd; g_3 = -0.5f * gd; g_4 = -0.5f * gd;
+    }
+    if (lane == 0) {
+        if (per_sample) per_sample[row] = num / den;
+        if (pred_eq) pred_eq[row] = (zi[0] == y) ? 1 : 0;
+    }
+    if (write_grad) {
+        for (int c = lane; c < C; c += 64) {
+            float g = 0.0f;
+            if (c == y) g += g_y;
+            if (c == yt) g += g_t;
+            if (c == zi[0]) g += g_1;
+            if (c == zi[1]) g += g_2;
+            if (c == zi[2]) g += g_3;
+            if (c == zi[3]) g += g_4;
+            l[c] = g * gscale;
+        }
+    }
+}
+
 // deterministic single-block reduction of the per-sample losses -> scalar
 __global__ void __launch_bounds__(256)
 reduce_loss_kernel(const float* __restrict__ per_sample, int B, float scale, float* __restrict__ out) {
@@ -96,7 +176,7 @@ argmax_eq_kernel(const float* __restrict__ logits, const int64_t* __restrict__ t
 using namespace rvlm;
 
 extern "C" int rvlm_loss_grad(int loss_kind, int reduction, const float* emb, const float* ref,
-                              const int64_t* targets, int B, int D, int C, float logit_scale,
+                              const int64_t* targets, const int64_t* y_target, int B, int D, int C, float logit_scale,
                               float* loss_per_sample, float* loss_scalar, float* d_emb,
                               uint8_t* pred_eq, float* scratch, rvlm_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
@@ -111,8 +191,12 @@ extern "C" int rvlm_loss_grad(int loss_kind, int reduction, const float* emb, co
         hipLaunchKernelGGL(l2_loss_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, emb, ref, B, D, gscale,
                            loss_per_sample, d_emb);
         RVLM_CHECK_LAUNCH();
-    } else if (loss_kind == RVLM_LOSS_CE) {
-        RVLM_REQUIRE(targets && scratch && C > 0, "rvlm_loss_grad: ce needs targets, scratch, C");
+    } else if (loss_kind == RVLM_LOSS_CE || loss_kind == RVLM_LOSS_DLR || loss_kind == RVLM_LOSS_DLR_TARGETED) {
+        RVLM_REQUIRE(targets && scratch && C > 0, "rvlm_loss_grad: head losses need targets, scratch, C");
+        RVLM_REQUIRE(loss_kind != RVLM_LOSS_DLR_TARGETED || y_target, "rvlm_loss_grad: dlr-targeted needs y_target");
+        // checks.check_n_classes: the DLR loss needs 3 logits, its targeted form 4
+        RVLM_REQUIRE(loss_kind == RVLM_LOSS_CE || C >= (loss_kind == RVLM_LOSS_DLR ? 3 : 4),
+                     "rvlm_loss_grad: too few classes for the DLR loss");
         RVLM_REQUIRE(loss_per_sample || !loss_scalar, "rvlm_loss_grad: loss_scalar needs loss_per_sample");
         float* logits = scratch;                 // [B, C]
         float* Ts = scratch + (size_t)B * C;     // [D, C] = logit_scale * T   (…clip.py:501)
@@ -125,8 +209,13 @@ extern "C" int rvlm_loss_grad(int loss_kind, int reduction, const float* emb, co
         g.M = B; g.N = C; g.K = D;
         rc = gemm_f32(g, s);
         if (rc) return rc;
-        hipLaunchKernelGGL(ce_loss_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, logits, targets, B, C,
-                           gscale, loss_per_sample, pred_eq, d_emb ? 1 : 0);
+        if (loss_kind == RVLM_LOSS_CE)
+            hipLaunchKernelGGL(ce_loss_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, logits, targets, B, C,
+                               gscale, loss_per_sample, pred_eq, d_emb ? 1 : 0);
+        else
+            hipLaunchKernelGGL(dlr_loss_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, logits, targets,
+                               loss_kind == RVLM_LOSS_DLR_TARGETED ? y_target : (const int64_t*)nullptr, B, C, gscale,
+                               loss_per_sample, pred_eq, d_emb ? 1 : 0);
         RVLM_CHECK_LAUNCH();
         if (d_emb) {
             GemmF32 h;

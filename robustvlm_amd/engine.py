@@ -142,15 +142,16 @@ class VitEngine:
         return g
 
     # ---- fused loops -----------------------------------------------------------------------------
-    def _loss_spec(self, loss_kind, reduction, output_normalize, ref, targets, logit_scale):
+    def _loss_spec(self, loss_kind, reduction, output_normalize, ref, targets, logit_scale, y_target=None):
         ls = L.LossSpecC()
-        ls.loss_kind = {"l2": L.LOSS_L2, "ce": L.LOSS_CE}[loss_kind]
+        ls.loss_kind = {"l2": L.LOSS_L2, "ce": L.LOSS_CE, "dlr": L.LOSS_DLR, "dlr-targeted": L.LOSS_DLR_TARGETED}[loss_kind]
         ls.reduction = {"mean": L.RED_MEAN, "none": L.RED_NONE}[reduction]
         ls.output_normalize = int(bool(output_normalize))
         ls.logit_scale = float(logit_scale)
         ls.ref = ref.data_ptr()
-        ls.n_classes = int(ref.shape[1]) if loss_kind == "ce" else 0
+        ls.n_classes = int(ref.shape[1]) if loss_kind != "l2" else 0
         ls.targets = targets.data_ptr() if targets is not None else None
+        ls.y_target = y_target.data_ptr() if y_target is not None else None
         return ls
 
     def pgd_run(self, x, delta0, loss_kind, reduction, ref, targets, output_normalize, eps, iterations,
@@ -174,14 +175,18 @@ class VitEngine:
         return out, flags, trace
 
     def apgd_run(self, x, x_init, loss_kind, ref, targets, output_normalize, eps, n_iter, step0,
-                 train_variant, logits_from_head, logit_scale=100.0, want_extra=False):
-        """Whole APGD Linf loop on the device (rvlm_apgd_run)."""
+                 train_variant, logits_from_head, logit_scale=100.0, want_extra=False, y_target=None):
+        """Whole APGD Linf loop on the device (rvlm_apgd_run).  loss_kind: 'l2' | 'ce' | 'dlr' | 'dlr-targeted'
+        (the DLR losses of AutoAttack need logits_from_head; 'dlr-targeted' needs y_target [B] int64)."""
         self._check_images(x)
         x = _f32c(x)
         xi = _f32c(x_init) if x_init is not None else None
         ref = _f32c(ref)
         tg = targets.detach().to(torch.int64).contiguous()
-        ls = self._loss_spec(loss_kind, "none", output_normalize, ref, tg, logit_scale)
+        yt = y_target.detach().to(torch.int64).contiguous() if y_target is not None else None
+        if (loss_kind == "dlr-targeted") != (yt is not None):
+            raise ValueError("y_target goes with loss_kind='dlr-targeted'")
+        ls = self._loss_spec(loss_kind, "none", output_normalize, ref, tg, logit_scale, yt)
         B = x.shape[0]
         x_best_adv = torch.empty_like(x)
         x_best = torch.empty_like(x) if want_extra else None

@@ -7,7 +7,8 @@ Needs /root/reference (read-only) and therefore never runs on the GPU box; only 
 
 What is executed from the reference (nothing is copied into this repo):
   * train.pgd_train.pgd, train.apgd_train.apgd_train, vlm_eval.attacks.utils.*,
-    autoattack.autopgd_base.APGDAttack         - imported from /root/reference
+    autoattack.autopgd_base.APGDAttack / APGDAttack_targeted, autoattack.AutoAttack
+                                                - imported from /root/reference
   * l2 / ce / compute_loss / ComputeLossWrapper / compute_acc of
     train/adversarial_training_clip.py          - that module needs torchvision/open_clip/wandb to
     import, so the function/class definitions are pulled out of the file with ``ast`` at run time
@@ -325,9 +326,84 @@ def g6_losses():
     save("losses.npz", **arrs)
 
 
+# ------------------------------------------------------------------ G7: AutoAttack orchestration (section 8(f) rank 3)
+def g7_autoattack():
+    """DLR losses on random logits (values + autograd gradients), APGDAttack_targeted.perturb and
+    AutoAttack(version='custom', ['apgd-ce', 'apgd-t']).run_standard_evaluation on the tiny ViT + 10-class head."""
+    from autoattack.autopgd_base import APGDAttack_targeted as RefTargeted
+    from autoattack import AutoAttack as RefAutoAttack
+    g = torch.Generator().manual_seed(77)
+    # (a) loss functions
+    B, C = 9, 12
+    logits = torch.randn(B, C, generator=g) * 3
+    y = torch.randint(0, C, (B,), generator=g)
+    y[:3] = logits[:3].argmax(1)                       # some rows correctly classified (ind = 1 branch)
+    yt = torch.randint(0, C, (B,), generator=g)
+    yt = torch.where(yt == y, (yt + 1) % C, yt)
+    obj = RefTargeted(lambda v: v, eps=0.1, n_iter=5, device="cpu")
+    res = {}
+    lg = logits.clone().requires_grad_(True)
+    l_u = obj.dlr_loss(lg, y)
+    g_u, = torch.autograd.grad(l_u.sum(), lg)
+    lg = logits.clone().requires_grad_(True)
+    obj.y_target = yt
+    l_t = obj.dlr_loss_targeted(lg, y)
+    g_t, = torch.autograd.grad(l_t.sum(), lg)
+    save("dlr_losses.npz", logits=logits.numpy(), y=y.numpy(), y_target=yt.numpy(), dlr=l_u.detach().numpy(),
+         dlr_grad=g_u.numpy(), dlr_targeted=l_t.detach().numpy(), dlr_targeted_grad=g_t.numpy())
+
+    # (b), (c) attacks on the tiny ViT + head.  Seed / eps chosen so that both stages matter: at eps = 5/255 apgd-ce
+    # leaves one sample robust and apgd-t then fools it; at eps = 3/255 three samples survive every attack.
+    cfg = vit_ref.VIT_TINY
+    w = init_weights(cfg, seed=3)
+    g = torch.Generator().manual_seed(80)
+    Bx = 7
+    x = torch.rand(Bx, 3, cfg.image_size, cfg.image_size, generator=g)
+    T = torch.randn(cfg.out_dim, 10, generator=g)
+    T = T / T.norm(dim=0, keepdim=True)
+    clf = vit_ref.ClassificationModelRef(cfg, w, T, 100.0).eval()
+    with torch.no_grad():
+        yy = clf(x).max(1)[1]
+    calls = []
+
+    def predict(v):
+        calls.append(tuple(v.shape))
+        return clf(v)
+
+    out = dict(x=x.numpy(), y=yy.numpy(), T=T.numpy(), n_iter=np.int64(6), n_target_classes=np.int64(3), bs=np.int64(4),
+               weights_seed=np.int64(3), weights_sha256=np.array(weights_digest(w)))
+    for tag, eps in (("e3", 3 / 255), ("e5", 5 / 255)):
+        calls.clear()
+        atk = RefTargeted(predict, n_iter=6, norm="Linf", n_restarts=1, eps=eps, seed=0, n_target_classes=3,
+                          device="cpu", alpha=2.0, use_rs=True)
+        adv_t = atk.perturb(x.clone(), yy.clone())
+        out[f"{tag}_adv_targeted"] = adv_t.detach().numpy()
+        out[f"{tag}_n_model_calls_targeted"] = np.int64(len(calls))
+        calls.clear()
+        aa = RefAutoAttack(predict, norm="Linf", eps=eps, seed=0, verbose=False, version="custom",
+                           attacks_to_run=["apgd-ce", "apgd-t"], device="cpu", alpha=2.0, iterations_apgd=6, use_rs=True)
+        aa.apgd.n_restarts = 1
+        aa.apgd_targeted.n_target_classes = 3
+        x_adv, y_adv = aa.run_standard_evaluation(x.clone(), yy.clone(), bs=4, return_labels=True)
+        with torch.no_grad():
+            final_pred = clf(x_adv).max(1)[1]
+        out[f"{tag}_eps"] = np.float64(eps)
+        out[f"{tag}_x_adv"] = x_adv.detach().numpy()
+        out[f"{tag}_y_adv"] = y_adv.numpy()
+        out[f"{tag}_robust"] = (final_pred == yy).numpy()
+        out[f"{tag}_n_model_calls_aa"] = np.int64(len(calls))
+        # apgd-ce alone (what the first stage leaves robust)
+        aa1 = RefAutoAttack(clf, norm="Linf", eps=eps, seed=0, verbose=False, version="custom",
+                            attacks_to_run=["apgd-ce"], device="cpu", alpha=2.0, iterations_apgd=6, use_rs=True)
+        aa1.apgd.n_restarts = 1
+        xa1 = aa1.run_standard_evaluation(x.clone(), yy.clone(), bs=4)
+        with torch.no_grad():
+            out[f"{tag}_robust_after_ce"] = (clf(xa1).max(1)[1] == yy).numpy()
+    save("autoattack_tiny.npz", **out)
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
     fns = dict(g1=g1_pgd_elementwise, g2=g2_apgd_controller, g3=g3_tiny_vit_attacks,
-               g4=g4_autopgd, g5=g5_vit_vs_hf, g6=g6_losses)
+               g4=g4_autopgd, g5=g5_vit_vs_hf, g6=g6_losses, g7=g7_autoattack)
     for k in which:
         fns[k]()

@@ -173,6 +173,71 @@ def test_apgdattack_fused_vs_oracle():
     eng.close()
 
 
+def test_dlr_loss_kernels_vs_reference_golden():
+    """rvlm_loss_grad(DLR / DLR_TARGETED) against the reference's own dlr_loss / dlr_loss_targeted outputs and
+    autograd gradients: an identity head (T = I, logit_scale 1) makes logits = emb and d_emb = d logits exactly."""
+    z = load_golden("dlr_losses.npz")
+    lib = L.load()
+    logits = torch.from_numpy(z["logits"]).to(dev())
+    B, C = logits.shape
+    y = torch.from_numpy(z["y"]).to(dev())
+    yt = torch.from_numpy(z["y_target"]).to(dev())
+    eye = torch.eye(C, device=dev())
+    for name, kind, tgt in (("dlr", L.LOSS_DLR, None), ("dlr_targeted", L.LOSS_DLR_TARGETED, yt)):
+        per = torch.empty(B, device=dev())
+        d_emb = torch.empty(B, C, device=dev())
+        pred = torch.empty(B, dtype=torch.uint8, device=dev())
+        scratch = torch.empty(B * C + C * C, device=dev())
+        L.check(lib.rvlm_loss_grad(kind, L.RED_NONE, logits.data_ptr(), eye.data_ptr(), y.data_ptr(), L.ptr(tgt), B, C, C,
+                                   1.0, per.data_ptr(), None, d_emb.data_ptr(), pred.data_ptr(), scratch.data_ptr(),
+                                   L.stream_ptr()))
+        torch.cuda.synchronize()
+        assert np.array_equal(per.cpu().numpy(), z[name]), "loss value must be bit-equal (same operation order)"
+        np.testing.assert_allclose(d_emb.cpu().numpy(), z[name + "_grad"], rtol=1e-6, atol=1e-7)
+        assert np.array_equal(pred.cpu().numpy().astype(bool), z["logits"].argmax(1) == z["y"])
+    with pytest.raises(ValueError):      # targeted form without targets
+        L.check(lib.rvlm_loss_grad(L.LOSS_DLR_TARGETED, L.RED_NONE, logits.data_ptr(), eye.data_ptr(), y.data_ptr(), None,
+                                   B, C, C, 1.0, per.data_ptr(), None, d_emb.data_ptr(), None, scratch.data_ptr(),
+                                   L.stream_ptr()))
+
+
+@pytest.mark.parametrize("tag", ["e3", "e5"])
+def test_autoattack_fused_vs_reference_golden(tag):
+    """APGDAttack_targeted.perturb and AutoAttack(version='custom', ['apgd-ce', 'apgd-t']).run_standard_evaluation on the
+    fp32 engine + zero-shot head against what the reference produced on the same seeded model (tests/golden/
+    autoattack_tiny.npz): same robust flags and labels, (almost) the same adversarial pixels."""
+    z = load_golden("autoattack_tiny.npz")
+    cfg = V.VIT_TINY
+    w = V.init_weights(cfg, seed=int(z["weights_seed"]))
+    eng = make_engine(cfg, w, "fp32")
+    clf = R.ClassificationModel(eng, torch.from_numpy(z["T"]).to(dev())).eval()
+    x, y = torch.from_numpy(z["x"]).to(dev()), torch.from_numpy(z["y"]).to(dev())
+    eps, n_iter, ntc = float(z[tag + "_eps"]), int(z["n_iter"]), int(z["n_target_classes"])
+    atk = R.APGDAttack_targeted(clf, n_iter=n_iter, norm="Linf", n_restarts=1, eps=eps, seed=0, n_target_classes=ntc,
+                                alpha=2.0, use_rs=True)
+    adv_t = atk.perturb(x.clone(), y.clone()).cpu().numpy()
+    ref_t = z[tag + "_adv_targeted"]
+    changed_ref = (ref_t != z["x"]).reshape(7, -1).any(1)
+    assert np.array_equal((adv_t != z["x"]).reshape(7, -1).any(1), changed_ref)
+    assert np.abs(adv_t - z["x"]).max() <= np.float32(eps) + 1e-7
+    assert np.mean(adv_t[changed_ref] == ref_t[changed_ref]) > 0.85
+    aa = R.AutoAttack(clf, norm="Linf", eps=eps, seed=0, verbose=False, version="custom",
+                      attacks_to_run=["apgd-ce", "apgd-t"], device=dev(), alpha=2.0, iterations_apgd=n_iter, use_rs=True)
+    aa.apgd.n_restarts = 1
+    aa.apgd_targeted.n_target_classes = ntc
+    x_adv, y_adv = aa.run_standard_evaluation(x.clone(), y.clone(), bs=int(z["bs"]), return_labels=True)
+    with torch.no_grad():
+        robust = (clf(x_adv).max(1)[1] == y).cpu().numpy()
+    assert np.array_equal(robust, z[tag + "_robust"])
+    assert np.array_equal(y_adv.cpu().numpy(), z[tag + "_y_adv"])
+    xa = x_adv.cpu().numpy()
+    moved = (z[tag + "_x_adv"] != z["x"]).reshape(7, -1).any(1)
+    assert np.array_equal((xa != z["x"]).reshape(7, -1).any(1), moved)
+    assert np.mean(xa[moved] == z[tag + "_x_adv"][moved]) > 0.85
+    assert abs(R.compute_accuracy_no_dataloader(clf, x_adv, y, dev(), batch_size=3) - float(z[tag + "_robust"].mean())) < 1e-9
+    eng.close()
+
+
 def test_full_size_properties_vit_l14_bf16():
     """BASELINE config 2 shape (ViT-L/14, bf16, 10-step PGD, eps=4/255) at a batch the test box runs in
     seconds: size-independent properties - determinism, ||delta||_inf = float32(eps), range, loss goes

@@ -147,3 +147,50 @@ def test_autopgd_bit_exact(r):
     assert np.array_equal(adv.numpy(), z["adv"])
     # never-attacked sample (started misclassified) comes back untouched
     assert np.array_equal(adv.numpy()[0], z["x"][0])
+
+
+# ------------------------------------------------------------------ section 8(f) rank 3: AutoAttack orchestration
+def test_dlr_losses_bit_exact():
+    z = load_golden("dlr_losses.npz")
+    obj = A.APGDAttackRef(lambda v: v, eps=0.1, n_iter=5, loss="dlr")
+    for name, tgt in (("dlr", None), ("dlr_targeted", torch.from_numpy(z["y_target"]))):
+        lg = torch.from_numpy(z["logits"]).clone().requires_grad_(True)
+        obj.y_target = tgt
+        fn = obj.dlr_loss if tgt is None else obj.dlr_loss_targeted
+        loss = fn(lg, torch.from_numpy(z["y"]))
+        (g,) = torch.autograd.grad(loss.sum(), lg)
+        assert np.array_equal(loss.detach().numpy(), z[name])
+        assert np.array_equal(g.numpy(), z[name + "_grad"])
+
+
+@pytest.mark.parametrize("tag", ["e3", "e5"])
+def test_autoattack_orchestration_bit_exact(tag):
+    from oracle import autoattack_ref as AA
+    z = load_golden("autoattack_tiny.npz")
+    cfg = V.VIT_TINY
+    w = V.init_weights(cfg, seed=int(z["weights_seed"]))
+    assert weights_digest(w) == str(z["weights_sha256"])
+    clf = V.ClassificationModelRef(cfg, w, torch.from_numpy(z["T"]), 100.0).eval()
+    calls = []
+
+    def predict(v):
+        calls.append(tuple(v.shape))
+        return clf(v)
+
+    x, y, eps = torch.from_numpy(z["x"]), torch.from_numpy(z["y"]), float(z[tag + "_eps"])
+    atk = AA.APGDAttackTargetedRef(predict, n_iter=int(z["n_iter"]), norm="Linf", n_restarts=1, eps=eps, seed=0,
+                                   n_target_classes=int(z["n_target_classes"]), alpha=2.0, use_rs=True)
+    adv_t = atk.perturb(x.clone(), y.clone())
+    assert len(calls) == int(z[tag + "_n_model_calls_targeted"])
+    assert np.array_equal(adv_t.numpy(), z[tag + "_adv_targeted"])
+    calls.clear()
+    aa = AA.AutoAttackRef(predict, norm="Linf", eps=eps, seed=0, version="custom", attacks_to_run=["apgd-ce", "apgd-t"],
+                          alpha=2.0, iterations_apgd=int(z["n_iter"]), use_rs=True)
+    aa.apgd.n_restarts = 1
+    aa.apgd_targeted.n_target_classes = int(z["n_target_classes"])
+    x_adv, y_adv = aa.run_standard_evaluation(x.clone(), y.clone(), bs=int(z["bs"]), return_labels=True)
+    assert len(calls) == int(z[tag + "_n_model_calls_aa"])
+    assert np.array_equal(x_adv.numpy(), z[tag + "_x_adv"])
+    assert np.array_equal(y_adv.numpy(), z[tag + "_y_adv"])
+    with torch.no_grad():
+        assert np.array_equal((clf(x_adv).max(1)[1] == y).numpy(), z[tag + "_robust"])
