@@ -219,6 +219,18 @@ int rvlm_apgd_run(rvlm_vit* h, const float* x, const float* x_init, int B,
                   float* loss_best, uint8_t* acc, rvlm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Input front end: replaces Compose([Resize(size, bicubic), CenterCrop(size),
+ * ToTensor()]) over a decoded RGB image (train/adversarial_training_clip.py:105-116; torchvision 0.15.2 over Pillow).
+ * img_hwc: device uint8 [H, W, 3]; out_chw: device float32 [3, size, size] in [0,1] (NOT normalised).  Bit-exact with
+ * Pillow's 8-bit bicubic resampler.  The taps of an input shape are computed on the host and cached in the object:
+ * consecutive images of equal shape cost one kernel launch.  max_input_dim bounds the longer input edge.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct rvlm_preproc rvlm_preproc;
+int rvlm_preproc_create(int size, int max_input_dim, rvlm_preproc** out);
+int rvlm_preproc_destroy(rvlm_preproc* p);
+int rvlm_preproc_run(rvlm_preproc* p, const uint8_t* img_hwc, int H, int W, float* out_chw, rvlm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Measurement support: per-kernel-class HIP-event timing on the engine's stream.
  * ------------------------------------------------------------------------------------------- */
 typedef struct {

@@ -1,0 +1,53 @@
+"""Input front end on the device.
+
+``ResizeCenterCropToTensor(224)`` is the transform the reference runs on its DataLoader workers -
+``Compose([Resize(224, bicubic), CenterCrop(224), ToTensor()])`` (train/adversarial_training_clip.py:105-116, the
+open_clip image processor minus Normalize) - applied to DECODED images (uint8 HWC tensors on the GPU; JPEG decoding is
+not part of this path).  Outputs are bit-identical to torchvision-over-Pillow: see csrc/preprocess.hip.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+class ResizeCenterCropToTensor:
+    def __init__(self, size: int = 224, max_input_dim: int = 8192):
+        self.size = int(size)
+        self.lib = L.load()
+        self._h = C.c_void_p()
+        L.check(self.lib.rvlm_preproc_create(self.size, int(max_input_dim), C.byref(self._h)), "rvlm_preproc_create")
+
+    def __call__(self, img: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+        """img: uint8 [H, W, 3] CUDA tensor (a decoded RGB image) -> float32 [3, size, size] in [0, 1]."""
+        if not (isinstance(img, torch.Tensor) and img.is_cuda and img.dtype == torch.uint8 and img.dim() == 3
+                and img.shape[2] == 3):
+            raise ValueError("expected a uint8 CUDA tensor of shape [H, W, 3]")
+        img = img.contiguous()
+        if out is None:
+            out = torch.empty(3, self.size, self.size, dtype=torch.float32, device=img.device)
+        with torch.cuda.device(img.device):
+            L.check(self.lib.rvlm_preproc_run(self._h, img.data_ptr(), img.shape[0], img.shape[1], out.data_ptr(),
+                                              L.stream_ptr()), "rvlm_preproc_run")
+        return out
+
+    def batch(self, images) -> torch.Tensor:
+        """List of decoded images (any sizes) -> [B, 3, size, size]; same-shaped neighbours share their tap tables."""
+        out = torch.empty(len(images), 3, self.size, self.size, dtype=torch.float32, device=images[0].device)
+        for i, im in enumerate(images):
+            self(im, out[i])
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.rvlm_preproc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

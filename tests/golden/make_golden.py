@@ -401,9 +401,39 @@ def g7_autoattack():
             out[f"{tag}_robust_after_ce"] = (clf(xa1).max(1)[1] == yy).numpy()
     save("autoattack_tiny.npz", **out)
 
+# ------------------------------------------------------------------ G8: input transform (section 8(f) rank 4)
+def g8_preprocess():
+    """Resize(size, bicubic) -> CenterCrop(size) -> ToTensor on synthetic 'decoded' images, computed by Pillow (the
+    resampler torchvision 0.15.2 delegates to for PIL inputs) with torchvision's size / crop arithmetic.  Stored as the
+    uint8 crop (ToTensor = /255 in float32 is exact to restate)."""
+    from PIL import Image
+    rng = np.random.default_rng(8)
+    out = {}
+    cases = [(61, 47, 32), (37, 90, 32), (40, 40, 32), (20, 27, 32), (300, 260, 224), (96, 400, 64)]
+    for i, (h, w, size) in enumerate(cases):
+        # low-frequency content + noise + saturated patches (clipping paths of the resampler)
+        yy, xx = np.mgrid[0:h, 0:w]
+        base = np.stack([127 + 120 * np.sin(xx / 7.0 + c) * np.cos(yy / 5.0 - c) for c in range(3)], -1)
+        img = np.clip(base + rng.normal(0, 25, (h, w, 3)), 0, 255).astype(np.uint8)
+        img[: h // 5, : w // 4] = 255
+        img[-h // 6:, -w // 3:] = 0
+        if w <= h:
+            nw, nh = size, (size if w == h else int(size * h / w))
+        else:
+            nh, nw = size, int(size * w / h)
+        r = Image.fromarray(img).resize((nw, nh), Image.BICUBIC)
+        top, left = int(round((nh - size) / 2.0)), int(round((nw - size) / 2.0))
+        crop = np.asarray(r.crop((left, top, left + size, top + size)))
+        out[f"img{i}"] = img
+        out[f"crop{i}"] = crop
+        out[f"size{i}"] = np.int64(size)
+    out["n"] = np.int64(len(cases))
+    save("preprocess_pil.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
     fns = dict(g1=g1_pgd_elementwise, g2=g2_apgd_controller, g3=g3_tiny_vit_attacks,
-               g4=g4_autopgd, g5=g5_vit_vs_hf, g6=g6_losses, g7=g7_autoattack)
+               g4=g4_autopgd, g5=g5_vit_vs_hf, g6=g6_losses, g7=g7_autoattack, g8=g8_preprocess)
     for k in which:
         fns[k]()

@@ -218,3 +218,32 @@ def test_apgd_kernels_vs_c_oracle_state_by_state(n_iter):
                 bad = np.argwhere(got != r)[:5]
                 raise AssertionError(f"iteration {i} (do_check={do_check}, k={k}): {name} differs at {bad.tolist()} "
                                      f"got {got[tuple(bad[0])]} want {r[tuple(bad[0])]}")
+
+
+# ------------------------------------------------------------------ section 8(f) rank 4: input front end
+def test_preprocess_kernel_bit_exact_vs_pillow_golden():
+    """csrc/preprocess.hip against Pillow's own output (tests/golden/preprocess_pil.npz) and, on larger / odd shapes,
+    against the oracle restatement (itself pinned bit-exactly to Pillow): every pixel identical."""
+    import robustvlm_amd as R
+    from oracle import preprocess_ref as P
+    from tests.helpers import load_golden
+    z = load_golden("preprocess_pil.npz")
+    tf = {}
+    for i in range(int(z["n"])):
+        size = int(z[f"size{i}"])
+        tf.setdefault(size, R.ResizeCenterCropToTensor(size))
+        got = tf[size](torch.from_numpy(z[f"img{i}"]).cuda()).cpu().numpy()
+        want = z[f"crop{i}"].transpose(2, 0, 1).astype(np.float32) / np.float32(255)
+        assert np.array_equal(got, want), f"golden case {i}"
+    rng = np.random.default_rng(3)
+    t224 = tf.setdefault(224, R.ResizeCenterCropToTensor(224))
+    imgs = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in ((375, 500), (500, 333), (224, 224), (100, 150),
+                                                                          (1200, 1600), (225, 1000), (375, 500))]
+    batch = t224.batch([torch.from_numpy(a).cuda() for a in imgs]).cpu().numpy()
+    for a, b in zip(imgs, batch):
+        assert np.array_equal(b, P.preprocess_ref(a, 224)), a.shape
+    with pytest.raises(ValueError):
+        t224(torch.zeros(4, 4, 3).cuda())
+    small = R.ResizeCenterCropToTensor(32, max_input_dim=64)
+    with pytest.raises(NotImplementedError):
+        small(torch.zeros(1000, 1000, 3, dtype=torch.uint8).cuda())   # 31x down-scaling needs more taps than provisioned

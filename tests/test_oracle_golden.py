@@ -194,3 +194,15 @@ def test_autoattack_orchestration_bit_exact(tag):
     assert np.array_equal(y_adv.numpy(), z[tag + "_y_adv"])
     with torch.no_grad():
         assert np.array_equal((clf(x_adv).max(1)[1] == y).numpy(), z[tag + "_robust"])
+
+
+# ------------------------------------------------------------------ section 8(f) rank 4: input transform
+def test_preprocess_oracle_bit_exact_vs_pillow_golden():
+    from oracle import preprocess_ref as P
+    z = load_golden("preprocess_pil.npz")
+    for i in range(int(z["n"])):
+        got = P.preprocess_ref(z[f"img{i}"], int(z[f"size{i}"]))
+        want = z[f"crop{i}"].transpose(2, 0, 1).astype(np.float32) / np.float32(255)
+        assert got.dtype == np.float32 and np.array_equal(got, want), f"case {i}"
+    assert P.resize_size(375, 500, 224) == (224, 298) and P.resize_size(500, 333, 224) == (336, 224)
+    assert P.center_crop_box(224, 298, 224, 224) == (0, 37) and P.center_crop_box(336, 224, 224, 224) == (56, 0)
