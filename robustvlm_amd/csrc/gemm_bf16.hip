@@ -307,8 +307,18 @@ int gemm_bf16_nt(const GemmBf16& p, hipStream_t s) {
         if (p.residual) r.residual = p.residual + (long)done * p.ldo;
         r.M = p.M - done;
         r.a_rows = (p.a_rows > 0 ? p.a_rows : p.M) - done;
-        // split-K when the serial K walk dominates (K >= 2048) and a scratch slab is available
-        const int splitk = (p.K >= 4096) ? 8 : (p.K >= 2048 ? (p.K % (6 * GB_K) == 0 ? 6 : 4) : 1);
+        // split-K: the strip is a handful of 128x128 tiles walking K serially (~1 us per 64-deep step, latency-bound).
+        // Cut K so that >= 128 workgroups share the walk, each keeping >= 2 K-steps; fp32 slabs + reduce/epilogue kernel.
+        int splitk = 1;
+        {
+            const int nk64 = p.K / GB_K, tiles = cdiv(r.M, GB_M) * cdiv(p.N, GB_N);
+            for (int cand : {2, 3, 4, 6, 8, 12, 16}) {
+                if (nk64 % cand != 0 || nk64 / cand < 2 || tiles * cand > 512) continue;
+                if ((size_t)cand * r.M * p.N * sizeof(float) > g_splitk_bytes) continue;
+                splitk = cand;
+                if (tiles * cand >= 128) break;
+            }
+        }
         const size_t need = (size_t)splitk * r.M * p.N * sizeof(float);
         if (splitk > 1 && r.M <= 256 && g_splitk_scratch && need <= g_splitk_bytes && p.K % (splitk * GB_K) == 0) {
             GemmBf16 part = r;

@@ -84,9 +84,23 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n) {
         a_soff = (m0 + w * 32) * lda * 2;
         b_soff = (n0 + w * 32) * ldb * 2;
     }
+    // experiment (ABL & 8): the same operand stream as plain buffer_load_dwordx4 into registers (folded into a sink one
+    // K-step later) - compares the VGPR return path of the texture unit with the LDS-DMA path
+    u32x4 pendA[4], pendB[4], sink = {0u, 0u, 0u, 0u};
+    if (ABL & 8) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { pendA[j] = sink; pendB[j] = sink; }
+    }
     auto issue_a = [&]() -> bool {
         if (a_ti >= ntw) return false;
-        if (!(ABL & 1)) {
+        if (ABL & 8) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                sink ^= pendA[j];
+                pendA[j] = __builtin_amdgcn_raw_buffer_load_b128(
+                    a_rs, a_loff[j & 1], __builtin_amdgcn_readfirstlane(a_soff + a_kt * (P_K * 2) + j * 16 * lda), 0);
+            }
+        } else if (!(ABL & 1)) {
             __attribute__((address_space(3))) char* dst =
                 (__attribute__((address_space(3))) char*)lds + (a_slot * PA_SLOT + stage_wave_off);
 #pragma unroll
@@ -108,7 +122,14 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n) {
     };
     auto issue_b = [&]() -> bool {
         if (b_ti >= ntw) return false;
-        if (!(ABL & 1)) {
+        if (ABL & 8) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                sink ^= pendB[j];
+                pendB[j] = __builtin_amdgcn_raw_buffer_load_b128(
+                    b_rs, b_loff[j & 1], __builtin_amdgcn_readfirstlane(b_soff + b_kt * (P_K * 2) + j * 16 * ldb), 0);
+            }
+        } else if (!(ABL & 1)) {
             __attribute__((address_space(3))) char* dst =
                 (__attribute__((address_space(3))) char*)lds + (PB_BASE + b_slot * PB_SLOT + stage_wave_off);
 #pragma unroll
@@ -400,6 +421,11 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n) {
         p.trace[((long)blockIdx.x * 8 + 7) * 4 + 2] = __builtin_amdgcn_s_memtime();
         p.trace[((long)blockIdx.x * 8 + 7) * 4 + 3] = __builtin_amdgcn_s_memrealtime();
     }
+    if (ABL & 8) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sink ^= pendA[j] ^ pendB[j];
+        if (sink.x == 0x12345678u && sink.y == 0x9abcdef0u && sink.z == sink.w) store16(sink, o_rs, 0, 0);
+    }
 }
 
 int g_persist_ablate = 0;
@@ -433,6 +459,8 @@ static int launch_256p_act(const GemmBf16& p, int tiles_m, int tiles_n, hipStrea
             case 4: return launch_256p_abl<EPI, ACT, 4>(p, tiles_m, tiles_n, s);
             case 5: return launch_256p_abl<EPI, ACT, 5>(p, tiles_m, tiles_n, s);
             case 6: return launch_256p_abl<EPI, ACT, 6>(p, tiles_m, tiles_n, s);
+            case 14: return launch_256p_abl<EPI, ACT, 14>(p, tiles_m, tiles_n, s);
+            case 12: return launch_256p_abl<EPI, ACT, 12>(p, tiles_m, tiles_n, s);
             default: break;
         }
     }
