@@ -12,7 +12,8 @@ extern "C" {
 #endif
 
 /* C[M,N] = epi(A[M,K] @ Bw[N,K]^T): epi 0 bf16 out(+bias); 1 f32 out(+bias)(+residual f32);
- * 2 out_pre=bf16(acc+bias), out=bf16 act(.); 3 out=bf16 acc*act'(h_pre); 4 f32 out(+bias).
+ * 2 h=acc+bias: out=bf16 act(h), out_pre=bf16 act'(h); 3 out=bf16 acc*h_pre (h_pre = a stored act'(h));
+ * 4 f32 out(+bias).
  * A must be readable for round_up(M,128) rows. */
 int rvlm_k_gemm_bf16_nt(const uint16_t* A, long lda, const uint16_t* Bw, long ldb, int M, int N, int K,
                         int a_rows, int epi, const float* bias, void* out, long ldo, uint16_t* out_pre,

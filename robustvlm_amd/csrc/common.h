@@ -78,6 +78,19 @@ __device__ __forceinline__ float act_bwd(float h, int act) {
         return cdf + h * pdf;
     }
 }
+// act(h) and act'(h) together (they share the sigmoid / erf): the bf16 fc1 epilogue stores both, so that the fc2 dgrad
+// epilogue is one multiply instead of an exp + rcp per element
+__device__ __forceinline__ void act_pair(float h, int act, float& a, float& d) {
+    if (act == RVLM_ACT_QUICK_GELU) {
+        const float s = 1.0f / (1.0f + __expf(-1.702f * h));
+        a = h * s;
+        d = s * (1.0f + 1.702f * h * (1.0f - s));
+    } else {
+        const float cdf = 0.5f * (1.0f + erff(h * 0.70710678118654752f));
+        a = h * cdf;
+        d = cdf + h * (0.3989422804014327f * __expf(-0.5f * h * h));
+    }
+}
 // precise variants for the fp32 (parity) path
 __device__ __forceinline__ float act_fwd_precise(float h, int act) {
     if (act == RVLM_ACT_QUICK_GELU) {

@@ -161,14 +161,19 @@ splitk_reduce_kernel(const float* __restrict__ slabs, int splitk, GemmBf16 p) {
         } else if (EPI == EPI_BF16_ACT) {
             bf16x4 pv, ov;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { pv[e] = (bf16_t)f[e]; ov[e] = (bf16_t)act_fwd(f[e], p.act); }
+            for (int e = 0; e < 4; ++e) {
+                float av, dv;
+                act_pair(f[e], p.act, av, dv);
+                pv[e] = (bf16_t)dv;
+                ov[e] = (bf16_t)av;
+            }
             *(bf16x4*)(p.out_pre + o) = pv;
             *(bf16x4*)((bf16_t*)p.out + o) = ov;
         } else if (EPI == EPI_BF16_DACT) {
             const bf16x4 hv = *(const bf16x4*)(p.h_pre + o);
             bf16x4 ov;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) ov[e] = (bf16_t)(f[e] * act_bwd((float)hv[e], p.act));
+            for (int e = 0; e < 4; ++e) ov[e] = (bf16_t)(f[e] * (float)hv[e]);
             *(bf16x4*)((bf16_t*)p.out + o) = ov;
         } else {
             *(float4*)((float*)p.out + o) = make_float4(f[0], f[1], f[2], f[3]);

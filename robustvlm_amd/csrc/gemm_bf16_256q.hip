@@ -317,7 +317,7 @@ gemm_bf16_nt_256q_kernel(GemmBf16 p, int tiles_m, int tiles_n) {
                     const unsigned r16_a = eb + r0 * 128 + (((lane & 7) ^ (r0 >> 1)) << 4);
                     const unsigned r16_b = eb + r0 * 128 + (((lane & 7) ^ (r0 >> 1) ^ 4) << 4);
                     const int so = __builtin_amdgcn_readfirstlane(((m_base + mi * 32) * ldo + n_base + nh * 64) * 2);
-                    auto stage_flush = [&](__amdgpu_buffer_rsrc_t rs, bool activated) {
+                    auto stage_flush = [&](__amdgpu_buffer_rsrc_t rs, int what) {   // what: 0 value, 1 act(value), 2 act'(value)
 #pragma unroll
                         for (int nj = 0; nj < 2; ++nj)
 #pragma unroll
@@ -327,7 +327,11 @@ gemm_bf16_nt_256q_kernel(GemmBf16 p, int tiles_m, int tiles_n) {
                                               acc[mi][ni][g * 4 + 3]};
                                 bf16x4 o;
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(activated ? actp_fwd<ACT>(v[e]) : v[e]);
+                                for (int e = 0; e < 4; ++e) {
+                                float av, dv;
+                                actp_pair<ACT>(v[e], av, dv);
+                                o[e] = (bf16_t)(what == 0 ? v[e] : what == 1 ? av : dv);
+                            }
                                 lds_w64(w16_pre ^ ((nj * 8 + 2 * g) << 3), __builtin_bit_cast(u32x2, o));
                             }
                         u32x4 t0 = lds_r128<0>(r16_a), t1 = lds_r128<8 * 128>(r16_b), t2 = lds_r128<16 * 128>(r16_a),
@@ -342,8 +346,8 @@ gemm_bf16_nt_256q_kernel(GemmBf16 p, int tiles_m, int tiles_n) {
                         store16(t2, rs, st16_loff, so + 32 * ldo);
                         store16(t3, rs, st16_loff, so + 48 * ldo);
                     };
-                    stage_flush(EPI == EPI_BF16_ACT ? pre_rs : o_rs, false);
-                    if (EPI == EPI_BF16_ACT) stage_flush(o_rs, true);
+                    stage_flush(EPI == EPI_BF16_ACT ? pre_rs : o_rs, EPI == EPI_BF16_ACT ? 2 : 0);
+                    if (EPI == EPI_BF16_ACT) stage_flush(o_rs, 1);
 #pragma unroll
                     for (int nj = 0; nj < 2; ++nj)
 #pragma unroll
@@ -382,7 +386,7 @@ gemm_bf16_nt_256q_kernel(GemmBf16 p, int tiles_m, int tiles_n) {
                             const bf16x8 h8 = __builtin_bit_cast(bf16x8, side[sub % SIDE_DEPTH][half]);
                             bf16x8 o;
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(f[e] * actp_bwd<ACT>((float)h8[e]));
+                            for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(f[e] * (float)h8[e]);   // h8 = act'(h) stored by the forward
                             store16(__builtin_bit_cast(u32x4, o), o_rs, h16_loff, so + half * 32 * ldo);
                         }
                     } else {

@@ -45,13 +45,15 @@ __device__ __forceinline__ void gemm_epilogue_edge(const f32x16 (&acc)[MI][NI], 
                 } else if (EPI == EPI_BF16_ACT) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        p.out_pre[o + e] = (bf16_t)v[e];
-                        ((bf16_t*)p.out)[o + e] = (bf16_t)act_fwd(v[e], p.act);
+                        float av, dv;
+                        act_pair(v[e], p.act, av, dv);
+                        p.out_pre[o + e] = (bf16_t)dv;
+                        ((bf16_t*)p.out)[o + e] = (bf16_t)av;
                     }
                 } else if (EPI == EPI_BF16_DACT) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        ((bf16_t*)p.out)[o + e] = (bf16_t)(v[e] * act_bwd((float)p.h_pre[o + e], p.act));
+                        ((bf16_t*)p.out)[o + e] = (bf16_t)(v[e] * (float)p.h_pre[o + e]);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) ((float*)p.out)[o + e] = v[e];
@@ -116,19 +118,21 @@ __device__ __forceinline__ void gemm_epilogue_full(const f32x16 (&acc)[MI][2], c
                 v[ni][g][3] = acc[mi][ni][g * 4 + 3] + bv[ni][g].w;
             }
         const long row0 = (long)(m_base + mi * 32) * p.ldo + n_base;
-        if (EPI == EPI_BF16 || EPI == EPI_BF16_ACT) {
+        if (EPI == EPI_BF16) {
             stage_bf16(buf, v, l31, hi);
-            flush_bf16(buf, (EPI == EPI_BF16_ACT ? p.out_pre : (bf16_t*)p.out) + row0, p.ldo, lane);
-            if (EPI == EPI_BF16_ACT) {
+            flush_bf16(buf, (bf16_t*)p.out + row0, p.ldo, lane);
+        } else if (EPI == EPI_BF16_ACT) {
+            float d[2][4][4];   // act'(h) -> out_pre, act(h) -> out
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
+            for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g)
+                for (int g = 0; g < 4; ++g)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[ni][g][e] = act_fwd(v[ni][g][e], p.act);
-                stage_bf16(buf, v, l31, hi);
-                flush_bf16(buf, (bf16_t*)p.out + row0, p.ldo, lane);
-            }
+                    for (int e = 0; e < 4; ++e) act_pair(v[ni][g][e], p.act, v[ni][g][e], d[ni][g][e]);
+            stage_bf16(buf, d, l31, hi);
+            flush_bf16(buf, p.out_pre + row0, p.ldo, lane);
+            stage_bf16(buf, v, l31, hi);
+            flush_bf16(buf, (bf16_t*)p.out + row0, p.ldo, lane);
         } else {
             // fp32 staging: 16 lanes x 16 B per row (64 fp32), 4 rows per wave instruction
             stage_f32(buf, v, l31, hi);
@@ -148,7 +152,7 @@ __device__ __forceinline__ void gemm_epilogue_full(const f32x16 (&acc)[MI][2], c
                     const bf16x8 h8 = *(const bf16x8*)&hv[it];
                     bf16x8 o;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(f[e] * act_bwd((float)h8[e], p.act));
+                    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(f[e] * (float)h8[e]);
                     *(bf16x8*)((bf16_t*)p.out + row0 + (long)(it * 8 + (lane >> 3)) * p.ldo + (lane & 7) * 8) = o;
                 }
             } else {

@@ -20,20 +20,18 @@ __device__ __forceinline__ void glds16p(const void* gptr, void* lds_ptr) {
                                      (__attribute__((address_space(3))) void*)lds_ptr, 16, 0, 0);
 }
 
+// act(h) and act'(h) together (shared sigmoid / erf); fast reciprocal for the QuickGELU of the CLIP towers
 template <int ACT>
-__device__ __forceinline__ float actp_fwd(float h) {
-    if (ACT == RVLM_ACT_QUICK_GELU) return h * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * h));
-    return 0.5f * h * (1.0f + erff(h * 0.70710678118654752f));
-}
-template <int ACT>
-__device__ __forceinline__ float actp_bwd(float h) {
+__device__ __forceinline__ void actp_pair(float h, float& a, float& d) {
     if (ACT == RVLM_ACT_QUICK_GELU) {
         const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * h));
-        return s * (1.0f + 1.702f * h * (1.0f - s));
+        a = h * s;
+        d = s * (1.0f + 1.702f * h * (1.0f - s));
+    } else {
+        const float cdf = 0.5f * (1.0f + erff(h * 0.70710678118654752f));
+        a = h * cdf;
+        d = cdf + h * (0.3989422804014327f * __expf(-0.5f * h * h));
     }
-    const float cdf = 0.5f * (1.0f + erff(h * 0.70710678118654752f));
-    const float pdf = 0.3989422804014327f * __expf(-0.5f * h * h);
-    return cdf + h * pdf;
 }
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));

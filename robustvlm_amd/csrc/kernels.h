@@ -33,8 +33,8 @@ int gemm_f32(const GemmF32& p, hipStream_t s);
 enum GemmEpi {
     EPI_BF16 = 0,          // out bf16 = acc (+bias)
     EPI_F32_RESID = 1,     // out f32  = acc (+bias) (+residual f32)
-    EPI_BF16_ACT = 2,      // out_pre bf16 = acc+bias ; out bf16 = act(acc+bias)
-    EPI_BF16_DACT = 3,     // out bf16 = acc * act'(h_pre bf16)
+    EPI_BF16_ACT = 2,      // h = acc+bias: out bf16 = act(h); out_pre bf16 = act'(h) (all the backward needs of h)
+    EPI_BF16_DACT = 3,     // out bf16 = acc * h_pre, h_pre bf16 = the act'(h) an EPI_BF16_ACT launch stored
     EPI_F32 = 4            // out f32 = acc (+bias)
 };
 struct GemmBf16 {
@@ -45,8 +45,8 @@ struct GemmBf16 {
     int epi = EPI_BF16;
     const float* bias = nullptr;        // [N] or null
     void* out = nullptr; long ldo = 0;  // bf16 or f32 per epi
-    bf16_t* out_pre = nullptr;          // EPI_BF16_ACT (ld = ldo)
-    const bf16_t* h_pre = nullptr;      // EPI_BF16_DACT (ld = ldo)
+    bf16_t* out_pre = nullptr;          // EPI_BF16_ACT: act'(h) (ld = ldo)
+    const bf16_t* h_pre = nullptr;      // EPI_BF16_DACT: act'(h) of the matching forward (ld = ldo)
     const float* residual = nullptr;    // EPI_F32_RESID (ld = ldo)
     int act = RVLM_ACT_QUICK_GELU;
     unsigned long long* trace = nullptr;   // persistent kernel only: per-tile s_memtime stamps (test hook)
