@@ -284,20 +284,21 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n) {
         constexpr int SIDE_DEPTH = 4;
         u32x4 side[SIDE_DEPTH][4];
         auto load_side = [&](int sub) {
-            const int mi = sub >> 1, ni = sub & 1;
-            if (EPI == EPI_F32_RESID) {    // 32 rows x 128 B: 4 loads of 8 rows
+            if (EPI == EPI_F32_RESID) {    // sub = 2*mi + ni: 32 rows x 128 B, 4 loads of 8 rows
+                const int mi = sub >> 1, ni = sub & 1;
                 const int so = __builtin_amdgcn_readfirstlane(((m_base + mi * 32) * ldo + n_base + ni * 32) * 4);
 #pragma unroll
                 for (int it = 0; it < 4; ++it)
                     side[sub % SIDE_DEPTH][it] = __builtin_amdgcn_raw_buffer_load_b128(r_rs, st32_loff, so + it * 32 * ldo, 0);
-            } else {                        // 32 rows x 64 B: 2 loads of 16 rows
-                const int so = __builtin_amdgcn_readfirstlane(((m_base + mi * 32) * ldo + n_base + ni * 32) * 2);
-                side[sub % SIDE_DEPTH][0] = __builtin_amdgcn_raw_buffer_load_b128(h_rs, h16_loff, so, 0);
-                side[sub % SIDE_DEPTH][1] = __builtin_amdgcn_raw_buffer_load_b128(h_rs, h16_loff, so + 32 * ldo, 0);
+            } else {                        // sub = mi: act'(h) next to the 32 x 64 bf16 block, 4 loads of 8 rows x 128 B
+                const int so = __builtin_amdgcn_readfirstlane(((m_base + sub * 32) * ldo + n_base) * 2);
+#pragma unroll
+                for (int it = 0; it < 4; ++it)
+                    side[sub % SIDE_DEPTH][it] = __builtin_amdgcn_raw_buffer_load_b128(h_rs, st16_loff, so + it * 16 * ldo, 0);
             }
         };
         if (EPI == EPI_F32_RESID) load_side(0);                            // a0/b0 are dead
-        if (EPI == EPI_BF16_DACT) { load_side(0); load_side(1); load_side(2); load_side(3); }
+        if (EPI == EPI_BF16_DACT) { load_side(0); load_side(1); }
         __builtin_amdgcn_sched_barrier(0);
         mma(a1, b1);
         __builtin_amdgcn_sched_barrier(0);
@@ -313,6 +314,7 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n) {
                 }
         __builtin_amdgcn_sched_barrier(0);
         if (EPI == EPI_F32_RESID) { load_side(1); load_side(2); load_side(3); }
+        if (EPI == EPI_BF16_DACT) { load_side(2); load_side(3); }
         stamp(ti, 2);
 
         // ---- epilogue of (m0, n0): staging through the freed B slot, accumulators re-zeroed sub-tile by sub-tile ----
@@ -325,11 +327,11 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n) {
         const unsigned r32 = ebuf + r0 * 128 + (((lane & 7) ^ r0) << 4);                // fp32 ((r0 + 8*it) & 7 == r0)
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
-            if (!OUT_F32 && EPI != EPI_BF16_DACT) {
+            if (!OUT_F32) {
                 // bf16 output(s): stage 32 rows x 64 columns (128-B rows, 8-B chunk index XOR (row & 15)), then 4
                 // stores of 8 full 128-B rows each.
                 const int so = __builtin_amdgcn_readfirstlane(((m_base + mi * 32) * ldo + n_base) * 2);
-                auto stage_flush = [&](__amdgpu_buffer_rsrc_t rs, int what) {   // what: 0 value, 1 act(value), 2 act'(value)
+                auto stage_flush = [&](__amdgpu_buffer_rsrc_t rs, int what) {   // what: 0 value, 1 act(value), 2 act'(value), 3 value * side
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -341,7 +343,7 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n) {
                             for (int e = 0; e < 4; ++e) {
                                 float av, dv;
                                 actp_pair<ACT>(v[e], av, dv);
-                                o[e] = (bf16_t)(what == 0 ? v[e] : what == 1 ? av : dv);
+                                o[e] = (bf16_t)(what == 1 ? av : what == 2 ? dv : v[e]);
                             }
                             lds_w64(w16_pre ^ ((ni * 8 + 2 * g) << 3), __builtin_bit_cast(u32x2, o));
                         }
@@ -352,12 +354,23 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n) {
                         t0 = __builtin_shufflevector(t0, t0, 2, 3, 0, 1); t1 = __builtin_shufflevector(t1, t1, 2, 3, 0, 1);
                         t2 = __builtin_shufflevector(t2, t2, 2, 3, 0, 1); t3 = __builtin_shufflevector(t3, t3, 2, 3, 0, 1);
                     }
+                    if (what == 3) {   // dgrad through the activation: times the act'(h) the forward stored (bf16 x bf16 in fp32)
+                        auto mul8 = [&](u32x4& t, const u32x4& hq) {
+                            const bf16x8 a = __builtin_bit_cast(bf16x8, t), b = __builtin_bit_cast(bf16x8, hq);
+                            bf16x8 o;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) o[e] = (bf16_t)((float)a[e] * (float)b[e]);
+                            t = __builtin_bit_cast(u32x4, o);
+                        };
+                        mul8(t0, side[mi % SIDE_DEPTH][0]); mul8(t1, side[mi % SIDE_DEPTH][1]);
+                        mul8(t2, side[mi % SIDE_DEPTH][2]); mul8(t3, side[mi % SIDE_DEPTH][3]);
+                    }
                     store16(t0, rs, st16_loff, so);
                     store16(t1, rs, st16_loff, so + 16 * ldo);
                     store16(t2, rs, st16_loff, so + 32 * ldo);
                     store16(t3, rs, st16_loff, so + 48 * ldo);
                 };
-                stage_flush(EPI == EPI_BF16_ACT ? pre_rs : o_rs, EPI == EPI_BF16_ACT ? 2 : 0);
+                stage_flush(EPI == EPI_BF16_ACT ? pre_rs : o_rs, EPI == EPI_BF16_ACT ? 2 : EPI == EPI_BF16_DACT ? 3 : 0);
                 if (EPI == EPI_BF16_ACT) stage_flush(o_rs, 1);
                 init_acc(mi, 0);
                 init_acc(mi, 1);
@@ -373,27 +386,7 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n) {
                         lds_w128(w32_pre ^ (g << 5), __builtin_bit_cast(u32x4, v));
                     }
                     init_acc(mi, ni);
-                    if (EPI == EPI_BF16_DACT) {
-                        const int so = __builtin_amdgcn_readfirstlane(((m_base + mi * 32) * ldo + n_base + ni * 32) * 2);
-                        // lane: row half*16 + (lane>>2), 8 columns (lane&3)*8.. = 16-B chunks q, q+1 of its staged row
-                        const int drow = lane >> 2, dq = (lane & 3) * 2;
-                        const unsigned dA = ebuf + drow * 128 + ((dq ^ (drow & 7)) << 4);
-                        const unsigned dB = ebuf + drow * 128 + (((dq + 1) ^ (drow & 7)) << 4);
-                        const u32x4 fa0 = lds_r128<0>(dA), fb0 = lds_r128<0>(dB), fa1 = lds_r128<16 * 128>(dA),
-                                    fb1 = lds_r128<16 * 128>(dB);
-                        lds_wait();
-#pragma unroll
-                        for (int half = 0; half < 2; ++half) {
-                            const float4 a = __builtin_bit_cast(float4, half ? fa1 : fa0);
-                            const float4 b = __builtin_bit_cast(float4, half ? fb1 : fb0);
-                            const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-                            const bf16x8 h8 = __builtin_bit_cast(bf16x8, side[sub % SIDE_DEPTH][half]);
-                            bf16x8 o;
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(f[e] * (float)h8[e]);   // h8 = act'(h) stored by the forward
-                            store16(__builtin_bit_cast(u32x4, o), o_rs, h16_loff, so + half * 32 * ldo);
-                        }
-                    } else {
+                    {
                         const int so = __builtin_amdgcn_readfirstlane(((m_base + mi * 32) * ldo + n_base + ni * 32) * 4);
                         u32x4 t[4] = {lds_r128<0>(r32), lds_r128<8 * 128>(r32), lds_r128<16 * 128>(r32),
                                       lds_r128<24 * 128>(r32)};
@@ -408,7 +401,7 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n) {
                             store16(t[it], o_rs, st32_loff, so + it * 32 * ldo);
                         }
                     }
-                    if ((EPI == EPI_F32_RESID || EPI == EPI_BF16_DACT) && sub + SIDE_DEPTH < 8) load_side(sub + SIDE_DEPTH);
+                    if (EPI == EPI_F32_RESID && sub + SIDE_DEPTH < 8) load_side(sub + SIDE_DEPTH);
                 }
             }
         }
