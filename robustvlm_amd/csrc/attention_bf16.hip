@@ -449,7 +449,19 @@ template <int NK>
 __global__ void __launch_bounds__(NK * 64)
 attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __restrict__ o, long ldo,
                       const bf16_t* __restrict__ d_o, long lddo, const float* __restrict__ lse2,
-                      bf16_t* __restrict__ dqkv, long lddq, int H, int S, int W, float scale, float scale_log2) {
+                      bf16_t* __restrict__ dqkv, long lddq, int H, int S, int W, float scale, float scale_log2,
+                      unsigned long long* __restrict__ trace, int desync) {
+    // optional phase timeline (RVLM_ATTN_TRACE=1: 5 s_memtime stamps per workgroup into the dsum scratch buffer)
+    auto stamp = [&](int k) {
+        if (trace && threadIdx.x == 0) trace[(long)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memtime();
+    };
+    // Phase offset: every CU would otherwise stage its head at the same moment (6 TB/s-bound, 22 % of the kernel spent
+    // waiting for HBM) and compute at the same moment (HBM idle).  The first workgroup of each CU starts up to 7 x desync
+    // kilo-cycles late; the stagger then persists, one CU's staging hides under the others' compute.
+    if (desync > 0 && blockIdx.x < 256) {
+        for (int i = 0; i < (int)((blockIdx.x >> 3) & 7) * desync; ++i) __builtin_amdgcn_s_sleep(16);   // 16 x 64 cycles
+    }
+    stamp(0);
     constexpr int NT = NK + 1, Sp = NT * 32, SE = NK * 32;   // query tiles, padded rows, index of the odd key
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Qt = smem;
@@ -462,7 +474,7 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
     float* Pe = Ds + Sp;                                       // p[q][odd key]
     float* De = Pe + Sp;                                       // dS[q][odd key]
     float* Ke = De + Sp;                                       // k[odd key][0..63] as fp32
-    float* KVe = Ke + 64;                                      // [NK][2][64] per-wave dK / dV of the odd key
+    float* KVe = Ke + 64;                                      // [NK + 1][2][64] per-wave (+ odd query) dK / dV of the odd key
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -477,7 +489,11 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
     stage_tile(Vt, base + 2 * W, ld, S, Sp, w, NK, lane);
     for (int i = tid; i < Sp; i += NK * 64) Ls[i] = (i < S) ? lse2[((long)b * H + h) * Sp + i] : INFINITY;
     if (tid < 64) Ke[tid] = (float)base[(long)SE * ld + W + tid];
+    bf16x8 ofr[4];   // O rows of this wave's query tile (for D = rowsum(dO * O)): requested under the staging
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) ofr[kk] = frag_global(ob, ldo, w * 32 + (lane & 31), kk, lane);
     __syncthreads();
+    stamp(1);
 
     const FragOffs fo = make_offs(lane);
     // ---- phase 1: this wave's key tile in registers; D for its query tile(s); the odd key -------------------
@@ -490,15 +506,16 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
         for (int ks = 0; ks < 2; ++ks) kT[dt][ks] = frag_tr(Kt, w * 32 + ks * 16, fo, dt);
     {
         f32x16 dke[2] = {zero16(), zero16()}, dve[2] = {zero16(), zero16()};
-        for (int qe = w; qe < NT; qe += NK) {
-            const int q = qe * 32 + l31, qc = min(q, S - 1);
+        {
+            const int qe = w;   // query tiles 0..NK-1: one per wave (the odd query, tile NK, takes the vector path below)
+            const int q = qe * 32 + l31;
             bf16x8 qf[4], dof[4];
             float dsum = 0.0f;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 qf[kk] = frag_rm(Qt, qe * 32, fo.rm[kk]);
                 dof[kk] = frag_rm(Dt, qe * 32, fo.rm[kk]);
-                const bf16x8 of = frag_global(ob, ldo, qc, kk, lane);
+                const bf16x8 of = ofr[kk];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) dsum = fmaf((float)dof[kk][e], (float)of[e], dsum);
             }
@@ -540,7 +557,19 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
                 }
         }
     }
+    if (w == NK - 1) {
+        // the odd QUERY (row SE) against the odd key, as 64-wide vectors (lane <-> d): D, p, dS, and its dK / dV terms
+        const float dov = (float)dob[(long)SE * lddo + lane], ov = (float)ob[(long)SE * ldo + lane];
+        const float qv = (float)base[(long)SE * ld + lane], kv = Ke[lane], vv = (float)base[(long)SE * ld + 2 * W + lane];
+        const float dsum = wave_sum(dov * ov), sc = wave_sum(qv * kv), dpe = wave_sum(dov * vv);
+        const float pe = EXP2(fmaf(sc, scale_log2, -Ls[SE]));
+        const float de = pe * (dpe - dsum);
+        if (lane < 32) { Ds[SE + lane] = (lane == 0) ? dsum : 0.0f; Pe[SE + lane] = (lane == 0) ? pe : 0.0f; De[SE + lane] = (lane == 0) ? de : 0.0f; }
+        KVe[(NK * 2 + 0) * 64 + lane] = de * qv;
+        KVe[(NK * 2 + 1) * 64 + lane] = pe * dov;
+    }
     __syncthreads();   // K / V tiles are dead: the area becomes the partial slots; Ds / Pe / De are complete
+    stamp(2);
 
     // ---- phase 2: lockstep walk over the query tiles -------------------------------------------------------------
     char* slot = area + w * FB_SLOT;
@@ -578,6 +607,14 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
                 dp[g * 4 + e] = pv * (dp[g * 4 + e] - dqa[e]);      // dS  (in place)
             }
         }
+        // dS -> LDS as [key][q] (this lane: its key, 4 x 4 consecutive q), read back with lane <-> q, k <-> key
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bf16x4 v4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v4[e] = (bf16_t)dp[g * 4 + e];
+            *(__attribute__((address_space(3))) bf16x4*)(slot3 + st_w + (((2 * g + hi) ^ st_sw) << 3)) = v4;
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const bf16x8 pb = pack_b(s, ks), db = pack_b(dp, ks);
@@ -586,14 +623,6 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
                 dv[dt] = MFMA(frag_tr(Dt, qt * 32 + ks * 16, fo, dt), pb, dv[dt]);
                 dk[dt] = MFMA(frag_tr(Qt, qt * 32 + ks * 16, fo, dt), db, dk[dt]);
             }
-        }
-        // dS -> LDS as [key][q] (this lane: its key, 4 x 4 consecutive q), read back with lane <-> q, k <-> key
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            bf16x4 v4;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v4[e] = (bf16_t)dp[g * 4 + e];
-            *(__attribute__((address_space(3))) bf16x4*)(slot3 + st_w + (((2 * g + hi) ^ st_sw) << 3)) = v4;
         }
         bf16x8 dsq[2];
 #pragma unroll
@@ -639,6 +668,7 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
         __syncthreads();
     }
 
+    stamp(3);
     // ---- phase 3: dK, dV of this wave's keys; the odd key ------------------------------------------------------
     {
         const int key = w * 32 + l31;
@@ -661,11 +691,12 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
     if (w == 0) {
         float ak = 0.0f, av = 0.0f;
 #pragma unroll
-        for (int ww = 0; ww < NK; ++ww) { ak += KVe[(ww * 2 + 0) * 64 + lane]; av += KVe[(ww * 2 + 1) * 64 + lane]; }
+        for (int ww = 0; ww <= NK; ++ww) { ak += KVe[(ww * 2 + 0) * 64 + lane]; av += KVe[(ww * 2 + 1) * 64 + lane]; }
         bf16_t* krow = dqkv + ((long)b * S + SE) * lddq + W + h * 64;
         krow[lane] = (bf16_t)(ak * scale);
         krow[W + lane] = (bf16_t)av;
     }
+    stamp(4);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -723,10 +754,13 @@ int attn_bwd_bf16(const bf16_t* qkv, long ldqkv, const bf16_t* o, long ldo, cons
     if (fused < 0) { const char* e = getenv("RVLM_ATTN_FUSED"); fused = e ? atoi(e) : 1; }
     if (fused && g_use_tr && S == 257) {   // one kernel: dQ, dK, dV (see attn_bwd_fused_kernel)
         constexpr int NK = 8, SpF = (NK + 1) * 32;
-        const size_t lds_f = (size_t)SpF * 256 + (size_t)SpF * 256 + (4 * SpF + 64 + NK * 128) * sizeof(float);
+        const size_t lds_f = (size_t)SpF * 256 + (size_t)SpF * 256 + (4 * SpF + 64 + (NK + 1) * 128) * sizeof(float);
         if ((rc = set_lds(attn_bwd_fused_kernel<NK>, lds_f))) return rc;
+        static int trace = -1, desync = -1;
+        if (trace < 0) { const char* e = getenv("RVLM_ATTN_TRACE"); trace = e ? atoi(e) : 0; }
+        if (desync < 0) { const char* e = getenv("RVLM_ATTN_DESYNC"); desync = e ? atoi(e) : 5; }
         hipLaunchKernelGGL((attn_bwd_fused_kernel<NK>), dim3(B * H), dim3(NK * 64), lds_f, s, qkv, ldqkv, o, ldo, d_o, lddo,
-                           lse, dqkv, lddqkv, H, S, W, scale, sl2);
+                           lse, dqkv, lddqkv, H, S, W, scale, sl2, trace ? (unsigned long long*)dsum_scratch : nullptr, desync);
         RVLM_CHECK_LAUNCH();
         return RVLM_OK;
     }

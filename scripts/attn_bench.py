@@ -11,7 +11,7 @@ g = torch.Generator(device=dev).manual_seed(0)
 qkv = torch.randn(B * S, 3 * W, generator=g, device=dev).bfloat16()
 d_o = torch.randn(B * S, W, generator=g, device=dev).bfloat16()
 o = torch.zeros(B * S, W, dtype=torch.bfloat16, device=dev)
-lse = torch.zeros(B * H * Sp, device=dev); dsum = torch.zeros(B * H * Sp, device=dev)
+lse = torch.zeros(B * H * Sp, device=dev); dsum = torch.zeros(max(B * H * Sp, B * H * 16), device=dev)
 dqkv = torch.zeros_like(qkv)
 def fwd(): L.check(lib.rvlm_k_attn_fwd_bf16(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), B, H, S, L.stream_ptr()))
 def bwd(): L.check(lib.rvlm_k_attn_bwd_bf16(qkv.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), dsum.data_ptr(), dqkv.data_ptr(), B, H, S, L.stream_ptr()))
@@ -28,3 +28,11 @@ for name, fn, flops in (("fwd", fwd, 4.0 * B * H * S * S * 64), ("bwd", bwd, 8.0
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 20
     print(f"S={S} attn {name}: {ms*1e3:8.1f} us  {flops/ms/1e9:7.1f} TFLOP/s (algorithmic)", flush=True)
+
+if os.environ.get("RVLM_ATTN_TRACE") and S == 257:
+    t = dsum.view(torch.int64)[: B * H * 8].view(B * H, 8).cpu().double()
+    names = ["stage Q,dO,K,V", "fragments + D + odd key", "9 query-tile steps", "dK/dV stores"]
+    tot = (t[:, 4] - t[:, 0]).mean()
+    for i, nm in enumerate(names):
+        print(f"   fused bwd phase {nm:26s}: {float((t[:, i + 1] - t[:, i]).mean()):9.0f} cycles ({100 * float((t[:, i + 1] - t[:, i]).mean() / tot):4.1f} %)")
+    print(f"   per workgroup: {float(tot):.0f} cycles")
