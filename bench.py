@@ -54,7 +54,7 @@ def cpu_baseline(iterations_full=10):
     from oracle import vit_ref as V
     from oracle.attacks_ref import pgd_ref
     from oracle.losses_ref import ComputeLossWrapperRef
-    # 32 threads: the small-M GEMMs of a 2-image batch do not scale past that (256 threads on the
+    # 32 threads: the small-M GEMMs of these batches do not scale past that (256 threads on the
     # GPU box's 2x64-core host was 50x SLOWER than 32: oversubscribed OpenMP teams on 514-row matmuls)
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
@@ -62,21 +62,28 @@ def cpu_baseline(iterations_full=10):
     w = V.init_weights(cfg, seed=0)
     model = V.ClipVisionModelRef(cfg, w).eval()
     g = torch.Generator().manual_seed(0)
-    B, iters = 2, 1
-    x = torch.rand(B, 3, 224, 224, generator=g)
     eps = 4 / 255
-    d0 = torch.zeros_like(x).uniform_(-eps, eps, generator=g)
-    with torch.no_grad():
-        e0 = model(x, False)
-    wrap = ComputeLossWrapperRef(e0, None, "mean", "l2", 100.)
-    t0 = time.time()
-    pgd_ref(model, wrap, x, None, "linf", eps, iters, 1 / 255, False, perturbation=d0, mode="max")
-    dt = time.time() - t0
+
+    def sample(B, iters):
+        x = torch.rand(B, 3, 224, 224, generator=g)
+        d0 = torch.zeros_like(x).uniform_(-eps, eps, generator=g)
+        with torch.no_grad():
+            e0 = model(x, False)
+        wrap = ComputeLossWrapperRef(e0, None, "mean", "l2", 100.)
+        t0 = time.time()
+        pgd_ref(model, wrap, x, None, "linf", eps, iters, 1 / 255, False, perturbation=d0, mode="max")
+        return time.time() - t0
+
+    sample(2, 1)                       # untimed: thread pool / allocator warm-up
+    probe = sample(2, 1)               # sizes the timed sample to ~15 s of CPU work
+    B = 16
+    iters = int(max(1, min(iterations_full, round(15.0 / max(probe * B / 2, 1e-3)))))
+    dt = sample(B, iters)
     per_call_full = dt * iterations_full / iters
     return {"value": B / per_call_full, "unit": "adversarial images/sec", "cores": cores, "kind": "port",
             "sample": f"oracle pgd_ref (torch {torch.__version__} CPU fp32, {cores} threads): ViT-L/14, batch {B}, "
-                      f"{iters} of {iterations_full} PGD iterations timed ({dt:.1f} s) and scaled x{iterations_full // iters}; "
-                      f"host has {os.cpu_count()} hardware threads"}
+                      f"{iters} of {iterations_full} PGD iterations timed ({dt:.1f} s) after an untimed warm-up, scaled "
+                      f"x{iterations_full / iters:.2g}; host has {os.cpu_count()} hardware threads"}
 
 
 def bench_train(args, R, cfg, sd, dev, dist, world, rank):

@@ -503,16 +503,24 @@ static int backward_impl(rvlm_vit* h, const float* d_emb, int B, float* grad_x, 
 
 // ---- weight gradients ------------------------------------------------------------------------------
 // dW[N,K] (+)= dY[M,N]^T @ X[M,K]
+// dbias != null: dbias[N] (+)= column sums of dY as well (fused into the operand transpose where that exists)
 template <typename T>
 static int wgrad(rvlm_vit* h, hipStream_t s, const void* dY, long lddy, const void* X, long ldx, int M, int N, int K,
-                 float* dW, long lddw, int accumulate);
+                 float* dW, long lddw, int accumulate, float* dbias = nullptr);
 template <>
 int wgrad<bf16_t>(rvlm_vit* h, hipStream_t s, const void* dY, long lddy, const void* X, long ldx, int M, int N,
-                  int K, float* dW, long lddw, int accumulate) {
-    // contraction over the token dimension: both operands are transposed so that it is the contiguous
-    // (MFMA k) dimension, zero-padded to a multiple of 64, then the NT MFMA GEMM runs as usual
+                  int K, float* dW, long lddw, int accumulate, float* dbias) {
+    // contraction over the token dimension: both operands are transposed so that it is the contiguous (MFMA k)
+    // dimension.  Encoder shapes: token chunks [splits][.][Kc] + one batched launch of the persistent kernel.
+    int rc, splits = 0, Kc = 0;
+    if (wgrad_split_plan(M, N, K, &splits, &Kc) && (long)splits * Kc <= h->Mpt) {
+        if ((rc = transpose_split((const bf16_t*)dY, lddy, M, N, (bf16_t*)h->tA, Kc, splits, dbias, accumulate, s))) return rc;
+        if ((rc = transpose_split((const bf16_t*)X, ldx, M, K, (bf16_t*)h->tB, Kc, splits, nullptr, 0, s))) return rc;
+        return gemm_bf16_wgrad_split((const bf16_t*)h->tA, (const bf16_t*)h->tB, splits, Kc, N, K, dW, lddw, accumulate, s);
+    }
+    // other shapes (conv1: K = 3*P*P): whole-K transposes zero-padded to a multiple of 64, NT GEMM as usual
+    if (dbias && (rc = colsum<bf16_t>((const bf16_t*)dY, lddy, M, N, dbias, accumulate, s))) return rc;
     const int Mk = (int)round_up(M, 64);
-    int rc;
     if ((rc = transpose_pad<bf16_t>((const bf16_t*)dY, lddy, M, N, (bf16_t*)h->tA, h->Mpt, Mk, s))) return rc;
     if ((rc = transpose_pad<bf16_t>((const bf16_t*)X, ldx, M, K, (bf16_t*)h->tB, h->Mpt, Mk, s))) return rc;
     GemmBf16 g;
@@ -524,7 +532,9 @@ int wgrad<bf16_t>(rvlm_vit* h, hipStream_t s, const void* dY, long lddy, const v
 }
 template <>
 int wgrad<float>(rvlm_vit*, hipStream_t s, const void* dY, long lddy, const void* X, long ldx, int M, int N, int K,
-                 float* dW, long lddw, int accumulate) {
+                 float* dW, long lddw, int accumulate, float* dbias) {
+    int rc;
+    if (dbias && (rc = colsum<float>((const float*)dY, lddy, M, N, dbias, accumulate, s))) return rc;
     GemmF32 g;
     g.A = (const float*)dY; g.sam = 1; g.sak = lddy;      // (m_out = n, k = token)
     g.B = (const float*)X; g.sbn = 1; g.sbk = ldx;        // (n_out = k, k = token)
@@ -577,13 +587,13 @@ static int backward_params_impl(rvlm_vit* h, const float* d_emb, int B, const rv
         Layer& y = h->layers[l];
         const rvlm_vit_block_weights& gb = gw->blocks_host[l];
         // fc2 (c_proj): dY = d(residual), X = act(fc1)
-        if ((rc = wgrad<T>(h, s, dres_A, W, h->g_act_l[l], 4 * W, M, W, 4 * W, G(gb.mlp_c_proj_weight), 4 * W, acc))) return rc;
-        if ((rc = colsum<T>((const T*)dres_A, W, M, W, G(gb.mlp_c_proj_bias), acc, s))) return rc;
+        if ((rc = wgrad<T>(h, s, dres_A, W, h->g_act_l[l], 4 * W, M, W, 4 * W, G(gb.mlp_c_proj_weight), 4 * W, acc,
+                           G(gb.mlp_c_proj_bias)))) return rc;
         if ((rc = linear_dgrad<T>(h, s, dres_A, W, M, W, 4 * W, y.w_proj, 4 * W, y.w_proj_t, EPI_BF16_DACT, h->dh,
                                   4 * W, h->h_pre[l]))) return rc;
         // fc1 (c_fc)
-        if ((rc = wgrad<T>(h, s, h->dh, 4 * W, h->ln2_out[l], W, M, 4 * W, W, G(gb.mlp_c_fc_weight), W, acc))) return rc;
-        if ((rc = colsum<T>((const T*)h->dh, 4 * W, M, 4 * W, G(gb.mlp_c_fc_bias), acc, s))) return rc;
+        if ((rc = wgrad<T>(h, s, h->dh, 4 * W, h->ln2_out[l], W, M, 4 * W, W, G(gb.mlp_c_fc_weight), W, acc,
+                           G(gb.mlp_c_fc_bias)))) return rc;
         if ((rc = linear_dgrad<T>(h, s, h->dh, 4 * W, M, 4 * W, W, y.w_fc, W, y.w_fc_t, EPI_BF16, h->d_ln, W, nullptr)))
             return rc;
         if ((rc = ln_param_grad<T>((const T*)h->d_ln, W, h->xs[2 * l + 1], W, h->mean_at(2 + 2 * l),
@@ -592,13 +602,13 @@ static int backward_params_impl(rvlm_vit* h, const float* d_emb, int B, const rv
                                       h->rstd_at(2 + 2 * l), h->dres, W, LP ? (T*)h->dres_lp : nullptr, W, 1, M, W, s)))
             return rc;
         // attention out-proj
-        if ((rc = wgrad<T>(h, s, dres_A, W, h->attn_o[l], W, M, W, W, G(gb.attn_out_proj_weight), W, acc))) return rc;
-        if ((rc = colsum<T>((const T*)dres_A, W, M, W, G(gb.attn_out_proj_bias), acc, s))) return rc;
+        if ((rc = wgrad<T>(h, s, dres_A, W, h->attn_o[l], W, M, W, W, G(gb.attn_out_proj_weight), W, acc,
+                           G(gb.attn_out_proj_bias)))) return rc;
         if ((rc = linear_dgrad<T>(h, s, dres_A, W, M, W, W, y.w_out, W, y.w_out_t, EPI_BF16, h->d_o, W, nullptr))) return rc;
         if ((rc = attention_bwd<T>(h, s, h->qkv[l], h->attn_o[l], h->d_o, h->lse[l], h->dqkv, B))) return rc;
         // qkv in-proj
-        if ((rc = wgrad<T>(h, s, h->dqkv, 3 * W, h->ln1_out[l], W, M, 3 * W, W, G(gb.attn_in_proj_weight), W, acc))) return rc;
-        if ((rc = colsum<T>((const T*)h->dqkv, 3 * W, M, 3 * W, G(gb.attn_in_proj_bias), acc, s))) return rc;
+        if ((rc = wgrad<T>(h, s, h->dqkv, 3 * W, h->ln1_out[l], W, M, 3 * W, W, G(gb.attn_in_proj_weight), W, acc,
+                           G(gb.attn_in_proj_bias)))) return rc;
         if ((rc = linear_dgrad<T>(h, s, h->dqkv, 3 * W, M, 3 * W, W, y.w_in, W, y.w_in_t, EPI_BF16, h->d_ln, W, nullptr)))
             return rc;
         if ((rc = ln_param_grad<T>((const T*)h->d_ln, W, h->xs[2 * l], W, h->mean_at(1 + 2 * l), h->rstd_at(1 + 2 * l),
@@ -734,7 +744,7 @@ extern "C" int rvlm_vit_create(const rvlm_vit_config* cfg, const rvlm_vit_weight
         ALLOC_OR_DIE(h->tokens, Mp * W * 4);
         ALLOC_OR_DIE(h->dtok, Mp * W * 4);
         if (h->bf16) {
-            h->Mpt = (long)Mp;
+            h->Mpt = (long)Mp + 16 * 128;   // token chunks of the split-K weight gradient: up to 16 x Kc
             const size_t rows = (size_t)std::max(4 * W, h->Kpad);
             ALLOC_OR_DIE(h->tA, rows * h->Mpt * 2);
             ALLOC_OR_DIE(h->tB, rows * h->Mpt * 2);
@@ -748,7 +758,8 @@ extern "C" int rvlm_vit_create(const rvlm_vit_config* cfg, const rvlm_vit_weight
         ALLOC_OR_DIE(h->splitk_scratch, sk);
         gemm_set_splitk_scratch(h->splitk_scratch, sk);
         if (cfg->trainable > 0) {
-            const size_t rf = (size_t)2 * 128 * 4 * W;      // [2][RED_NCH][4W] partial column sums
+            // partial column sums: [2][RED_NCH][4W] (LayerNorm affine) or one row per 64-token tile of a transpose
+            const size_t rf = std::max((size_t)2 * 128 * 4 * W, (size_t)((Mp + 16 * 128) / 64) * 4 * W);
             float* rs = nullptr;
             ALLOC_OR_DIE(rs, rf * sizeof(float));
             set_reduce_scratch(rs, rf);

@@ -249,6 +249,49 @@ static int gemm_bf16_nt_128(const GemmBf16& p, hipStream_t s) {
     return RVLM_OK;
 }
 
+// Split-K weight gradient on the persistent kernel.  dW[N,K] (+)= sum_b tA_b tB_b^T with tA = [splits][N][Kc] and
+// tB = [splits][K][Kc] (token chunks of the transposed operands, written by transpose_split): one batched launch of
+// splits * (N/256) * (K/256) work items, fp32 slabs [splits][N][K], then the deterministic slab reduce.
+// Plan: enough splits to give every CU one work item (the W x W out-projection gradient has 16 output tiles).
+int wgrad_split_plan(int M, int N, int K, int* splits, int* Kc) {
+    if (N % 256 != 0 || K % 256 != 0 || M < 256) return 0;
+    const int tiles = (N / 256) * (K / 256), nk128 = cdiv(M, 128);
+    int sp = std::max(1, std::min(16, 256 / tiles));
+    sp = std::min(sp, nk128);
+    if (sp > 1 && (size_t)sp * N * K * sizeof(float) > g_splitk_bytes) return 0;
+    *splits = sp;
+    *Kc = cdiv(nk128, sp) * 128;
+    return 1;
+}
+int gemm_bf16_wgrad_split(const bf16_t* tA, const bf16_t* tB, int splits, int Kc, int N, int K, float* dW, long lddw,
+                          int accumulate, hipStream_t s) {
+    GemmBf16 g;
+    g.A = tA; g.lda = Kc; g.Bw = tB; g.ldb = Kc;
+    g.M = splits * N; g.N = K; g.K = Kc;
+    g.batch_m_rows = N;
+    if (splits == 1) {
+        g.epi = accumulate ? EPI_F32_RESID : EPI_F32; g.residual = accumulate ? dW : nullptr;
+        g.out = dW; g.ldo = lddw;
+    } else {
+        g.epi = EPI_F32; g.out = g_splitk_scratch; g.ldo = K;
+    }
+    int done = 0;
+    int rc = gemm_bf16_nt_256p(g, &done, s);
+    if (rc) return rc;
+    if (done != g.M) return fail(RVLM_ERR_UNSUPPORTED, "gemm_bf16_wgrad_split: shape not covered by the persistent kernel");
+    if (splits > 1) {
+        GemmBf16 r;
+        r.M = N; r.N = K; r.out = dW; r.ldo = lddw; r.residual = accumulate ? dW : nullptr;
+        const int rb = cdiv((long)N * (K / 4), 256);
+        if (accumulate)
+            hipLaunchKernelGGL((splitk_reduce_kernel<EPI_F32_RESID>), dim3(rb), dim3(256), 0, s, g_splitk_scratch, splits, r);
+        else
+            hipLaunchKernelGGL((splitk_reduce_kernel<EPI_F32>), dim3(rb), dim3(256), 0, s, g_splitk_scratch, splits, r);
+        RVLM_CHECK_LAUNCH();
+    }
+    return RVLM_OK;
+}
+
 int gemm_bf16_nt(const GemmBf16& p, hipStream_t s) {
     if (!p.A || !p.Bw || !p.out || p.M <= 0 || p.N <= 0 || p.K <= 0)
         return fail(RVLM_ERR_ARG, "gemm_bf16_nt: bad arguments");

@@ -43,7 +43,11 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n) {
     // buffer descriptors (wave-uniform, built from kernel arguments only): every global access below is
     // descriptor + 32-bit lane offset (VGPR, constant for the whole kernel) + 32-bit scalar offset
     const auto a_rs = make_rsrc(p.A, (unsigned)((p.M - 1) * lda + p.K) * 2u);
-    const auto b_rs = make_rsrc(p.Bw, (unsigned)((p.N - 1) * ldb + p.K) * 2u);
+    // batched form (batch_m_rows > 0, the split-K weight-gradient GEMM): rows [b*batch_m_rows, (b+1)*batch_m_rows) of A
+    // meet rows [b*N, (b+1)*N) of Bw; the output keeps A's row index (a stack of per-batch [batch_m_rows, N] slabs)
+    const int nbatch = p.batch_m_rows > 0 ? p.M / p.batch_m_rows : 1;
+    const auto b_rs = make_rsrc(p.Bw, (unsigned)((nbatch * p.N - 1) * ldb + p.K) * 2u);
+    auto b_row0 = [&](int m0, int n0) { return p.batch_m_rows > 0 ? n0 + (m0 / p.batch_m_rows) * p.N : n0; };
     const unsigned out_elems = (unsigned)((p.M - 1) * ldo + p.N);
     const auto o_rs = make_rsrc(p.out, out_elems * (OUT_F32 ? 4u : 2u));
     const auto pre_rs = make_rsrc(EPI == EPI_BF16_ACT ? (const void*)p.out_pre : (const void*)p.out, out_elems * 2u);
@@ -82,7 +86,7 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n) {
         int m0, n0;
         tile_origin(blockIdx.x, m0, n0);
         a_soff = (m0 + w * 32) * lda * 2;
-        b_soff = (n0 + w * 32) * ldb * 2;
+        b_soff = (b_row0(m0, n0) + w * 32) * ldb * 2;
     }
     // experiment (ABL & 8): the same operand stream as plain buffer_load_dwordx4 into registers (folded into a sink one
     // K-step later) - compares the VGPR return path of the texture unit with the LDS-DMA path
@@ -144,7 +148,7 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n) {
             if (++b_ti < ntw) {
                 int m0, n0;
                 tile_origin(blockIdx.x + b_ti * gridDim.x, m0, n0);
-                b_soff = (n0 + w * 32) * ldb * 2;
+                b_soff = (b_row0(m0, n0) + w * 32) * ldb * 2;
             }
         }
         return true;
@@ -478,6 +482,11 @@ int gemm_bf16_nt_256p(const GemmBf16& p, int* rows_done, hipStream_t s) {
     // buffer descriptors address with 32-bit offsets
     const long lim = 1L << 31;
     if ((long)p.M * p.lda * 2 >= lim || (long)p.N * p.ldb * 2 >= lim || (long)p.M * p.ldo * 4 >= lim) return RVLM_OK;
+    if (p.batch_m_rows > 0) {
+        if (p.batch_m_rows % P_M != 0 || p.M % p.batch_m_rows != 0)
+            return fail(RVLM_ERR_ARG, "gemm_bf16_nt_256p: batch_m_rows must be a multiple of 256 dividing M");
+        if ((long)(p.M / p.batch_m_rows) * p.N * p.ldb * 2 >= lim) return RVLM_OK;
+    }
     GemmBf16 q = p;
     const int tiles_m = p.M / P_M, tiles_n = p.N / P_N;
     q.M = tiles_m * P_M;

@@ -7,6 +7,11 @@
 
 namespace rvlm {
 
+constexpr int RED_NCH = 128;
+static float* g_red_scratch = nullptr;     // partial column sums, provided by the engine
+static size_t g_red_floats = 0;
+void set_reduce_scratch(float* p, size_t floats) { g_red_scratch = p; g_red_floats = floats; }
+
 // out[c, r] = in[r, c] for r < R, zero for R <= r < Rp (the GEMM's K padding).  64x64 tiles via LDS.
 template <typename T>
 __global__ void __launch_bounds__(256)
@@ -35,15 +40,95 @@ int transpose_pad(const T* in, long ldi, int R, int C, T* out, long ldo, int Rp,
 }
 template int transpose_pad<bf16_t>(const bf16_t*, long, int, int, bf16_t*, long, int, hipStream_t);
 
+// Split-K layout for the persistent weight-gradient GEMM: out[((r / Kc) * C + c) * Kc + r % Kc] = in[r, c] for r < R,
+// zero for R <= r < Rp (Rp = splits * Kc).  C % 64 == 0, Kc % 64 == 0 (a 64-row tile never straddles two chunks).
+// Every global access is 16 B per lane, 128 B per row (the 2-byte-per-lane version above reaches 2.4 TB/s).
+// colpart != null: also emits the column sums of the tile's 64 rows, colpart[blockIdx.y][c] (bias gradient).
+__global__ void __launch_bounds__(256)
+transpose_split_kernel(const bf16_t* __restrict__ in, long ldi, int R, int C, bf16_t* __restrict__ out, int Kc,
+                       float* __restrict__ colpart) {
+    __shared__ unsigned tile[64 * 33];   // 64 rows x 64 bf16, row pitch 33 dwords
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int row = pass * 32 + wv * 8 + (lane >> 3), r = r0 + row;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (r < R) v = *(const uint4*)(in + (long)r * ldi + c0 + (lane & 7) * 8);
+        unsigned* d = tile + row * 33 + (lane & 7) * 4;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+    const unsigned short* t16 = (const unsigned short*)tile;
+    const int split = r0 / Kc;
+    const long obase = (long)split * C * Kc + (r0 - split * Kc);
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int c = pass * 32 + wv * 8 + (lane >> 3), rc = (lane & 7) * 8;
+        unsigned short e[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) e[i] = t16[(rc + i) * 66 + c];
+        uint4 o;
+        o.x = e[0] | ((unsigned)e[1] << 16); o.y = e[2] | ((unsigned)e[3] << 16);
+        o.z = e[4] | ((unsigned)e[5] << 16); o.w = e[6] | ((unsigned)e[7] << 16);
+        *(uint4*)(out + obase + (long)(c0 + c) * Kc + rc) = o;
+        if (colpart) {
+            float sum = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sum += __uint_as_float((unsigned)e[i] << 16);
+            sum += __shfl_xor(sum, 1);
+            sum += __shfl_xor(sum, 2);
+            sum += __shfl_xor(sum, 4);
+            if ((lane & 7) == 0) colpart[(long)blockIdx.y * C + c0 + c] = sum;
+        }
+    }
+}
+// partial column sums -> out (+)=: 16 columns x 16 partial lanes per workgroup
+__global__ void __launch_bounds__(256)
+reduce_partials16_kernel(const float* __restrict__ partial, int nch, int C, float* __restrict__ out, int accumulate) {
+    __shared__ float red[16][17];
+    const int cl = threadIdx.x & 15, kl = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
+    float a0 = 0.0f, a1 = 0.0f;
+    if (c < C) {
+        int k = kl;
+        for (; k + 16 < nch; k += 32) {
+            a0 += partial[(long)k * C + c];
+            a1 += partial[(long)(k + 16) * C + c];
+        }
+        if (k < nch) a0 += partial[(long)k * C + c];
+    }
+    red[kl][cl] = a0 + a1;
+    __syncthreads();
+    if (kl == 0 && c < C) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc += red[i][cl];
+        out[c] = (accumulate ? out[c] : 0.0f) + acc;
+    }
+}
+// transposes one wgrad operand into the split layout; dbias != null: dbias[c] (+)= sum_r in[r, c] on the way
+int transpose_split(const bf16_t* in, long ldi, int R, int C, bf16_t* out, int Kc, int splits, float* dbias,
+                    int accumulate, hipStream_t s) {
+    if (C % 64 != 0 || Kc % 64 != 0 || ldi % 8 != 0) return fail(RVLM_ERR_ARG, "transpose_split: C, Kc % 64, ldi % 8");
+    const int rt = splits * Kc / 64;
+    float* part = nullptr;
+    if (dbias) {
+        if (!g_red_scratch || (size_t)rt * C > g_red_floats) return fail(RVLM_ERR_STATE, "transpose_split: no reduce scratch");
+        part = g_red_scratch;
+    }
+    hipLaunchKernelGGL(transpose_split_kernel, dim3(C / 64, rt), dim3(256), 0, s, in, ldi, R, C, out, Kc, part);
+    RVLM_CHECK_LAUNCH();
+    if (dbias) {
+        hipLaunchKernelGGL(reduce_partials16_kernel, dim3(cdiv(C, 16)), dim3(256), 0, s, part, rt, C, dbias, accumulate);
+        RVLM_CHECK_LAUNCH();
+    }
+    return RVLM_OK;
+}
+
 // ---- column reductions over the token dimension (bias and LayerNorm-affine gradients) ---------------
 // Two deterministic passes: grid (C/64, NCH) blocks each reduce a 64-column x (R/NCH)-row slab into
 // partial[chunk][c]; a second tiny kernel sums the NCH partials.  (A single pass with C/64 workgroups
 // left 94 % of the chip idle: 3.1 ms per call at M = 32 896.)
-constexpr int RED_NCH = 128;
-static float* g_red_scratch = nullptr;     // [2][RED_NCH][cols] floats, provided by the engine
-static size_t g_red_floats = 0;
-void set_reduce_scratch(float* p, size_t floats) { g_red_scratch = p; g_red_floats = floats; }
-
 template <typename T>
 __global__ void __launch_bounds__(256)
 colsum_partial_kernel(const T* __restrict__ in, long ld, int R, int C, float* __restrict__ partial) {
@@ -87,22 +172,13 @@ ln_param_partial_kernel(const T* __restrict__ dy, long lddy, const float* __rest
         pb[(long)blockIdx.y * C + c] = (rb[0][t] + rb[1][t]) + (rb[2][t] + rb[3][t]);
     }
 }
-__global__ void __launch_bounds__(256)
-reduce_partials_kernel(const float* __restrict__ partial, int nch, int C, float* __restrict__ out, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float acc = 0.0f;
-    for (int k = 0; k < nch; ++k) acc += partial[(long)k * C + c];
-    out[c] = (accumulate ? out[c] : 0.0f) + acc;
-}
-
 template <typename T>
 int colsum(const T* in, long ld, int R, int C, float* out, int accumulate, hipStream_t s) {
     const int nch = R >= 4096 ? RED_NCH : (R >= 256 ? 16 : 1);
     if (!g_red_scratch || (size_t)nch * C > g_red_floats) return fail(RVLM_ERR_STATE, "colsum: no reduce scratch");
     hipLaunchKernelGGL((colsum_partial_kernel<T>), dim3(cdiv(C, 64), nch), dim3(256), 0, s, in, ld, R, C, g_red_scratch);
     RVLM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, g_red_scratch, nch, C, out, accumulate);
+    hipLaunchKernelGGL(reduce_partials16_kernel, dim3(cdiv(C, 16)), dim3(256), 0, s, g_red_scratch, nch, C, out, accumulate);
     RVLM_CHECK_LAUNCH();
     return RVLM_OK;
 }
@@ -120,9 +196,9 @@ int ln_param_grad(const T* dy, long lddy, const float* x, long ldx, const float*
     hipLaunchKernelGGL((ln_param_partial_kernel<T>), dim3(cdiv(C, 64), nch), dim3(256), 0, s, dy, lddy, x, ldx, mean,
                        rstd, R, C, pg, pb);
     RVLM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, pg, nch, C, dgamma, accumulate);
+    hipLaunchKernelGGL(reduce_partials16_kernel, dim3(cdiv(C, 16)), dim3(256), 0, s, pg, nch, C, dgamma, accumulate);
     RVLM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, pb, nch, C, dbeta, accumulate);
+    hipLaunchKernelGGL(reduce_partials16_kernel, dim3(cdiv(C, 16)), dim3(256), 0, s, pb, nch, C, dbeta, accumulate);
     RVLM_CHECK_LAUNCH();
     return RVLM_OK;
 }
