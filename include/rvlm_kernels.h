@@ -48,6 +48,13 @@ int rvlm_k_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma
  * (>= 2048 elements, copied to LDS) at per-lane byte offsets `offs[64]`. */
 int rvlm_k_probe_tr16(const uint16_t* src, const int32_t* offs, uint16_t* out, rvlm_stream_t stream);
 
+/* Weight gradient of one linear layer on the split-K path of the training step (train/adversarial_training_clip.py:
+ * 356-364, loss.backward()): dW[N,K] (+)= dY[M,N]^T X[M,K] (bf16 operands, fp32 result), dbias[N] (+)= column sums of
+ * dY (NULL: skipped).  N, K multiples of 256, M >= 256.  `work`: device scratch of rvlm_k_wgrad_work_bytes(M, N, K). */
+size_t rvlm_k_wgrad_work_bytes(int M, int N, int K);
+int rvlm_k_wgrad_bf16(const uint16_t* dY, long lddy, const uint16_t* X, long ldx, int M, int N, int K, float* dW,
+                      long lddw, int accumulate, float* dbias, void* work, size_t work_bytes, rvlm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

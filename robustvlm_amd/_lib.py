@@ -139,6 +139,9 @@ _SIGS = {
     "rvlm_k_layernorm_bwd_f32": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int,
                                            C.c_int, C.c_int, c_stream]),
     "rvlm_k_probe_tr16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_stream]),
+    "rvlm_k_wgrad_work_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "rvlm_k_wgrad_bf16": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, c_f32p,
+                                    C.c_long, C.c_int, c_f32p, C.c_void_p, C.c_size_t, c_stream]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGS)

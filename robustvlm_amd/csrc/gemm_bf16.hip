@@ -184,6 +184,7 @@ splitk_reduce_kernel(const float* __restrict__ slabs, int splitk, GemmBf16 p) {
 static float* g_splitk_scratch = nullptr;
 static size_t g_splitk_bytes = 0;
 void gemm_set_splitk_scratch(float* ptr, size_t bytes) { g_splitk_scratch = ptr; g_splitk_bytes = bytes; }
+void gemm_get_splitk_scratch(float** ptr, size_t* bytes) { *ptr = g_splitk_scratch; *bytes = g_splitk_bytes; }
 
 int gemm_bf16_nt_256(const GemmBf16& p, int* rows_done, hipStream_t s);
 int gemm_bf16_nt_256p(const GemmBf16& p, int* rows_done, hipStream_t s);

@@ -9,6 +9,9 @@ void gemm_set_variant(int v);
 void gemm_set_trace(unsigned long long* ptr);
 void gemm_set_ablate(int v);
 void gemm_set_splitk_scratch(float* ptr, size_t bytes);
+void gemm_get_splitk_scratch(float** ptr, size_t* bytes);
+void set_reduce_scratch(float* p, size_t floats);
+void get_reduce_scratch(float** p, size_t* floats);
 int attn_occupancy(int S, int* out3);
 
 __global__ void probe_tr16_kernel(const bf16_t* __restrict__ src, const int32_t* __restrict__ offs,
@@ -78,3 +81,35 @@ extern "C" int rvlm_k_probe_tr16(const uint16_t* src, const int32_t* offs, uint1
     return RVLM_OK;
 }
 extern "C" int rvlm_k_attn_occupancy(int S, int* out3) { return attn_occupancy(S, out3); }
+
+// dW[N,K] (+)= dY[M,N]^T X[M,K], dbias[N] (+)= column sums of dY, on the split-K path of the training step.  `work` is a
+// caller-provided device buffer of rvlm_k_wgrad_work_bytes(M, N, K) bytes (token-chunk operands, fp32 slabs, partials).
+extern "C" size_t rvlm_k_wgrad_work_bytes(int M, int N, int K) {
+    const size_t Mpt = (size_t)round_up(M, 128) + 16 * 128;
+    return Mpt * (size_t)(N + K) * 2 + (Mpt / 64) * (size_t)N * 4 + (size_t)16 * N * K * 4 + 4096;
+}
+extern "C" int rvlm_k_wgrad_bf16(const uint16_t* dY, long lddy, const uint16_t* X, long ldx, int M, int N, int K,
+                                 float* dW, long lddw, int accumulate, float* dbias, void* work, size_t work_bytes,
+                                 rvlm_stream_t stream) {
+    int splits = 0, Kc = 0;
+    float* old_sk; size_t old_skb; float* old_red; size_t old_redf;
+    gemm_get_splitk_scratch(&old_sk, &old_skb);
+    get_reduce_scratch(&old_red, &old_redf);
+    const size_t Mpt = (size_t)round_up(M, 128) + 16 * 128;
+    char* w = (char*)work;
+    bf16_t* tA = (bf16_t*)w; w += Mpt * N * 2;
+    bf16_t* tB = (bf16_t*)w; w += Mpt * K * 2;
+    float* red = (float*)w; const size_t redf = (Mpt / 64) * (size_t)N; w += redf * 4;
+    float* slab = (float*)w; const size_t slab_bytes = (size_t)16 * N * K * 4;
+    if ((size_t)(w - (char*)work) + slab_bytes > work_bytes) return fail(RVLM_ERR_ARG, "rvlm_k_wgrad_bf16: work buffer too small");
+    gemm_set_splitk_scratch(slab, slab_bytes);
+    set_reduce_scratch(red, redf);
+    int rc = RVLM_OK;
+    if (!wgrad_split_plan(M, N, K, &splits, &Kc)) rc = fail(RVLM_ERR_UNSUPPORTED, "rvlm_k_wgrad_bf16: N, K % 256, M >= 256");
+    if (!rc) rc = transpose_split((const bf16_t*)dY, lddy, M, N, tA, Kc, splits, dbias, accumulate, (hipStream_t)stream);
+    if (!rc) rc = transpose_split((const bf16_t*)X, ldx, M, K, tB, Kc, splits, nullptr, 0, (hipStream_t)stream);
+    if (!rc) rc = gemm_bf16_wgrad_split(tA, tB, splits, Kc, N, K, dW, lddw, accumulate, (hipStream_t)stream);
+    gemm_set_splitk_scratch(old_sk, old_skb);
+    set_reduce_scratch(old_red, old_redf);
+    return rc;
+}

@@ -11,6 +11,7 @@ constexpr int RED_NCH = 128;
 static float* g_red_scratch = nullptr;     // partial column sums, provided by the engine
 static size_t g_red_floats = 0;
 void set_reduce_scratch(float* p, size_t floats) { g_red_scratch = p; g_red_floats = floats; }
+void get_reduce_scratch(float** p, size_t* floats) { *p = g_red_scratch; *floats = g_red_floats; }
 
 // out[c, r] = in[r, c] for r < R, zero for R <= r < Rp (the GEMM's K padding).  64x64 tiles via LDS.
 template <typename T>

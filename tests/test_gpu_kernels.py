@@ -236,3 +236,39 @@ def test_gemm_bf16_splitk_remainder(K):
         assert rel_max(out.float(), acc * hp.double()) < 1.5e-2
     finally:
         lib().rvlm_k_gemm_set_variant(-1)
+
+
+@pytest.mark.parametrize("M,N,K", [(257 * 7, 256, 256), (257 * 24, 512, 256), (257 * 24, 256, 1024), (300, 768, 256),
+                                   (257 * 128, 1024, 1024)])
+def test_wgrad_split_vs_fp32(M, N, K):
+    """Split-K weight gradient of the training step (token-chunk transposes with the fused bias gradient + batched
+    persistent GEMM + slab reduce) against an fp64 matmul of the same bf16 operands; strided operands (column
+    slices of wider buffers, as dqkv / the MLP activations are) and accumulate on top."""
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    dYw = torch.randn(M, N + 64, generator=g, device=dev()).bfloat16()
+    Xw = torch.randn(M, K + 8, generator=g, device=dev()).bfloat16()
+    dY, X = dYw[:, :N], Xw[:, :K]
+    ref = dY.double().t() @ X.double()
+    refb = dY.double().sum(0)
+    nb = lib().rvlm_k_wgrad_work_bytes(M, N, K)
+    work = torch.empty(nb, dtype=torch.uint8, device=dev())
+    dW = torch.full((N, K), 7.0, device=dev())
+    db = torch.full((N,), 7.0, device=dev())
+    L.check(lib().rvlm_k_wgrad_bf16(dY.data_ptr(), dYw.stride(0), X.data_ptr(), Xw.stride(0), M, N, K, dW.data_ptr(), K,
+                                    0, db.data_ptr(), work.data_ptr(), nb, st()), "wgrad")
+    torch.cuda.synchronize()
+    assert rel_max(dW, ref) < 3e-5
+    assert rel_max(db, refb) < 3e-5
+    L.check(lib().rvlm_k_wgrad_bf16(dY.data_ptr(), dYw.stride(0), X.data_ptr(), Xw.stride(0), M, N, K, dW.data_ptr(), K,
+                                    1, db.data_ptr(), work.data_ptr(), nb, st()), "wgrad")
+    torch.cuda.synchronize()
+    assert rel_max(dW, 2 * ref) < 3e-5
+    assert rel_max(db, 2 * refb) < 3e-5
+    # deterministic: same bits on a second run
+    dW2 = torch.empty_like(dW)
+    dW3 = torch.empty_like(dW)
+    for o in (dW2, dW3):
+        L.check(lib().rvlm_k_wgrad_bf16(dY.data_ptr(), dYw.stride(0), X.data_ptr(), Xw.stride(0), M, N, K, o.data_ptr(),
+                                        K, 0, None, work.data_ptr(), nb, st()), "wgrad")
+    torch.cuda.synchronize()
+    assert torch.equal(dW2, dW3)
