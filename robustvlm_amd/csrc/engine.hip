@@ -54,7 +54,10 @@ struct rvlm_vit {
     float* dres;  void* dres_lp;  void* d_o;  void* dqkv;  void* dh;  void* d_ln;  void* d_patch;
     float* dA0;   float* dsum;   float *d_raw, *d_pooled;
     float *scores, *dscores;   // fp32 mode [B,H,S,S]
-    float* splitk_scratch;     // fp32 slabs for the split-K remainder GEMMs
+    float* splitk_scratch;     // fp32 slabs for the split-K remainder GEMMs (+ weight-gradient GEMMs when trainable)
+    size_t splitk_bytes = 0;
+    float* red_scratch = nullptr;   // partial column sums of the training step
+    size_t red_floats = 0;
     // training (cfg.trainable): inputs of every linear layer + embedding tokens + transpose scratch
     bool trainable = false;
     bool inference_only = false;
@@ -315,12 +318,20 @@ int attention_bwd<float>(rvlm_vit* h, hipStream_t s, const void* qkv_, const voi
 }
 
 // ---- forward -----------------------------------------------------------------------------------
+// The GEMM / reduction scratch pointers are process-wide: every entry that launches encoder kernels points them at
+// this handle's buffers first (several handles coexist - e.g. the frozen original encoder next to the trained one).
+static void bind_scratch(rvlm_vit* h) {
+    gemm_set_splitk_scratch(h->splitk_scratch, h->splitk_bytes);
+    set_reduce_scratch(h->red_scratch, h->red_floats);
+}
+
 template <typename T>
 static int forward_impl(rvlm_vit* h, const float* x, const float* delta, int B, int normalize, int save,
                         float* out_emb, hipStream_t s) {
     const int S = h->S, W = h->W, L = h->L, D = h->D, M = B * S, M0 = B * h->G * h->G;
     const double attn_flops = 4.0 * B * h->H * (double)S * S * 64;
     int rc;
+    bind_scratch(h);
     {
         PROF("patch_im2col", 0, (double)B * 3 * h->img * h->img * (delta ? 8 : 4) + (double)M0 * h->Kpad * sizeof(T));
         if ((rc = im2col_normalize<T>(x, delta, B, h->img, h->P, h->cfg.mean, h->cfg.std, (T*)h->A0, h->Kpad, h->Kpad, s))) return rc;
@@ -413,6 +424,7 @@ static int backward_impl(rvlm_vit* h, const float* d_emb, int B, float* grad_x, 
     const double attn_flops = 8.0 * B * h->H * (double)S * S * 64;
     constexpr bool LP = !std::is_same<T, float>::value;
     int rc;
+    bind_scratch(h);
     {
         PROF("head_bwd", 2.0 * B * W * D, 0);
         const float* d_raw = d_emb;
@@ -551,6 +563,7 @@ static int backward_params_impl(rvlm_vit* h, const float* d_emb, int B, const rv
     constexpr bool LP = !std::is_same<T, float>::value;
     auto G = [](const float* p) { return const_cast<float*>(p); };
     int rc;
+    bind_scratch(h);
     // ---- head ----
     const float* d_raw = d_emb;
     if (h->saved_norm) {
@@ -756,13 +769,12 @@ extern "C" int rvlm_vit_create(const rvlm_vit_config* cfg, const rvlm_vit_weight
         size_t sk = (size_t)8 * 256 * 4 * W * sizeof(float);
         if (cfg->trainable > 0) sk = std::max(sk, (size_t)16 * W * W * sizeof(float));
         ALLOC_OR_DIE(h->splitk_scratch, sk);
-        gemm_set_splitk_scratch(h->splitk_scratch, sk);
+        h->splitk_bytes = sk;
         if (cfg->trainable > 0) {
             // partial column sums: [2][RED_NCH][4W] (LayerNorm affine) or one row per 64-token tile of a transpose
             const size_t rf = std::max((size_t)2 * 128 * 4 * W, (size_t)((Mp + 16 * 128) / 64) * 4 * W);
-            float* rs = nullptr;
-            ALLOC_OR_DIE(rs, rf * sizeof(float));
-            set_reduce_scratch(rs, rf);
+            ALLOC_OR_DIE(h->red_scratch, rf * sizeof(float));
+            h->red_floats = rf;
         }
     }
     const size_t npix = (size_t)B * 3 * h->img * h->img;
