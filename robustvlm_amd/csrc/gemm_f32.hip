@@ -7,9 +7,10 @@
 namespace rvlm {
 
 constexpr int FT = 64;   // tile
-constexpr int FK = 16;   // k step
-
-template <bool A_KC, bool B_KC>
+// FK = k step: 16 in general; 64 for launches that cannot fill the chip (the head projection: 24 workgroups walking
+// K = 1024 were latency-bound at ~3 us per load -> LDS -> barrier round, 196 us per call; 4x fewer rounds with 4x the
+// loads in flight).  The fmaf chain over k is the same for every FK, so results do not depend on it.
+template <bool A_KC, bool B_KC, int FK>
 __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32 p) {
     __shared__ float As[FK][FT + 4];
     __shared__ float Bs[FK][FT + 4];
@@ -28,19 +29,19 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32 p) {
 
     for (int k0 = 0; k0 < p.K; k0 += FK) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < FK / 4; ++j) {
             int idx = threadIdx.x + j * 256;
             int m, k;
-            if (A_KC) { m = idx >> 4; k = idx & 15; } else { m = idx & 63; k = idx >> 6; }
+            if (A_KC) { m = idx / FK; k = idx % FK; } else { m = idx & 63; k = idx >> 6; }
             float v = 0.0f;
             if (m0 + m < p.M && k0 + k < p.K) v = A[(long)(m0 + m) * p.sam + (long)(k0 + k) * p.sak];
             As[k][m] = v;
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < FK / 4; ++j) {
             int idx = threadIdx.x + j * 256;
             int n, k;
-            if (B_KC) { n = idx >> 4; k = idx & 15; } else { n = idx & 63; k = idx >> 6; }
+            if (B_KC) { n = idx / FK; k = idx % FK; } else { n = idx & 63; k = idx >> 6; }
             float v = 0.0f;
             if (n0 + n < p.N && k0 + k < p.K) v = Bm[(long)(n0 + n) * p.sbn + (long)(k0 + k) * p.sbk];
             Bs[k][n] = v;
@@ -83,10 +84,17 @@ int gemm_f32(const GemmF32& p, hipStream_t s) {
         return fail(RVLM_ERR_ARG, "gemm_f32: bad arguments");
     dim3 grid(cdiv(p.N, FT), cdiv(p.M, FT), p.nb1 * p.nb2);
     const bool akc = (p.sak == 1), bkc = (p.sbk == 1);
-    if (akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, s, p);
-    else if (akc) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, s, p);
-    else if (bkc) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, s, p);
+    const bool deep = (long)grid.x * grid.y * grid.z < 256 && p.K >= 256;
+#define RVLM_F32_LAUNCH(FKV)                                                                                       \
+    do {                                                                                                           \
+        if (akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<true, true, FKV>), grid, dim3(256), 0, s, p);          \
+        else if (akc) hipLaunchKernelGGL((gemm_f32_kernel<true, false, FKV>), grid, dim3(256), 0, s, p);           \
+        else if (bkc) hipLaunchKernelGGL((gemm_f32_kernel<false, true, FKV>), grid, dim3(256), 0, s, p);           \
+        else hipLaunchKernelGGL((gemm_f32_kernel<false, false, FKV>), grid, dim3(256), 0, s, p);                   \
+    } while (0)
+    if (deep) RVLM_F32_LAUNCH(64);
+    else RVLM_F32_LAUNCH(16);
+#undef RVLM_F32_LAUNCH
     RVLM_CHECK_LAUNCH();
     return RVLM_OK;
 }

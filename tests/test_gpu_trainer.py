@@ -19,8 +19,12 @@ def to_cfg(c):
     return R.VitConfig(c.image_size, c.patch, c.width, c.layers, c.heads, c.out_dim, c.act)
 
 
+# width 1024 / 65 tokens / B=8: the encoder-shaped case - weight gradients take the split-K persistent-GEMM path
+VIT_WIDE = V.VitConfig(64, 8, 1024, 2, 16, 64)
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
-@pytest.mark.parametrize("cfg,B,norm", [(V.VIT_TINY, 4, False), (V.VIT_TINY2, 3, True)])
+@pytest.mark.parametrize("cfg,B,norm", [(V.VIT_TINY, 4, False), (V.VIT_TINY2, 3, True), (VIT_WIDE, 8, True)])
 def test_weight_gradients_vs_autograd(cfg, B, norm, precision):
     w = V.init_weights(cfg, seed=11)
     g = torch.Generator().manual_seed(2)
