@@ -786,6 +786,166 @@ int attn_bwd_bf16(const bf16_t* qkv, long ldqkv, const bf16_t* o, long ldo, cons
     return RVLM_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Class-token attention of the LAST transformer block.  The encoder's output is ln_post(x[:, 0]) @ proj
+// (open_clip VisionTransformer.forward with pool_type 'tok'), so in the last block only the class-token query
+// contributes: every other query row of that block (and everything downstream of it) is dead.  One wave per
+// (image, head): q is the class token's query, the keys / values are all S tokens.  fp32 softmax, natural-log lse.
+//   fwd: o[b, h*64 + d] = sum_j softmax_j(scale * q.k_j) v_j[d]
+//   bwd: dV_j = p_j dO, dK_j = dS_j q, dQ_0 = sum_j dS_j k_j with dS_j = scale * p_j (dO.v_j - dO.o); dQ_j = 0 (j > 0)
+// HBM-bound: K and V of the block are read once (fwd) / K twice, V once (bwd); dqkv is written in full.
+__device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+    const bf16_t x = (bf16_t)a, y = (bf16_t)b;
+    return (unsigned)*(const unsigned short*)&x | ((unsigned)*(const unsigned short*)&y << 16);
+}
+__device__ __forceinline__ float dot64(const uint4 (&row)[8], const float* __restrict__ vec) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        float f[8];
+        unpack8(row[c], f);
+        const float4 a = *(const float4*)(vec + c * 8), b = *(const float4*)(vec + c * 8 + 4);
+        acc = fmaf(f[0], a.x, acc); acc = fmaf(f[1], a.y, acc); acc = fmaf(f[2], a.z, acc); acc = fmaf(f[3], a.w, acc);
+        acc = fmaf(f[4], b.x, acc); acc = fmaf(f[5], b.y, acc); acc = fmaf(f[6], b.z, acc); acc = fmaf(f[7], b.w, acc);
+    }
+    return acc;
+}
+
+__global__ void __launch_bounds__(256)
+attn_cls_fwd_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict__ o, long ldo, float* __restrict__ lse,
+                    int H, int S, int W, int total, int Sp, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm_cls[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int bh = blockIdx.x * 4 + wave;
+    if (bh >= total) return;                       // no workgroup barrier below: each wave is on its own
+    const int b = bh / H, hd = bh - b * H;
+    float* qs = sm_cls + wave * (64 + Sp);
+    float* ps = qs + 64;
+    const bf16_t* base = qkv + (long)b * S * ld + hd * 64;
+    qs[lane] = (float)base[lane] * scale;
+    float mx = -INFINITY;
+    for (int j = lane; j < S; j += 64) {
+        const uint4* kr = (const uint4*)(base + (long)j * ld + W);
+        uint4 row[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) row[c] = kr[c];
+        const float sc = dot64(row, qs);
+        ps[j] = sc;
+        mx = fmaxf(mx, sc);
+    }
+    mx = wave_max(mx);
+    float sum = 0.0f;
+    for (int j = lane; j < S; j += 64) {
+        const float pj = __expf(ps[j] - mx);
+        ps[j] = pj;
+        sum += pj;
+    }
+    sum = wave_sum(sum);
+    // lanes = head dims: o[d] = sum_j p_j v_j[d]  (128-byte coalesced row reads, p_j broadcast from LDS)
+    const bf16_t* vb = base + 2 * W + lane;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    int j = 0;
+    for (; j + 4 <= S; j += 4) {
+        const float v0 = (float)vb[(long)j * ld], v1 = (float)vb[(long)(j + 1) * ld];
+        const float v2 = (float)vb[(long)(j + 2) * ld], v3 = (float)vb[(long)(j + 3) * ld];
+        a0 = fmaf(ps[j], v0, a0); a1 = fmaf(ps[j + 1], v1, a1); a2 = fmaf(ps[j + 2], v2, a2); a3 = fmaf(ps[j + 3], v3, a3);
+    }
+    for (; j < S; ++j) a0 = fmaf(ps[j], (float)vb[(long)j * ld], a0);
+    o[(long)b * ldo + hd * 64 + lane] = (bf16_t)(((a0 + a1) + (a2 + a3)) / sum);
+    if (lane == 0) lse[bh] = mx + __logf(sum);
+}
+
+__global__ void __launch_bounds__(256)
+attn_cls_bwd_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __restrict__ o, long ldo,
+                    const bf16_t* __restrict__ d_o, long lddo, const float* __restrict__ lse,
+                    bf16_t* __restrict__ dqkv, long lddq, int H, int S, int W, int total, int Sp, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm_cls[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int bh = blockIdx.x * 4 + wave;
+    if (bh >= total) return;
+    const int b = bh / H, hd = bh - b * H;
+    float* qf = sm_cls + wave * (128 + Sp);
+    float* dof = qf + 64;
+    float* dss = dof + 64;
+    const bf16_t* base = qkv + (long)b * S * ld + hd * 64;
+    bf16_t* dbase = dqkv + (long)b * S * lddq + hd * 64;
+    const float qv = (float)base[lane];
+    const float dov = (float)d_o[(long)b * lddo + hd * 64 + lane];
+    qf[lane] = qv;
+    dof[lane] = dov;
+    const float Dsum = wave_sum(dov * (float)o[(long)b * ldo + hd * 64 + lane]);
+    const float Lse = lse[bh];
+    const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+    for (int j = lane; j < S; j += 64) {
+        const uint4* kr = (const uint4*)(base + (long)j * ld + W);
+        const uint4* vr = (const uint4*)(base + (long)j * ld + 2 * W);
+        uint4 krow[8], vrow[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { krow[c] = kr[c]; vrow[c] = vr[c]; }
+        const float pj = __expf(scale * dot64(krow, qf) - Lse);
+        const float dsj = pj * (dot64(vrow, dof) - Dsum) * scale;
+        dss[j] = dsj;
+        uint4* dq_row = (uint4*)(dbase + (long)j * lddq);
+        uint4* dk_row = (uint4*)(dbase + (long)j * lddq + W);
+        uint4* dv_row = (uint4*)(dbase + (long)j * lddq + 2 * W);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float4 q0 = *(const float4*)(qf + c * 8), q1 = *(const float4*)(qf + c * 8 + 4);
+            const float4 g0 = *(const float4*)(dof + c * 8), g1 = *(const float4*)(dof + c * 8 + 4);
+            uint4 kk, vv;
+            kk.x = pack2(dsj * q0.x, dsj * q0.y); kk.y = pack2(dsj * q0.z, dsj * q0.w);
+            kk.z = pack2(dsj * q1.x, dsj * q1.y); kk.w = pack2(dsj * q1.z, dsj * q1.w);
+            vv.x = pack2(pj * g0.x, pj * g0.y); vv.y = pack2(pj * g0.z, pj * g0.w);
+            vv.z = pack2(pj * g1.x, pj * g1.y); vv.w = pack2(pj * g1.z, pj * g1.w);
+            dk_row[c] = kk;
+            dv_row[c] = vv;
+            if (j > 0) dq_row[c] = zero;
+        }
+    }
+    // lanes = head dims: dQ_0[d] = sum_j dS_j k_j[d]
+    const bf16_t* kb = base + W + lane;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    int j = 0;
+    for (; j + 4 <= S; j += 4) {
+        const float k0 = (float)kb[(long)j * ld], k1 = (float)kb[(long)(j + 1) * ld];
+        const float k2 = (float)kb[(long)(j + 2) * ld], k3 = (float)kb[(long)(j + 3) * ld];
+        a0 = fmaf(dss[j], k0, a0); a1 = fmaf(dss[j + 1], k1, a1); a2 = fmaf(dss[j + 2], k2, a2); a3 = fmaf(dss[j + 3], k3, a3);
+    }
+    for (; j < S; ++j) a0 = fmaf(dss[j], (float)kb[(long)j * ld], a0);
+    dbase[lane] = (bf16_t)((a0 + a1) + (a2 + a3));
+}
+
+int attn_cls_fwd_bf16(const bf16_t* qkv, long ldqkv, bf16_t* o, long ldo, float* lse, int B, int H, int S,
+                      hipStream_t s) {
+    if (!qkv || !o || !lse || B <= 0 || H <= 0 || S <= 0 || ldqkv % 8 != 0)
+        return fail(RVLM_ERR_ARG, "attn_cls_fwd_bf16: bad arguments");
+    const int total = B * H, Sp = (int)round_up(S, 4);
+    const size_t lds = (size_t)4 * (64 + Sp) * sizeof(float);
+    if (lds > 64 * 1024) return fail(RVLM_ERR_UNSUPPORTED, "attn_cls_fwd_bf16: sequence too long");
+    hipLaunchKernelGGL(attn_cls_fwd_kernel, dim3(cdiv(total, 4)), dim3(256), lds, s, qkv, ldqkv, o, ldo, lse, H, S, H * 64,
+                       total, Sp, 0.125f);
+    RVLM_CHECK_LAUNCH();
+    return RVLM_OK;
+}
+int attn_cls_bwd_bf16(const bf16_t* qkv, long ldqkv, const bf16_t* o, long ldo, const bf16_t* d_o, long lddo,
+                      const float* lse, bf16_t* dqkv, long lddqkv, int B, int H, int S, hipStream_t s) {
+    if (!qkv || !o || !d_o || !lse || !dqkv || B <= 0 || H <= 0 || S <= 0 || ldqkv % 8 != 0 || lddqkv % 8 != 0)
+        return fail(RVLM_ERR_ARG, "attn_cls_bwd_bf16: bad arguments");
+    const int total = B * H, Sp = (int)round_up(S, 4);
+    const size_t lds = (size_t)4 * (128 + Sp) * sizeof(float);
+    if (lds > 64 * 1024) return fail(RVLM_ERR_UNSUPPORTED, "attn_cls_bwd_bf16: sequence too long");
+    hipLaunchKernelGGL(attn_cls_bwd_kernel, dim3(cdiv(total, 4)), dim3(256), lds, s, qkv, ldqkv, o, ldo, d_o, lddo, lse, dqkv,
+                       lddqkv, H, S, H * 64, total, Sp, 0.125f);
+    RVLM_CHECK_LAUNCH();
+    return RVLM_OK;
+}
+
 // occupancy (workgroups per CU) the runtime reports for the three kernels at sequence length S
 int attn_occupancy(int S, int* out3) {
     const int Sp = (int)round_up(S, 32);

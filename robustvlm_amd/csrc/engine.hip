@@ -56,6 +56,11 @@ struct rvlm_vit {
     float *scores, *dscores;   // fp32 mode [B,H,S,S]
     float* splitk_scratch;     // fp32 slabs for the split-K remainder GEMMs (+ weight-gradient GEMMs when trainable)
     size_t splitk_bytes = 0;
+    // class-token tail (bf16 mode): in the last block only the class token's row is live downstream of the attention
+    // (the output is ln_post(x[:, 0]) @ proj), so out-proj / MLP / their LayerNorm run on B rows and the attention on
+    // the class query only.  Row b of the B-row intermediates is image b; x rows stay in place (stride S*W).
+    bool cls_tail = false;
+    float* lse_cls = nullptr;
     float* red_scratch = nullptr;   // partial column sums of the training step
     size_t red_floats = 0;
     // training (cfg.trainable): inputs of every linear layer + embedding tokens + transpose scratch
@@ -192,21 +197,21 @@ static int load_weights(rvlm_vit* h, const rvlm_vit_weights* w, hipStream_t s, b
 template <typename T>
 static int linear_fwd(rvlm_vit* h, hipStream_t s, const void* A, long lda, int M, int N, int K,
                       const float* w_f32, const bf16_t* w_nk, const float* bias, int epi, void* out, long ldo,
-                      void* out_pre, const float* residual);
+                      void* out_pre, const float* residual, int a_rows = 0);
 template <>
 int linear_fwd<bf16_t>(rvlm_vit* h, hipStream_t s, const void* A, long lda, int M, int N, int K,
                        const float*, const bf16_t* w_nk, const float* bias, int epi, void* out, long ldo,
-                       void* out_pre, const float* residual) {
+                       void* out_pre, const float* residual, int a_rows) {
     GemmBf16 g;
     g.A = (const bf16_t*)A; g.lda = lda; g.Bw = w_nk; g.ldb = K; g.M = M; g.N = N; g.K = K;
-    g.a_rows = (int)round_up(M, 128); g.epi = epi; g.bias = bias; g.out = out; g.ldo = ldo;
+    g.a_rows = a_rows > 0 ? a_rows : (int)round_up(M, 128); g.epi = epi; g.bias = bias; g.out = out; g.ldo = ldo;
     g.out_pre = (bf16_t*)out_pre; g.residual = residual; g.act = h->cfg.act;
     return gemm_bf16_nt(g, s);
 }
 template <>
 int linear_fwd<float>(rvlm_vit* h, hipStream_t s, const void* A, long lda, int M, int N, int K,
                       const float* w_f32, const bf16_t*, const float* bias, int epi, void* out, long ldo,
-                      void* out_pre, const float* residual) {
+                      void* out_pre, const float* residual, int) {
     GemmF32 g;
     g.A = (const float*)A; g.sam = lda; g.sak = 1;
     g.B = w_f32; g.sbn = K; g.sbk = 1;
@@ -219,21 +224,21 @@ int linear_fwd<float>(rvlm_vit* h, hipStream_t s, const void* A, long lda, int M
 template <typename T>
 static int linear_dgrad(rvlm_vit* h, hipStream_t s, const void* dY, long lddy, int M, int N, int K,
                         const float* w_f32, long ldw, const bf16_t* w_t, int epi, void* out, long ldo,
-                        const void* h_pre);
+                        const void* h_pre, int a_rows = 0);
 template <>
 int linear_dgrad<bf16_t>(rvlm_vit* h, hipStream_t s, const void* dY, long lddy, int M, int N, int K,
                          const float*, long, const bf16_t* w_t, int epi, void* out, long ldo,
-                         const void* h_pre) {
+                         const void* h_pre, int a_rows) {
     GemmBf16 g;
     g.A = (const bf16_t*)dY; g.lda = lddy; g.Bw = w_t; g.ldb = N; g.M = M; g.N = K; g.K = N;
-    g.a_rows = (int)round_up(M, 128); g.epi = epi; g.out = out; g.ldo = ldo;
+    g.a_rows = a_rows > 0 ? a_rows : (int)round_up(M, 128); g.epi = epi; g.out = out; g.ldo = ldo;
     g.h_pre = (const bf16_t*)h_pre; g.act = h->cfg.act;
     return gemm_bf16_nt(g, s);
 }
 template <>
 int linear_dgrad<float>(rvlm_vit* h, hipStream_t s, const void* dY, long lddy, int M, int N, int K,
                         const float* w_f32, long ldw, const bf16_t*, int epi, void* out, long ldo,
-                        const void* h_pre) {
+                        const void* h_pre, int) {
     GemmF32 g;
     g.A = (const float*)dY; g.sam = lddy; g.sak = 1;
     g.B = w_f32; g.sbn = 1; g.sbk = ldw;          // (n = k_out, k = n_in) at n_in*ldw + k_out
@@ -373,6 +378,26 @@ static int forward_impl(rvlm_vit* h, const float* x, const float* delta, int B, 
             if ((rc = linear_fwd<T>(h, s, ln1o, W, M, 3 * W, W, y.w_in, y.w_in_nk, y.b_in, EPI_BF16,
                                     h->qkv[sl], 3 * W, nullptr, nullptr))) return rc;
         }
+        if (h->cls_tail && l == L - 1) {
+            const long SW = (long)S * W;
+            {
+                PROF("tail_attn_fwd", 4.0 * B * h->H * (double)S * 64, (double)M * 2 * W * sizeof(T));
+                if ((rc = attn_cls_fwd_bf16((const bf16_t*)h->qkv[sl], 3 * W, (bf16_t*)h->attn_o[sl], W, h->lse_cls, B, h->H,
+                                            S, s))) return rc;
+            }
+            {
+                PROF("tail_mlp_fwd", 2.0 * B * W * 9 * W, 0);
+                if ((rc = linear_fwd<T>(h, s, h->attn_o[sl], W, B, W, W, y.w_out, y.w_out_nk, y.b_out, EPI_F32_RESID,
+                                        x_mid, SW, nullptr, x_in))) return rc;
+                if ((rc = layernorm_fwd<T>(x_mid, SW, y.ln2_w, y.ln2_b, (T*)ln2o, W, h->mean_at(2 + 2 * l),
+                                           h->rstd_at(2 + 2 * l), B, W, s))) return rc;
+                if ((rc = linear_fwd<T>(h, s, ln2o, W, B, 4 * W, W, y.w_fc, y.w_fc_nk, y.b_fc, EPI_BF16_ACT,
+                                        gact, 4 * W, h->h_pre[sl], nullptr))) return rc;
+                if ((rc = linear_fwd<T>(h, s, gact, 4 * W, B, W, 4 * W, y.w_proj, y.w_proj_nk, y.b_proj,
+                                        EPI_F32_RESID, x_out, SW, nullptr, x_mid))) return rc;
+            }
+            continue;
+        }
         {
             PROF("attn_fwd", attn_flops, 0);
             if ((rc = attention_fwd<T>(h, s, h->qkv[sl], h->attn_o[sl], h->lse[sl], B))) return rc;
@@ -447,6 +472,27 @@ static int backward_impl(rvlm_vit* h, const float* d_emb, int B, float* grad_x, 
     const void* dres_A = LP ? (const void*)h->dres_lp : (const void*)h->dres;
     for (int l = L - 1; l >= 0; --l) {
         Layer& y = h->layers[l];
+        if (h->cls_tail && l == L - 1) {
+            const long SW = (long)S * W;
+            {
+                PROF("tail_mlp_bwd", 2.0 * B * W * 9 * W, 0);
+                if ((rc = linear_dgrad<T>(h, s, dres_A, SW, B, W, 4 * W, y.w_proj, 4 * W, y.w_proj_t, EPI_BF16_DACT,
+                                          h->dh, 4 * W, h->h_pre[l], B))) return rc;
+                if ((rc = linear_dgrad<T>(h, s, h->dh, 4 * W, B, 4 * W, W, y.w_fc, W, y.w_fc_t, EPI_BF16, h->d_ln, W,
+                                          nullptr))) return rc;
+                if ((rc = layernorm_bwd<T, T>((const T*)h->d_ln, W, h->xs[2 * l + 1], SW, y.ln2_w, h->mean_at(2 + 2 * l),
+                                              h->rstd_at(2 + 2 * l), h->dres, SW, (T*)h->dres_lp, SW, 1, B, W, s)))
+                    return rc;
+                if ((rc = linear_dgrad<T>(h, s, dres_A, SW, B, W, W, y.w_out, W, y.w_out_t, EPI_BF16, h->d_o, W,
+                                          nullptr, B))) return rc;
+            }
+            {
+                PROF("tail_attn_bwd", 12.0 * B * h->H * (double)S * 64, (double)M * 5 * W * sizeof(T));
+                if ((rc = attn_cls_bwd_bf16((const bf16_t*)h->qkv[l], 3 * W, (const bf16_t*)h->attn_o[l], W,
+                                            (const bf16_t*)h->d_o, W, h->lse_cls, (bf16_t*)h->dqkv, 3 * W, B, h->H, S, s)))
+                    return rc;
+            }
+        } else {
         {
             PROF("gemm_fc2_bwd", 2.0 * M * W * 4 * W, 0);
             if ((rc = linear_dgrad<T>(h, s, dres_A, W, M, W, 4 * W, y.w_proj, 4 * W, y.w_proj_t, EPI_BF16_DACT,
@@ -471,6 +517,7 @@ static int backward_impl(rvlm_vit* h, const float* d_emb, int B, float* grad_x, 
         {
             PROF("attn_bwd", attn_flops, 0);
             if ((rc = attention_bwd<T>(h, s, h->qkv[l], h->attn_o[l], h->d_o, h->lse[l], h->dqkv, B))) return rc;
+        }
         }
         {
             PROF("gemm_qkv_bwd", 2.0 * M * W * 3 * W, 0);
@@ -599,26 +646,37 @@ static int backward_params_impl(rvlm_vit* h, const float* d_emb, int B, const rv
     for (int l = L - 1; l >= 0; --l) {
         Layer& y = h->layers[l];
         const rvlm_vit_block_weights& gb = gw->blocks_host[l];
+        // last block with the class-token tail: only the B class-token rows are live from here up to the attention
+        const bool tail = h->cls_tail && l == L - 1;
+        const int Mr = tail ? B : M, ar = tail ? B : 0;
+        const long ldr = tail ? (long)S * W : (long)W;
         // fc2 (c_proj): dY = d(residual), X = act(fc1)
-        if ((rc = wgrad<T>(h, s, dres_A, W, h->g_act_l[l], 4 * W, M, W, 4 * W, G(gb.mlp_c_proj_weight), 4 * W, acc,
+        if ((rc = wgrad<T>(h, s, dres_A, ldr, h->g_act_l[l], 4 * W, Mr, W, 4 * W, G(gb.mlp_c_proj_weight), 4 * W, acc,
                            G(gb.mlp_c_proj_bias)))) return rc;
-        if ((rc = linear_dgrad<T>(h, s, dres_A, W, M, W, 4 * W, y.w_proj, 4 * W, y.w_proj_t, EPI_BF16_DACT, h->dh,
-                                  4 * W, h->h_pre[l]))) return rc;
+        if ((rc = linear_dgrad<T>(h, s, dres_A, ldr, Mr, W, 4 * W, y.w_proj, 4 * W, y.w_proj_t, EPI_BF16_DACT, h->dh,
+                                  4 * W, h->h_pre[l], ar))) return rc;
         // fc1 (c_fc)
-        if ((rc = wgrad<T>(h, s, h->dh, 4 * W, h->ln2_out[l], W, M, 4 * W, W, G(gb.mlp_c_fc_weight), W, acc,
+        if ((rc = wgrad<T>(h, s, h->dh, 4 * W, h->ln2_out[l], W, Mr, 4 * W, W, G(gb.mlp_c_fc_weight), W, acc,
                            G(gb.mlp_c_fc_bias)))) return rc;
-        if ((rc = linear_dgrad<T>(h, s, h->dh, 4 * W, M, 4 * W, W, y.w_fc, W, y.w_fc_t, EPI_BF16, h->d_ln, W, nullptr)))
+        if ((rc = linear_dgrad<T>(h, s, h->dh, 4 * W, Mr, 4 * W, W, y.w_fc, W, y.w_fc_t, EPI_BF16, h->d_ln, W, nullptr)))
             return rc;
-        if ((rc = ln_param_grad<T>((const T*)h->d_ln, W, h->xs[2 * l + 1], W, h->mean_at(2 + 2 * l),
-                                   h->rstd_at(2 + 2 * l), M, W, G(gb.ln_2_weight), G(gb.ln_2_bias), acc, s))) return rc;
-        if ((rc = layernorm_bwd<T, T>((const T*)h->d_ln, W, h->xs[2 * l + 1], W, y.ln2_w, h->mean_at(2 + 2 * l),
-                                      h->rstd_at(2 + 2 * l), h->dres, W, LP ? (T*)h->dres_lp : nullptr, W, 1, M, W, s)))
+        if ((rc = ln_param_grad<T>((const T*)h->d_ln, W, h->xs[2 * l + 1], ldr, h->mean_at(2 + 2 * l),
+                                   h->rstd_at(2 + 2 * l), Mr, W, G(gb.ln_2_weight), G(gb.ln_2_bias), acc, s))) return rc;
+        if ((rc = layernorm_bwd<T, T>((const T*)h->d_ln, W, h->xs[2 * l + 1], ldr, y.ln2_w, h->mean_at(2 + 2 * l),
+                                      h->rstd_at(2 + 2 * l), h->dres, ldr, LP ? (T*)h->dres_lp : nullptr, ldr, 1, Mr, W, s)))
             return rc;
         // attention out-proj
-        if ((rc = wgrad<T>(h, s, dres_A, W, h->attn_o[l], W, M, W, W, G(gb.attn_out_proj_weight), W, acc,
+        if ((rc = wgrad<T>(h, s, dres_A, ldr, h->attn_o[l], W, Mr, W, W, G(gb.attn_out_proj_weight), W, acc,
                            G(gb.attn_out_proj_bias)))) return rc;
-        if ((rc = linear_dgrad<T>(h, s, dres_A, W, M, W, W, y.w_out, W, y.w_out_t, EPI_BF16, h->d_o, W, nullptr))) return rc;
-        if ((rc = attention_bwd<T>(h, s, h->qkv[l], h->attn_o[l], h->d_o, h->lse[l], h->dqkv, B))) return rc;
+        if ((rc = linear_dgrad<T>(h, s, dres_A, ldr, Mr, W, W, y.w_out, W, y.w_out_t, EPI_BF16, h->d_o, W, nullptr, ar)))
+            return rc;
+        if (tail) {
+            if ((rc = attn_cls_bwd_bf16((const bf16_t*)h->qkv[l], 3 * W, (const bf16_t*)h->attn_o[l], W,
+                                        (const bf16_t*)h->d_o, W, h->lse_cls, (bf16_t*)h->dqkv, 3 * W, B, h->H, S, s)))
+                return rc;
+        } else {
+            if ((rc = attention_bwd<T>(h, s, h->qkv[l], h->attn_o[l], h->d_o, h->lse[l], h->dqkv, B))) return rc;
+        }
         // qkv in-proj
         if ((rc = wgrad<T>(h, s, h->dqkv, 3 * W, h->ln1_out[l], W, M, 3 * W, W, G(gb.attn_in_proj_weight), W, acc,
                            G(gb.attn_in_proj_bias)))) return rc;
@@ -747,6 +805,11 @@ extern "C" int rvlm_vit_create(const rvlm_vit_config* cfg, const rvlm_vit_weight
     } else { h->scores = h->dscores = nullptr; }
     h->trainable = cfg->trainable > 0;
     h->tokens = h->dtok = nullptr; h->tA = h->tB = nullptr;
+    {
+        const char* e = getenv("RVLM_CLS_TAIL");    // 0: run the last block on every row like the other blocks
+        h->cls_tail = h->bf16 && !(e && atoi(e) == 0);
+        if (h->cls_tail) ALLOC_OR_DIE(h->lse_cls, (size_t)B * h->H * 4);
+    }
     if (h->trainable) {
         h->ln1_out.resize(L); h->ln2_out.resize(L); h->g_act_l.resize(L);
         for (int l = 0; l < L; ++l) {

@@ -332,16 +332,19 @@ int gemm_bf16_nt(const GemmBf16& p, hipStream_t s) {
     }
     int done = 0;
     const int variant = gemm_variant();
+    // few-row problems (the class-token rows of the last block: M = batch): a handful of 256x256 tiles cannot fill the
+    // chip - they take the 128x128 kernel with split-K below, like the remainder rows of the big problems
+    const bool small_m = p.M <= 512;
     // 1 or 2 (default): the persistent 256x256 kernel wherever the shape qualifies (N % 256 == 0, K % 128 == 0); it
     // beats both older kernels on every encoder shape (scripts/gemm_bench.py, profiles/).  RVLM_GEMM_PERSIST=0
     // restores the per-shape choice between the one-tile-per-workgroup 256x256 kernel and the 128x128 kernel.
-    if (variant != 0 && gemm_persist()) {
+    if (variant != 0 && gemm_persist() && !small_m) {
         int rc = gemm_waves() == 4 ? gemm_bf16_nt_256q(p, &done, s) : gemm_bf16_nt_256p(p, &done, s);
         if (rc) return rc;
         if (done >= p.M) return RVLM_OK;
     }
     const bool big = variant == 1 || (variant == 2 && (p.epi == EPI_BF16 || p.K >= 2048));
-    if (done == 0 && big) {
+    if (done == 0 && big && !small_m) {
         int rc = gemm_bf16_nt_256(p, &done, s);
         if (rc) return rc;
         if (done >= p.M) return RVLM_OK;
@@ -356,6 +359,8 @@ int gemm_bf16_nt(const GemmBf16& p, hipStream_t s) {
         if (p.residual) r.residual = p.residual + (long)done * p.ldo;
         r.M = p.M - done;
         r.a_rows = (p.a_rows > 0 ? p.a_rows : p.M) - done;
+    }
+    if ((done > 0 || small_m) && variant != 0) {
         // split-K: the strip is a handful of 128x128 tiles walking K serially (~1 us per 64-deep step, latency-bound).
         // Cut K so that >= 128 workgroups share the walk, each keeping >= 2 K-steps; fp32 slabs + reduce/epilogue kernel.
         int splitk = 1;
@@ -369,10 +374,11 @@ int gemm_bf16_nt(const GemmBf16& p, hipStream_t s) {
             }
         }
         const size_t need = (size_t)splitk * r.M * p.N * sizeof(float);
-        if (splitk > 1 && r.M <= 256 && g_splitk_scratch && need <= g_splitk_bytes && p.K % (splitk * GB_K) == 0) {
+        if (splitk > 1 && r.M <= 512 && g_splitk_scratch && need <= g_splitk_bytes && p.K % (splitk * GB_K) == 0) {
             GemmBf16 part = r;
             part.epi = EPI_F32; part.bias = nullptr; part.residual = nullptr; part.out = g_splitk_scratch;
             part.ldo = p.N; part.out_pre = nullptr; part.h_pre = nullptr;
+            part.a_rows = r.a_rows > 0 ? r.a_rows : r.M;
             const int tiles_m = cdiv(part.M, GB_M), tiles_n = cdiv(part.N, GB_N);
             hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI_F32>), dim3(tiles_m * tiles_n, splitk), dim3(256), 0, s, part,
                                tiles_m, tiles_n, part.a_rows, 0);

@@ -115,6 +115,12 @@ int attn_fwd_bf16(const bf16_t* qkv, long ldqkv, bf16_t* o, long ldo, float* lse
 int attn_bwd_bf16(const bf16_t* qkv, long ldqkv, const bf16_t* o, long ldo, const bf16_t* d_o,
                   long lddo, const float* lse, float* dsum_scratch, bf16_t* dqkv, long lddqkv,
                   int B, int H, int S, hipStream_t s);
+// class-token attention of the last block (only the class token's query row is live there): o [B, W] (row b = image b),
+// lse [B*H] natural log; bwd writes dqkv [B*S, 3W] in full (dQ rows of the other tokens are zero)
+int attn_cls_fwd_bf16(const bf16_t* qkv, long ldqkv, bf16_t* o, long ldo, float* lse, int B, int H, int S,
+                      hipStream_t s);
+int attn_cls_bwd_bf16(const bf16_t* qkv, long ldqkv, const bf16_t* o, long ldo, const bf16_t* d_o, long lddo,
+                      const float* lse, bf16_t* dqkv, long lddqkv, int B, int H, int S, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
 // misc

@@ -277,3 +277,27 @@ def test_full_size_properties_vit_l14_bf16():
     la = ((model(xa, False) - e0) ** 2).sum(1)
     assert float(((ls - la).abs() / la).max()) < 0.05
     eng.close()
+
+
+@pytest.mark.parametrize("cfg,B,norm", [(V.VIT_TINY2, 5, True), (V.VIT_B_32, 3, False),
+                                        (V.VitConfig(64, 8, 1024, 2, 16, 64), 8, True)])
+def test_class_token_tail_matches_full_last_block(cfg, B, norm, monkeypatch):
+    """The last block evaluated on the class-token rows only (default) against the same engine running the last block
+    on every row (RVLM_CLS_TAIL=0): the dead rows do not reach the output, so embedding and input gradient agree to
+    bf16 rounding (the two attention kernels round P differently)."""
+    w = V.init_weights(cfg, seed=21)
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(B, 3, cfg.image_size, cfg.image_size, generator=g).to(dev())
+    cot = torch.randn(B, cfg.out_dim, generator=g).to(dev())
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("RVLM_CLS_TAIL", mode)
+        eng = make_engine(cfg, w, "bf16")
+        emb = eng.forward(x, None, norm, save=True)
+        gx = eng.backward_input(cot)
+        torch.cuda.synchronize()
+        out[mode] = (emb.clone(), gx.clone())
+        eng.close()
+    assert cos_sim(out["0"][0].cpu(), out["1"][0].cpu()) > 0.99995
+    assert rel_max(out["1"][0].cpu(), out["0"][0].cpu()) < 2e-2
+    assert cos_sim(out["0"][1].cpu(), out["1"][1].cpu()) > 0.999
