@@ -226,6 +226,9 @@ def main():
                                           args.attack == "apgd" else args.iterations + 1.5) / 1e12,
         }
         res["whole_loop_frac_of_peak"] = res["whole_loop_tflops_per_gpu"] / PEAK_BF16_TFLOPS
+        res["whole_loop_flop_basis"] = ("reference model FLOPs per image (SURVEY.md Appendix C); the engine's class-token "
+                                        "tail skips the dead rows of the last block (~3 % of them) - roofline.achieved "
+                                        "counts executed FLOPs only")
 
     # ---- roofline of the dominant kernel (bf16 MFMA GEMM), HIP events on the engine's stream ------
     if rank == 0 and not args.no_roofline:

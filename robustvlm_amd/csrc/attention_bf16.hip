@@ -804,144 +804,151 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
     const bf16_t x = (bf16_t)a, y = (bf16_t)b;
     return (unsigned)*(const unsigned short*)&x | ((unsigned)*(const unsigned short*)&y << 16);
 }
-__device__ __forceinline__ float dot64(const uint4 (&row)[8], const float* __restrict__ vec) {
-    float acc = 0.0f;
+__device__ __forceinline__ float dot8(const float (&a)[8], const float (&b)[8]) {
+    float acc = a[0] * b[0];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        float f[8];
-        unpack8(row[c], f);
-        const float4 a = *(const float4*)(vec + c * 8), b = *(const float4*)(vec + c * 8 + 4);
-        acc = fmaf(f[0], a.x, acc); acc = fmaf(f[1], a.y, acc); acc = fmaf(f[2], a.z, acc); acc = fmaf(f[3], a.w, acc);
-        acc = fmaf(f[4], b.x, acc); acc = fmaf(f[5], b.y, acc); acc = fmaf(f[6], b.z, acc); acc = fmaf(f[7], b.w, acc);
-    }
+    for (int e = 1; e < 8; ++e) acc = fmaf(a[e], b[e], acc);
     return acc;
 }
+// sum over the 8 lanes that share lane >> 3 (the 8 sixteen-byte chunks of one 64-wide head row)
+__device__ __forceinline__ float chunk_sum(float v) {
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    return v;
+}
+// Lane (g, c) = (lane >> 3, lane & 7): key j = g + 8 i, 16-byte chunk c of its 128-byte head row, so that one wave load
+// covers 8 whole rows.  Dot products are reduced over c, the per-group running results over g at the end.
 
 __global__ void __launch_bounds__(256)
 attn_cls_fwd_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict__ o, long ldo, float* __restrict__ lse,
-                    int H, int S, int W, int total, int Sp, float scale) {
-    extern __shared__ __attribute__((aligned(16))) float sm_cls[];
+                    int H, int S, int W, int total, float scale) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int bh = blockIdx.x * 4 + wave;
-    if (bh >= total) return;                       // no workgroup barrier below: each wave is on its own
-    const int b = bh / H, hd = bh - b * H;
-    float* qs = sm_cls + wave * (64 + Sp);
-    float* ps = qs + 64;
-    const bf16_t* base = qkv + (long)b * S * ld + hd * 64;
-    qs[lane] = (float)base[lane] * scale;
-    float mx = -INFINITY;
-    for (int j = lane; j < S; j += 64) {
-        const uint4* kr = (const uint4*)(base + (long)j * ld + W);
-        uint4 row[8];
+    if (bh >= total) return;
+    const int b = bh / H, hd = bh - b * H, g = lane >> 3, c = lane & 7;
+    const bf16_t* base = qkv + (long)b * S * ld + hd * 64 + c * 8;
+    float qc[8];
+    unpack8(*(const uint4*)base, qc);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) row[c] = kr[c];
-        const float sc = dot64(row, qs);
-        ps[j] = sc;
-        mx = fmaxf(mx, sc);
+    for (int e = 0; e < 8; ++e) qc[e] *= scale;
+    float m = -INFINITY, l = 0.0f, acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
+    const int iters = (S + 7) >> 3;
+    for (int i = 0; i < iters; ++i) {
+        const int j = g + 8 * i;
+        const bool valid = j < S;
+        const bf16_t* row = base + (long)(valid ? j : S - 1) * ld;
+        float kf[8], vf[8];
+        unpack8(*(const uint4*)(row + W), kf);
+        unpack8(*(const uint4*)(row + 2 * W), vf);
+        const float sc = chunk_sum(dot8(kf, qc));
+        if (valid) {
+            const float mn = fmaxf(m, sc);
+            const float corr = __expf(m - mn), pj = __expf(sc - mn);
+            l = fmaf(l, corr, pj);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = fmaf(acc[e], corr, pj * vf[e]);
+            m = mn;
+        }
     }
-    mx = wave_max(mx);
-    float sum = 0.0f;
-    for (int j = lane; j < S; j += 64) {
-        const float pj = __expf(ps[j] - mx);
-        ps[j] = pj;
-        sum += pj;
+#pragma unroll
+    for (int off = 8; off < 64; off <<= 1) {
+        const float m2 = __shfl_xor(m, off), l2 = __shfl_xor(l, off);
+        const float mn = fmaxf(m, m2);
+        const float ca = (m == -INFINITY) ? 0.0f : __expf(m - mn), cb = (m2 == -INFINITY) ? 0.0f : __expf(m2 - mn);
+        l = l * ca + l2 * cb;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = acc[e] * ca + __shfl_xor(acc[e], off) * cb;
+        m = mn;
     }
-    sum = wave_sum(sum);
-    // lanes = head dims: o[d] = sum_j p_j v_j[d]  (128-byte coalesced row reads, p_j broadcast from LDS)
-    const bf16_t* vb = base + 2 * W + lane;
-    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-    int j = 0;
-    for (; j + 4 <= S; j += 4) {
-        const float v0 = (float)vb[(long)j * ld], v1 = (float)vb[(long)(j + 1) * ld];
-        const float v2 = (float)vb[(long)(j + 2) * ld], v3 = (float)vb[(long)(j + 3) * ld];
-        a0 = fmaf(ps[j], v0, a0); a1 = fmaf(ps[j + 1], v1, a1); a2 = fmaf(ps[j + 2], v2, a2); a3 = fmaf(ps[j + 3], v3, a3);
+    if (g == 0) {
+        const float inv = 1.0f / l;
+        uint4 ov;
+        ov.x = pack2(acc[0] * inv, acc[1] * inv); ov.y = pack2(acc[2] * inv, acc[3] * inv);
+        ov.z = pack2(acc[4] * inv, acc[5] * inv); ov.w = pack2(acc[6] * inv, acc[7] * inv);
+        *(uint4*)(o + (long)b * ldo + hd * 64 + c * 8) = ov;
+        if (c == 0) lse[bh] = m + __logf(l);
     }
-    for (; j < S; ++j) a0 = fmaf(ps[j], (float)vb[(long)j * ld], a0);
-    o[(long)b * ldo + hd * 64 + lane] = (bf16_t)(((a0 + a1) + (a2 + a3)) / sum);
-    if (lane == 0) lse[bh] = mx + __logf(sum);
 }
 
 __global__ void __launch_bounds__(256)
 attn_cls_bwd_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __restrict__ o, long ldo,
                     const bf16_t* __restrict__ d_o, long lddo, const float* __restrict__ lse,
-                    bf16_t* __restrict__ dqkv, long lddq, int H, int S, int W, int total, int Sp, float scale) {
-    extern __shared__ __attribute__((aligned(16))) float sm_cls[];
+                    bf16_t* __restrict__ dqkv, long lddq, int H, int S, int W, int total, float scale) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int bh = blockIdx.x * 4 + wave;
     if (bh >= total) return;
-    const int b = bh / H, hd = bh - b * H;
-    float* qf = sm_cls + wave * (128 + Sp);
-    float* dof = qf + 64;
-    float* dss = dof + 64;
-    const bf16_t* base = qkv + (long)b * S * ld + hd * 64;
-    bf16_t* dbase = dqkv + (long)b * S * lddq + hd * 64;
-    const float qv = (float)base[lane];
-    const float dov = (float)d_o[(long)b * lddo + hd * 64 + lane];
-    qf[lane] = qv;
-    dof[lane] = dov;
-    const float Dsum = wave_sum(dov * (float)o[(long)b * ldo + hd * 64 + lane]);
+    const int b = bh / H, hd = bh - b * H, g = lane >> 3, c = lane & 7;
+    const bf16_t* base = qkv + (long)b * S * ld + hd * 64 + c * 8;
+    bf16_t* dbase = dqkv + (long)b * S * lddq + hd * 64 + c * 8;
+    float qc[8], doc[8], oc[8];
+    unpack8(*(const uint4*)base, qc);
+    unpack8(*(const uint4*)(d_o + (long)b * lddo + hd * 64 + c * 8), doc);
+    unpack8(*(const uint4*)(o + (long)b * ldo + hd * 64 + c * 8), oc);
+    const float Dsum = chunk_sum(dot8(doc, oc));
     const float Lse = lse[bh];
+    float accq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) accq[e] = 0.0f;
     const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
-    for (int j = lane; j < S; j += 64) {
-        const uint4* kr = (const uint4*)(base + (long)j * ld + W);
-        const uint4* vr = (const uint4*)(base + (long)j * ld + 2 * W);
-        uint4 krow[8], vrow[8];
+    const int iters = (S + 7) >> 3;
+    for (int i = 0; i < iters; ++i) {
+        const int j = g + 8 * i;
+        const bool valid = j < S;
+        const long rj = valid ? j : S - 1;
+        float kf[8], vf[8];
+        unpack8(*(const uint4*)(base + rj * ld + W), kf);
+        unpack8(*(const uint4*)(base + rj * ld + 2 * W), vf);
+        const float sc = chunk_sum(dot8(kf, qc));
+        const float dp = chunk_sum(dot8(vf, doc));
+        const float pj = valid ? __expf(scale * sc - Lse) : 0.0f;
+        const float dsj = pj * (dp - Dsum) * scale;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) { krow[c] = kr[c]; vrow[c] = vr[c]; }
-        const float pj = __expf(scale * dot64(krow, qf) - Lse);
-        const float dsj = pj * (dot64(vrow, dof) - Dsum) * scale;
-        dss[j] = dsj;
-        uint4* dq_row = (uint4*)(dbase + (long)j * lddq);
-        uint4* dk_row = (uint4*)(dbase + (long)j * lddq + W);
-        uint4* dv_row = (uint4*)(dbase + (long)j * lddq + 2 * W);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const float4 q0 = *(const float4*)(qf + c * 8), q1 = *(const float4*)(qf + c * 8 + 4);
-            const float4 g0 = *(const float4*)(dof + c * 8), g1 = *(const float4*)(dof + c * 8 + 4);
+        for (int e = 0; e < 8; ++e) accq[e] = fmaf(dsj, kf[e], accq[e]);
+        if (valid) {
             uint4 kk, vv;
-            kk.x = pack2(dsj * q0.x, dsj * q0.y); kk.y = pack2(dsj * q0.z, dsj * q0.w);
-            kk.z = pack2(dsj * q1.x, dsj * q1.y); kk.w = pack2(dsj * q1.z, dsj * q1.w);
-            vv.x = pack2(pj * g0.x, pj * g0.y); vv.y = pack2(pj * g0.z, pj * g0.w);
-            vv.z = pack2(pj * g1.x, pj * g1.y); vv.w = pack2(pj * g1.z, pj * g1.w);
-            dk_row[c] = kk;
-            dv_row[c] = vv;
-            if (j > 0) dq_row[c] = zero;
+            kk.x = pack2(dsj * qc[0], dsj * qc[1]); kk.y = pack2(dsj * qc[2], dsj * qc[3]);
+            kk.z = pack2(dsj * qc[4], dsj * qc[5]); kk.w = pack2(dsj * qc[6], dsj * qc[7]);
+            vv.x = pack2(pj * doc[0], pj * doc[1]); vv.y = pack2(pj * doc[2], pj * doc[3]);
+            vv.z = pack2(pj * doc[4], pj * doc[5]); vv.w = pack2(pj * doc[6], pj * doc[7]);
+            bf16_t* drow = dbase + rj * lddq;
+            *(uint4*)(drow + W) = kk;
+            *(uint4*)(drow + 2 * W) = vv;
+            if (j > 0) *(uint4*)drow = zero;
         }
     }
-    // lanes = head dims: dQ_0[d] = sum_j dS_j k_j[d]
-    const bf16_t* kb = base + W + lane;
-    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-    int j = 0;
-    for (; j + 4 <= S; j += 4) {
-        const float k0 = (float)kb[(long)j * ld], k1 = (float)kb[(long)(j + 1) * ld];
-        const float k2 = (float)kb[(long)(j + 2) * ld], k3 = (float)kb[(long)(j + 3) * ld];
-        a0 = fmaf(dss[j], k0, a0); a1 = fmaf(dss[j + 1], k1, a1); a2 = fmaf(dss[j + 2], k2, a2); a3 = fmaf(dss[j + 3], k3, a3);
+#pragma unroll
+    for (int off = 8; off < 64; off <<= 1)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) accq[e] += __shfl_xor(accq[e], off);
+    if (g == 0) {
+        uint4 qq;
+        qq.x = pack2(accq[0], accq[1]); qq.y = pack2(accq[2], accq[3]);
+        qq.z = pack2(accq[4], accq[5]); qq.w = pack2(accq[6], accq[7]);
+        *(uint4*)dbase = qq;
     }
-    for (; j < S; ++j) a0 = fmaf(dss[j], (float)kb[(long)j * ld], a0);
-    dbase[lane] = (bf16_t)((a0 + a1) + (a2 + a3));
 }
 
 int attn_cls_fwd_bf16(const bf16_t* qkv, long ldqkv, bf16_t* o, long ldo, float* lse, int B, int H, int S,
                       hipStream_t s) {
-    if (!qkv || !o || !lse || B <= 0 || H <= 0 || S <= 0 || ldqkv % 8 != 0)
+    if (!qkv || !o || !lse || B <= 0 || H <= 0 || S <= 0 || ldqkv % 8 != 0 || ldo % 8 != 0)
         return fail(RVLM_ERR_ARG, "attn_cls_fwd_bf16: bad arguments");
-    const int total = B * H, Sp = (int)round_up(S, 4);
-    const size_t lds = (size_t)4 * (64 + Sp) * sizeof(float);
-    if (lds > 64 * 1024) return fail(RVLM_ERR_UNSUPPORTED, "attn_cls_fwd_bf16: sequence too long");
-    hipLaunchKernelGGL(attn_cls_fwd_kernel, dim3(cdiv(total, 4)), dim3(256), lds, s, qkv, ldqkv, o, ldo, lse, H, S, H * 64,
-                       total, Sp, 0.125f);
+    const int total = B * H;
+    hipLaunchKernelGGL(attn_cls_fwd_kernel, dim3(cdiv(total, 4)), dim3(256), 0, s, qkv, ldqkv, o, ldo, lse, H, S, H * 64,
+                       total, 0.125f);
     RVLM_CHECK_LAUNCH();
     return RVLM_OK;
 }
 int attn_cls_bwd_bf16(const bf16_t* qkv, long ldqkv, const bf16_t* o, long ldo, const bf16_t* d_o, long lddo,
                       const float* lse, bf16_t* dqkv, long lddqkv, int B, int H, int S, hipStream_t s) {
-    if (!qkv || !o || !d_o || !lse || !dqkv || B <= 0 || H <= 0 || S <= 0 || ldqkv % 8 != 0 || lddqkv % 8 != 0)
+    if (!qkv || !o || !d_o || !lse || !dqkv || B <= 0 || H <= 0 || S <= 0 || ldqkv % 8 != 0 || lddqkv % 8 != 0 ||
+        ldo % 8 != 0 || lddo % 8 != 0)
         return fail(RVLM_ERR_ARG, "attn_cls_bwd_bf16: bad arguments");
-    const int total = B * H, Sp = (int)round_up(S, 4);
-    const size_t lds = (size_t)4 * (128 + Sp) * sizeof(float);
-    if (lds > 64 * 1024) return fail(RVLM_ERR_UNSUPPORTED, "attn_cls_bwd_bf16: sequence too long");
-    hipLaunchKernelGGL(attn_cls_bwd_kernel, dim3(cdiv(total, 4)), dim3(256), lds, s, qkv, ldqkv, o, ldo, d_o, lddo, lse, dqkv,
-                       lddqkv, H, S, H * 64, total, Sp, 0.125f);
+    const int total = B * H;
+    hipLaunchKernelGGL(attn_cls_bwd_kernel, dim3(cdiv(total, 4)), dim3(256), 0, s, qkv, ldqkv, o, ldo, d_o, lddo, lse, dqkv,
+                       lddqkv, H, S, H * 64, total, 0.125f);
     RVLM_CHECK_LAUNCH();
     return RVLM_OK;
 }

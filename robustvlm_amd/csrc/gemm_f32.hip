@@ -79,9 +79,95 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32 p) {
     }
 }
 
+// ---- few-row problems (the projection head: M = batch).  The 64x64-tile kernel gives them a couple of dozen
+// workgroups (220 us for 128 x 768 x 1024); here every wave owns a 4-row strip and the chip is covered.
+// NN: C[m, n] = alpha * sum_k A[m, k] B[k, n]  (A row-major, B with n contiguous).  Lanes = 64 consecutive n; the A
+// values are wave-uniform.  Same k-ordered fmaf chain as the tiled kernel -> identical results.
+__global__ void __launch_bounds__(256) gemm_f32_skinny_nn_kernel(GemmF32 p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + lane;
+    const int m0 = (blockIdx.y * 4 + wave) * 4;
+    if (m0 >= p.M) return;
+    const int nc = min(n, p.N - 1);
+    const float* __restrict__ Bp = p.B + (long)nc * p.sbn;
+    const float* __restrict__ A0 = p.A + (long)min(m0, p.M - 1) * p.sam;
+    const float* __restrict__ A1 = p.A + (long)min(m0 + 1, p.M - 1) * p.sam;
+    const float* __restrict__ A2 = p.A + (long)min(m0 + 2, p.M - 1) * p.sam;
+    const float* __restrict__ A3 = p.A + (long)min(m0 + 3, p.M - 1) * p.sam;
+    float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f;
+    int k = 0;
+    for (; k + 8 <= p.K; k += 8) {
+        float b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) b[u] = Bp[(long)(k + u) * p.sbk];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            c0 = fmaf(A0[k + u], b[u], c0); c1 = fmaf(A1[k + u], b[u], c1);
+            c2 = fmaf(A2[k + u], b[u], c2); c3 = fmaf(A3[k + u], b[u], c3);
+        }
+    }
+    for (; k < p.K; ++k) {
+        const float b = Bp[(long)k * p.sbk];
+        c0 = fmaf(A0[k], b, c0); c1 = fmaf(A1[k], b, c1); c2 = fmaf(A2[k], b, c2); c3 = fmaf(A3[k], b, c3);
+    }
+    if (n >= p.N) return;
+    const float c[4] = {c0, c1, c2, c3};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (m0 + i < p.M) p.C[(long)(m0 + i) * p.scm + n] = p.alpha * c[i];
+}
+// NT: C[m, n] = alpha * sum_k A[m, k] B[n, k]  (both K-contiguous).  A wave owns a 4 x 4 output block, lanes stride K.
+__global__ void __launch_bounds__(256) gemm_f32_skinny_nt_kernel(GemmF32 p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n0 = (blockIdx.x * 4 + wave) * 4, m0 = blockIdx.y * 4;
+    if (n0 >= p.N) return;
+    const float* __restrict__ Ar[4];
+    const float* __restrict__ Br[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        Ar[i] = p.A + (long)min(m0 + i, p.M - 1) * p.sam;
+        Br[i] = p.B + (long)min(n0 + i, p.N - 1) * p.sbn;
+    }
+    float c[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[i][j] = 0.0f;
+    for (int k = lane; k < p.K; k += 64) {
+        float a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a[i] = Ar[i][k]; b[i] = Br[i][k]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c[i][j] = fmaf(a[i], b[j], c[i][j]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float v = wave_sum(c[i][j]);
+            if (lane == 0 && m0 + i < p.M && n0 + j < p.N) p.C[(long)(m0 + i) * p.scm + n0 + j] = p.alpha * v;
+        }
+}
+
 int gemm_f32(const GemmF32& p, hipStream_t s) {
     if (!p.A || !p.B || !p.C || p.M <= 0 || p.N <= 0 || p.K <= 0 || p.nb1 <= 0 || p.nb2 <= 0)
         return fail(RVLM_ERR_ARG, "gemm_f32: bad arguments");
+    const bool plain = !p.bias && p.act < 0 && !p.C_pre && !p.dact_h && !p.residual && p.nb1 == 1 && p.nb2 == 1 &&
+                       p.scn == 1;
+    if (plain && p.M <= 512 && p.K >= 256 && p.sak == 1 && (long)cdiv(p.N, 64) * cdiv(p.M, 64) < 128) {
+        if (p.sbn == 1) {
+            hipLaunchKernelGGL(gemm_f32_skinny_nn_kernel, dim3(cdiv(p.N, 64), cdiv(p.M, 16)), dim3(256), 0, s, p);
+            RVLM_CHECK_LAUNCH();
+            return RVLM_OK;
+        }
+        if (p.sbk == 1) {
+            hipLaunchKernelGGL(gemm_f32_skinny_nt_kernel, dim3(cdiv(p.N, 16), cdiv(p.M, 4)), dim3(256), 0, s, p);
+            RVLM_CHECK_LAUNCH();
+            return RVLM_OK;
+        }
+    }
     dim3 grid(cdiv(p.N, FT), cdiv(p.M, FT), p.nb1 * p.nb2);
     const bool akc = (p.sak == 1), bkc = (p.sbk == 1);
     const bool deep = (long)grid.x * grid.y * grid.z < 256 && p.K >= 256;
