@@ -272,3 +272,42 @@ def test_wgrad_split_vs_fp32(M, N, K):
                                         K, 0, None, work.data_ptr(), nb, st()), "wgrad")
     torch.cuda.synchronize()
     assert torch.equal(dW2, dW3)
+
+
+@pytest.mark.parametrize("r", [32, 100, 128, 255])
+@pytest.mark.parametrize("N,K", [(512, 128), (3072, 1024), (1024, 4096)])
+def test_gemm_bf16_remainder_rows_in_launch(r, N, K):
+    """M = 256 q + r: the r remainder rows are computed by the persistent kernel's strip phase (same launch); every
+    epilogue, rows beyond M untouched."""
+    lib().rvlm_k_gemm_set_variant(1)
+    try:
+        M = 256 * 3 + r
+        g = torch.Generator(device="cuda").manual_seed(r + N + K)
+        A = torch.randn(M, K, generator=g, device=dev()).bfloat16()
+        Bw = (torch.randn(N, K, generator=g, device=dev()) * K ** -0.5).bfloat16()
+        bias = torch.randn(N, generator=g, device=dev())
+        res = torch.randn(M, N, generator=g, device=dev())
+        hp = torch.randn(M, N, generator=g, device=dev()).bfloat16()
+        acc = (A.float() @ Bw.float().t()).double()
+        out, _ = gemm_bf16(A, Bw, epi=4, bias=bias)
+        assert rel_max(out, acc + bias.double()) < 3e-5
+        out, _ = gemm_bf16(A, Bw, epi=1, bias=bias, residual=res)
+        assert rel_max(out, acc + bias.double() + res.double()) < 3e-5
+        out, _ = gemm_bf16(A, Bw, epi=0)
+        assert rel_max(out.float(), acc) < 1e-2
+        out, pre = gemm_bf16(A, Bw, epi=2, bias=bias, act=0)
+        assert rel_max(pre.float(), dact_ref(acc + bias.double(), 0)) < 1.5e-2
+        assert rel_max(out.float(), act_ref(acc + bias.double(), 0)) < 1.5e-2
+        out, _ = gemm_bf16(A, Bw, epi=3, h_pre=hp)
+        assert rel_max(out.float(), acc * hp.double()) < 1.5e-2
+        # rows beyond M of a taller output buffer stay untouched
+        tall = torch.full((M + 64, N), 7.0, device=dev())
+        Ap = torch.zeros(256 * 4, K, dtype=torch.bfloat16, device=dev())
+        Ap[:M] = A
+        L.check(lib().rvlm_k_gemm_bf16_nt(Ap.data_ptr(), K, Bw.data_ptr(), K, M, N, K, Ap.shape[0], 4, None,
+                                          tall.data_ptr(), N, None, None, None, 0, st()), "gemm")
+        torch.cuda.synchronize()
+        assert rel_max(tall[:M], acc) < 3e-5
+        assert torch.all(tall[M:] == 7.0)
+    finally:
+        lib().rvlm_k_gemm_set_variant(-1)
