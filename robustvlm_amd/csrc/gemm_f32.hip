@@ -96,12 +96,13 @@ __global__ void __launch_bounds__(256) gemm_f32_skinny_nn_kernel(GemmF32 p) {
     const float* __restrict__ A3 = p.A + (long)min(m0 + 3, p.M - 1) * p.sam;
     float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f;
     int k = 0;
-    for (; k + 8 <= p.K; k += 8) {
-        float b[8];
+    // 32 independent B loads in flight per wave: with ~1.5 waves per CU the loop is bound by load latency
+    for (; k + 32 <= p.K; k += 32) {
+        float b[32];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) b[u] = Bp[(long)(k + u) * p.sbk];
+        for (int u = 0; u < 32; ++u) b[u] = Bp[(long)(k + u) * p.sbk];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 32; ++u) {
             c0 = fmaf(A0[k + u], b[u], c0); c1 = fmaf(A1[k + u], b[u], c1);
             c2 = fmaf(A2[k + u], b[u], c2); c3 = fmaf(A3[k + u], b[u], c3);
         }
