@@ -322,6 +322,39 @@ int attention_bwd<float>(rvlm_vit* h, hipStream_t s, const void* qkv_, const voi
     return gemm_f32(v, s);
 }
 
+// ---- QKV projection of the last block under the class-token tail: K, V for every token, Q for the class rows only
+// (the other 256 query rows of that block are dead).  Forward: qkv[:, W:3W] by the big GEMM (N = 2W), then the class
+// rows' Q by a B-row GEMM.  Backward: d_ln = dqkv[:, W:3W] @ W_in[W:3W] for every row (K = 2W), then the class rows are
+// overwritten with their full product (K = 3W).
+static int qkv_tail_fwd(rvlm_vit* h, hipStream_t s, const void* ln1o, const Layer& y, void* qkv, int B) {
+    const int S = h->S, W = h->W, M = B * S;
+    GemmBf16 g;
+    g.A = (const bf16_t*)ln1o; g.lda = W; g.Bw = y.w_in_nk + (size_t)W * W; g.ldb = W;
+    g.M = M; g.N = 2 * W; g.K = W; g.a_rows = (int)round_up(M, 128); g.epi = EPI_BF16;
+    g.bias = y.b_in + W; g.out = (bf16_t*)qkv + W; g.ldo = 3 * W; g.act = h->cfg.act;
+    int rc = gemm_bf16_nt(g, s);
+    if (rc) return rc;
+    GemmBf16 q;
+    q.A = (const bf16_t*)ln1o; q.lda = (long)S * W; q.Bw = y.w_in_nk; q.ldb = W;
+    q.M = B; q.N = W; q.K = W; q.a_rows = B; q.epi = EPI_BF16;
+    q.bias = y.b_in; q.out = qkv; q.ldo = (long)S * 3 * W; q.act = h->cfg.act;
+    return gemm_bf16_nt(q, s);
+}
+static int qkv_tail_bwd(rvlm_vit* h, hipStream_t s, const void* dqkv, const Layer& y, void* d_ln, int B) {
+    const int S = h->S, W = h->W, M = B * S;
+    GemmBf16 g;
+    g.A = (const bf16_t*)dqkv + W; g.lda = 3 * W; g.Bw = y.w_in_t + W; g.ldb = 3 * W;
+    g.M = M; g.N = W; g.K = 2 * W; g.a_rows = (int)round_up(M, 128); g.epi = EPI_BF16;
+    g.out = d_ln; g.ldo = W; g.act = h->cfg.act;
+    int rc = gemm_bf16_nt(g, s);
+    if (rc) return rc;
+    GemmBf16 q;
+    q.A = (const bf16_t*)dqkv; q.lda = (long)S * 3 * W; q.Bw = y.w_in_t; q.ldb = 3 * W;
+    q.M = B; q.N = W; q.K = 3 * W; q.a_rows = B; q.epi = EPI_BF16;
+    q.out = d_ln; q.ldo = (long)S * W; q.act = h->cfg.act;
+    return gemm_bf16_nt(q, s);
+}
+
 // ---- forward -----------------------------------------------------------------------------------
 // The GEMM / reduction scratch pointers are process-wide: every entry that launches encoder kernels points them at
 // this handle's buffers first (several handles coexist - e.g. the frozen original encoder next to the trained one).
@@ -373,7 +406,10 @@ static int forward_impl(rvlm_vit* h, const float* x, const float* delta, int B, 
             if ((rc = layernorm_fwd<T>(x_in, W, y.ln1_w, y.ln1_b, (T*)ln1o, W, h->mean_at(1 + 2 * l),
                                        h->rstd_at(1 + 2 * l), M, W, s))) return rc;
         }
-        {
+        if (h->cls_tail && l == L - 1) {
+            PROF("gemm_qkv_fwd", 2.0 * M * W * 2 * W + 2.0 * B * W * W, 0);
+            if ((rc = qkv_tail_fwd(h, s, ln1o, y, h->qkv[sl], B))) return rc;
+        } else {
             PROF("gemm_qkv_fwd", 2.0 * M * W * 3 * W, 0);
             if ((rc = linear_fwd<T>(h, s, ln1o, W, M, 3 * W, W, y.w_in, y.w_in_nk, y.b_in, EPI_BF16,
                                     h->qkv[sl], 3 * W, nullptr, nullptr))) return rc;
@@ -463,8 +499,10 @@ static int backward_impl(rvlm_vit* h, const float* d_emb, int B, float* grad_x, 
         g.C = h->d_pooled; g.scm = W; g.scn = 1;
         g.M = B; g.N = W; g.K = D;
         if ((rc = gemm_f32(g, s))) return rc;
-        RVLM_HIP(hipMemsetAsync(h->dres, 0, (size_t)h->Mp * W * 4, s));
-        if (LP) RVLM_HIP(hipMemsetAsync(h->dres_lp, 0, (size_t)h->Mp * W * sizeof(T), s));
+        if (!h->cls_tail) {   // with the class-token tail the last block's ln_1 backward overwrites the other rows
+            RVLM_HIP(hipMemsetAsync(h->dres, 0, (size_t)h->Mp * W * 4, s));
+            if (LP) RVLM_HIP(hipMemsetAsync(h->dres_lp, 0, (size_t)h->Mp * W * sizeof(T), s));
+        }
         if ((rc = layernorm_bwd<float, T>(h->d_pooled, W, h->xs[2 * L], (long)S * W, h->lnpost_w,
                                           h->mean_at(2 * L + 1), h->rstd_at(2 * L + 1), h->dres, (long)S * W,
                                           LP ? (T*)h->dres_lp : nullptr, (long)S * W, 0, B, W, s))) return rc;
@@ -519,7 +557,10 @@ static int backward_impl(rvlm_vit* h, const float* d_emb, int B, float* grad_x, 
             if ((rc = attention_bwd<T>(h, s, h->qkv[l], h->attn_o[l], h->d_o, h->lse[l], h->dqkv, B))) return rc;
         }
         }
-        {
+        if (h->cls_tail && l == L - 1) {
+            PROF("gemm_qkv_bwd", 2.0 * M * W * 2 * W + 2.0 * B * W * 3 * W, 0);
+            if ((rc = qkv_tail_bwd(h, s, h->dqkv, y, h->d_ln, B))) return rc;
+        } else {
             PROF("gemm_qkv_bwd", 2.0 * M * W * 3 * W, 0);
             if ((rc = linear_dgrad<T>(h, s, h->dqkv, 3 * W, M, 3 * W, W, y.w_in, W, y.w_in_t, EPI_BF16, h->d_ln, W,
                                       nullptr))) return rc;
@@ -527,8 +568,8 @@ static int backward_impl(rvlm_vit* h, const float* d_emb, int B, float* grad_x, 
         {
             PROF("layernorm_bwd", 0, (double)M * W * (12 + 2 * sizeof(T)));
             if ((rc = layernorm_bwd<T, T>((const T*)h->d_ln, W, h->xs[2 * l], W, y.ln1_w, h->mean_at(1 + 2 * l),
-                                          h->rstd_at(1 + 2 * l), h->dres, W, LP ? (T*)h->dres_lp : nullptr, W, 1,
-                                          M, W, s))) return rc;
+                                          h->rstd_at(1 + 2 * l), h->dres, W, LP ? (T*)h->dres_lp : nullptr, W,
+                                          (h->cls_tail && l == L - 1) ? -S : 1, M, W, s))) return rc;
         }
     }
     {
@@ -637,8 +678,10 @@ static int backward_params_impl(rvlm_vit* h, const float* d_emb, int B, const rv
     if ((rc = ln_param_grad<float>(h->d_pooled, W, h->xs[2 * L], (long)S * W, h->mean_at(2 * L + 1),
                                    h->rstd_at(2 * L + 1), B, W, G(gw->ln_post_weight), G(gw->ln_post_bias), acc, s)))
         return rc;
-    RVLM_HIP(hipMemsetAsync(h->dres, 0, (size_t)h->Mp * W * 4, s));
-    if (LP) RVLM_HIP(hipMemsetAsync(h->dres_lp, 0, (size_t)h->Mp * W * sizeof(T), s));
+    if (!h->cls_tail) {
+        RVLM_HIP(hipMemsetAsync(h->dres, 0, (size_t)h->Mp * W * 4, s));
+        if (LP) RVLM_HIP(hipMemsetAsync(h->dres_lp, 0, (size_t)h->Mp * W * sizeof(T), s));
+    }
     if ((rc = layernorm_bwd<float, T>(h->d_pooled, W, h->xs[2 * L], (long)S * W, h->lnpost_w, h->mean_at(2 * L + 1),
                                       h->rstd_at(2 * L + 1), h->dres, (long)S * W, LP ? (T*)h->dres_lp : nullptr,
                                       (long)S * W, 0, B, W, s))) return rc;
@@ -685,7 +728,8 @@ static int backward_params_impl(rvlm_vit* h, const float* d_emb, int B, const rv
         if ((rc = ln_param_grad<T>((const T*)h->d_ln, W, h->xs[2 * l], W, h->mean_at(1 + 2 * l), h->rstd_at(1 + 2 * l),
                                    M, W, G(gb.ln_1_weight), G(gb.ln_1_bias), acc, s))) return rc;
         if ((rc = layernorm_bwd<T, T>((const T*)h->d_ln, W, h->xs[2 * l], W, y.ln1_w, h->mean_at(1 + 2 * l),
-                                      h->rstd_at(1 + 2 * l), h->dres, W, LP ? (T*)h->dres_lp : nullptr, W, 1, M, W, s)))
+                                      h->rstd_at(1 + 2 * l), h->dres, W, LP ? (T*)h->dres_lp : nullptr, W,
+                                      tail ? -S : 1, M, W, s)))
             return rc;
     }
     // ---- embeddings: ln_pre, positional / class embedding, conv1 ----

@@ -62,7 +62,8 @@ template <typename TO>
 int layernorm_fwd(const float* x, long ldx, const float* gamma, const float* beta, TO* y, long ldy,
                   float* mean, float* rstd, int M, int W, hipStream_t s);
 // dres[m,:] (+)= LN'(dy[m,:]) ; optionally also writes dres as TB (A operand of the next dgrad GEMM)
-// accumulate=0 overwrites dres.
+// accumulate=0 overwrites dres; accumulate=-S accumulates on rows that are multiples of S only (the other rows of
+// dres are overwritten: the class-token tail leaves a gradient on the class rows and garbage elsewhere).
 template <typename TI, typename TB>
 int layernorm_bwd(const TI* dy, long lddy, const float* x, long ldx, const float* gamma,
                   const float* mean, const float* rstd, float* dres, long lddres, TB* dres_lp,

@@ -157,6 +157,7 @@ layernorm_bwd_kernel(const TI* __restrict__ dy, long lddy, const float* __restri
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= M) return;
+    if (accumulate < 0) accumulate = (row % -accumulate) == 0;     // -S: only the class-token rows hold a gradient yet
     const float mu = mean[row], rs = rstd[row];
     const TI* dyr = dy + (long)row * lddy;
     const float* xr = x + (long)row * ldx;
@@ -204,6 +205,7 @@ layernorm_bwd8_kernel(const bf16_t* __restrict__ dy, long lddy, const float* __r
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= M) return;
+    if (accumulate < 0) accumulate = (row % -accumulate) == 0;
     const float mu = mean[row], rs = rstd[row];
     const bf16_t* dyr = dy + (long)row * lddy + lane * 8;
     const float* xr = x + (long)row * ldx + lane * 8;
