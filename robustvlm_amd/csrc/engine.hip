@@ -15,7 +15,9 @@
 namespace rvlm {
 void attn_set_use_tr(int on);
 void gemm_set_splitk_scratch(float* ptr, size_t bytes);
+void gemm_get_splitk_scratch(float** ptr, size_t* bytes);
 void set_reduce_scratch(float* p, size_t floats);
+void get_reduce_scratch(float** p, size_t* floats);
 
 struct Layer {
     float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *b_in, *b_out, *b_fc, *b_proj;
@@ -910,6 +912,13 @@ extern "C" int rvlm_vit_destroy(rvlm_vit* h) {
     if (!h) return RVLM_OK;
     (void)hipDeviceSynchronize();
     for (auto& r : h->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    {   // the process-wide scratch pointers must not outlive this handle's buffers
+        float* p; size_t n;
+        gemm_get_splitk_scratch(&p, &n);
+        if (p && p == h->splitk_scratch) gemm_set_splitk_scratch(nullptr, 0);
+        get_reduce_scratch(&p, &n);
+        if (p && p == h->red_scratch) set_reduce_scratch(nullptr, 0);
+    }
     for (void* p : h->allocs) (void)hipFree(p);
     delete h;
     return RVLM_OK;

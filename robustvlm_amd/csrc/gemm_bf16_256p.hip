@@ -141,6 +141,9 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const int ntiles = tiles_m * tiles_n;
     constexpr bool OUT_F32 = (EPI == EPI_F32_RESID || EPI == EPI_F32);
+    // phase offset (performance only): with every workgroup in lockstep the fp32 epilogues' HBM bursts coincide chip-wide
+    if (p.stagger > 0 && ((blockIdx.x >> 3) & 1))
+        for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -603,6 +606,9 @@ int gemm_bf16_nt_256p(const GemmBf16& p, int* rows_done, hipStream_t s) {
     // the remainder rows ride along in the same launch (strip_tail) unless RVLM_GEMM_TAIL=0 / an ablation build is on
     static int tail_on = -1;
     if (tail_on < 0) { const char* e = getenv("RVLM_GEMM_TAIL"); tail_on = e ? atoi(e) : 1; }
+    static int stagger = -1;
+    if (stagger < 0) { const char* e = getenv("RVLM_GEMM_STAGGER"); stagger = e ? atoi(e) : 0; }
+    if (q.epi == EPI_F32_RESID) q.stagger = stagger;
     const bool tail = tail_on && g_persist_ablate == 0 && p.batch_m_rows == 0 && p.M > q.M;
     const int m_total = tail ? p.M : q.M;
     int rc;

@@ -50,6 +50,7 @@ struct GemmBf16 {
     const float* residual = nullptr;    // EPI_F32_RESID (ld = ldo)
     int act = RVLM_ACT_QUICK_GELU;
     unsigned long long* trace = nullptr;   // persistent kernel only: per-tile s_memtime stamps (test hook)
+    int stagger = 0;                    // persistent kernel only: odd workgroup groups start stagger x ~4 us late
     int batch_m_rows = 0;               // persistent kernel only, > 0: batched form - rows [b*batch_m_rows, ...) of A meet
                                         // rows [b*N, (b+1)*N) of Bw (the split-K weight-gradient GEMM, gemm_bf16_wgrad)
 };

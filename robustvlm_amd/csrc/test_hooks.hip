@@ -31,11 +31,12 @@ extern "C" int rvlm_k_gemm_bf16_nt(const uint16_t* A, long lda, const uint16_t* 
                                    int K, int a_rows, int epi, const float* bias, void* out, long ldo,
                                    uint16_t* out_pre, const uint16_t* h_pre, const float* residual, int act,
                                    rvlm_stream_t stream) {
-    static float* scratch = nullptr;      // split-K slabs for the remainder rows (test surface only)
-    if (!scratch) {
-        const size_t bytes = (size_t)8 * 256 * 4096 * sizeof(float);
-        if (hipMalloc((void**)&scratch, bytes) == hipSuccess) gemm_set_splitk_scratch(scratch, bytes);
-    }
+    // split-K slabs for few-row problems (test surface only).  Bound on EVERY call: the pointer is process-wide and an
+    // engine handle created (and destroyed) by an earlier test may have left its own buffer there.
+    static float* scratch = nullptr;
+    const size_t bytes = (size_t)8 * 512 * 4096 * sizeof(float);
+    if (!scratch && hipMalloc((void**)&scratch, bytes) != hipSuccess) scratch = nullptr;
+    gemm_set_splitk_scratch(scratch, scratch ? bytes : 0);
     GemmBf16 g;
     g.A = (const bf16_t*)A; g.lda = lda; g.Bw = (const bf16_t*)Bw; g.ldb = ldb; g.M = M; g.N = N; g.K = K;
     g.a_rows = a_rows; g.epi = epi; g.bias = bias; g.out = out; g.ldo = ldo; g.out_pre = (bf16_t*)out_pre;
