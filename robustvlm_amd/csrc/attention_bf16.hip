@@ -227,6 +227,153 @@ attn_fwd_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict__ o,
 }
 
 // =============================================================================================
+// forward, S = 32 NK + 1 (257 = 256 patch tokens + the class token): NK waves, no padded tiles.
+// The generic kernel pads S to NK + 1 tiles each way: 81 MFMA/softmax blocks for 64.5 blocks of work, and its 9th
+// wave (one valid query) makes 9 waves share 4 SIMDs.  Here wave w owns query tile w and walks the NK full key
+// tiles; the odd key (token S-1) is folded in with VALU dot products (one score per query: 32 FMAs + a shuffle, no
+// MFMA block); the odd query (row S-1) is split over the waves - wave w evaluates it against key tile w - and the NK
+// partial (max, sum, O) triples are merged through 2 KiB of LDS.
+// =============================================================================================
+template <int NK>
+__global__ void __launch_bounds__(NK * 64, 4)    // 4 waves per SIMD = two 8-wave workgroups per CU (128 VGPRs)
+attn_fwd_odd_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict__ o, long ldo,
+                    float* __restrict__ lse2, int H, int W, float scale_log2) {
+    constexpr int S = 32 * NK + 1, Sp = 32 * NK + 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Kt = smem;
+    char* Vt = smem + (size_t)Sp * 128;
+    float* mrg = (float*)(smem + (size_t)Sp * 256);     // [NK][66]: m, sum, O[64] of the odd query per key tile
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const bf16_t* base = qkv + (long)b * S * ld + h * 64;
+    stage_tile(Kt, base + W, ld, S, Sp, w, NK, lane);
+    stage_tile(Vt, base + 2 * W, ld, S, Sp, w, NK, lane);
+    __syncthreads();
+
+    const FragOffs fo = make_offs(lane);
+    constexpr float RESCALE_THR = 6.0f;
+    // row S-1 = 32 NK of a tile: ((row >> 1) & 7) == 0, i.e. its chunks are not swizzled
+    const char* kl = Kt + (S - 1) * 128;
+    const char* vl = Vt + (S - 1) * 128;
+
+    auto rescale = [&](float tmax, float& m, float& l, f32x16 (&oacc)[2]) {
+        if (__any(tmax > m + RESCALE_THR)) {
+            const float mnew = fmaxf(m, tmax);
+            const float alpha = EXP2(m - mnew);
+            l *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+            m = mnew;
+        }
+    };
+    auto block = [&](const bf16x8 (&qf)[4], int kt, float& m, float& l, f32x16 (&oacc)[2]) {
+        f32x16 sc = zero16();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) sc = MFMA(frag_rm(Kt, kt * 32, fo.rm[kk]), qf[kk], sc);
+        float tmax = sc[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sc[r]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * scale_log2;
+        rescale(tmax, m, l, oacc);
+        float psum = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sc[r] = EXP2(fmaf(sc[r], scale_log2, -m)); psum += sc[r]; }
+        l += psum;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 pb = pack_b(sc, ks);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) oacc[dt] = MFMA(frag_tr(Vt, kt * 32 + ks * 16, fo, dt), pb, oacc[dt]);
+        }
+    };
+    // the odd key: one score per query (this lane holds 32 of its query's 64 dims, lane ^ 32 the others)
+    auto odd_key = [&](const bf16x8 (&qf)[4], float& m, float& l, f32x16 (&oacc)[2]) {
+        float sc = 0.0f;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const bf16x8 kv = *(const bf16x8*)(kl + (kk * 2 + hi) * 16);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sc = fmaf((float)qf[kk][e], (float)kv[e], sc);
+        }
+        sc += __shfl_xor(sc, 32, 64);
+        rescale(sc * scale_log2, m, l, oacc);
+        const float pj = EXP2(fmaf(sc, scale_log2, -m));
+        if (hi == 0) l += pj;                       // l is a per-lane partial (summed over the two halves at the end)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const bf16x4 vv = *(const bf16x4*)(vl + (dt * 32 + 8 * g + 4 * hi) * 2);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) oacc[dt][g * 4 + e] = fmaf(pj, (float)vv[e], oacc[dt][g * 4 + e]);
+            }
+    };
+
+    {   // ---- this wave's 32 queries ----
+        const int q = w * 32 + l31;
+        bf16x8 qf[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) qf[kk] = frag_global(base, ld, q, kk, lane);
+        f32x16 oacc[2] = {zero16(), zero16()};
+        float m = -INFINITY, l = 0.0f;
+#pragma unroll 1
+        for (int kt = 0; kt < NK; ++kt) block(qf, kt, m, l, oacc);
+        odd_key(qf, m, l, oacc);
+        const float ltot = l + __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / ltot;
+        bf16_t* orow = o + ((long)b * S + q) * ldo + h * 64;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 ov;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ov[e] = (bf16_t)(oacc[dt][g * 4 + e] * inv);
+                *(bf16x4*)(orow + dt * 32 + 8 * g + 4 * hi) = ov;
+            }
+        if (hi == 0 && lse2) lse2[((long)b * H + h) * Sp + q] = m + log2f(ltot);
+    }
+    {   // ---- the odd query against key tile w (every MFMA column carries the same query) ----
+        bf16x8 qf[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) qf[kk] = frag_global(base, ld, S - 1, kk, lane);
+        f32x16 oacc[2] = {zero16(), zero16()};
+        float m = -INFINITY, l = 0.0f;
+        block(qf, w, m, l, oacc);
+        if (w == 0) odd_key(qf, m, l, oacc);
+        const float ltot = l + __shfl_xor(l, 32, 64);
+        if (l31 == 0) {
+            float* dst = mrg + w * 66;
+            if (hi == 0) { dst[0] = m; dst[1] = ltot; }
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dst[2 + dt * 32 + 8 * g + 4 * hi + e] = oacc[dt][g * 4 + e];
+        }
+    }
+    __syncthreads();
+    if (w == 0) {   // merge: lane = head dim
+        float M = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < NK; ++i) M = fmaxf(M, mrg[i * 66]);
+        float L = 0.0f, O = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NK; ++i) {
+            const float c = EXP2(mrg[i * 66] - M);
+            L = fmaf(mrg[i * 66 + 1], c, L);
+            O = fmaf(mrg[i * 66 + 2 + lane], c, O);
+        }
+        o[((long)b * S + S - 1) * ldo + h * 64 + lane] = (bf16_t)(O / L);
+        if (lane == 0 && lse2) lse2[((long)b * H + h) * Sp + S - 1] = M + log2f(L);
+    }
+}
+
+// =============================================================================================
 // backward prep: D[b,h,q] = sum_d dO[q,d] * O[q,d]
 // =============================================================================================
 __global__ void __launch_bounds__(256)
@@ -725,8 +872,17 @@ int attn_fwd_bf16(const bf16_t* qkv, long ldqkv, bf16_t* o, long ldo, float* lse
     int rc;
     // MINW = 5 caps the kernel at 96 VGPRs so that two 9-wave workgroups (2 x 74 KiB LDS) share a CU:
     // one workgroup's K/V staging then hides under the other's MFMA/softmax phase.
-    static int occ = -1;
+    static int occ = -1, odd = -1;
     if (occ < 0) { const char* e = getenv("RVLM_ATTN_OCC"); occ = e ? atoi(e) : 5; }
+    if (odd < 0) { const char* e = getenv("RVLM_ATTN_FWD_ODD"); odd = e ? atoi(e) : 1; }
+    if (odd && g_use_tr && S == 257) {   // 8 waves, no padded tiles (see attn_fwd_odd_kernel)
+        constexpr int NK = 8;
+        const size_t lds_o = (size_t)(32 * NK + 32) * 256 + (size_t)NK * 66 * sizeof(float);
+        if ((rc = set_lds(attn_fwd_odd_kernel<NK>, lds_o))) return rc;
+        hipLaunchKernelGGL((attn_fwd_odd_kernel<NK>), dim3(B * H), dim3(NK * 64), lds_o, s, qkv, ldqkv, o, ldo, lse, H, W, sl2);
+        RVLM_CHECK_LAUNCH();
+        return RVLM_OK;
+    }
 #define LAUNCH_FWD(TR, MW)                                                                                   \
     do {                                                                                                      \
         if ((rc = set_lds(attn_fwd_kernel<TR, MW>, lds_bytes))) return rc;                                   \

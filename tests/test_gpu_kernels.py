@@ -131,13 +131,15 @@ def test_attention_bf16_fwd_bwd(B, H, S, use_tr):
         l.rvlm_k_attn_set_use_tr(1)
 
 
-def test_attention_forced_large_scores():
-    """Online-softmax rescale path: one key dominates a query late in the sequence."""
+@pytest.mark.parametrize("qi,ki", [(5, 250), (7, 256), (256, 100), (256, 256), (256, 3)])
+def test_attention_forced_large_scores(qi, ki):
+    """Online-softmax rescale path: one key dominates a query late in the sequence - also for the odd key (token 256,
+    folded in by vector code at S = 257) and the odd query (split over the waves and merged through LDS)."""
     l = lib()
     B, H, S = 1, 1, 257
-    g = torch.Generator(device="cuda").manual_seed(11)
+    g = torch.Generator(device="cuda").manual_seed(11 + qi + ki)
     qkv = torch.randn(S, 192, generator=g, device=dev())
-    qkv[5, 0:64] = 6.0 * qkv[250, 64:128]          # q_5 . k_250 >> others (last key tile)
+    qkv[qi, 0:64] = 6.0 * qkv[ki, 64:128]          # q_qi . k_ki >> others
     qkv = qkv.bfloat16()
     o = torch.zeros(S, 64, dtype=torch.bfloat16, device=dev())
     lse = torch.zeros(288, device=dev())
@@ -145,6 +147,11 @@ def test_attention_forced_large_scores():
     torch.cuda.synchronize()
     ref = attn_ref(qkv, B, H, S)
     assert rel_max(o.float(), ref) < 2e-2
+    # lse (log2 domain of scale*log2e * q.k) of every row, incl. the odd one
+    q, k = qkv[:, 0:64].double(), qkv[:, 64:128].double()
+    sc = (q @ k.t()) * 0.125
+    lse_ref = torch.logsumexp(sc, dim=1) * 1.4426950408889634
+    assert torch.allclose(lse[:S].double().cpu(), lse_ref.cpu(), atol=2e-2)
 
 
 @pytest.mark.parametrize("M,W", [(37, 64), (50, 768), (257, 1024), (9, 128)])
