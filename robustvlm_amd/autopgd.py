@@ -107,52 +107,71 @@ class APGDAttack():
             crit = self.dlr_loss if self.loss == 'dlr' else self.dlr_loss_targeted
         return _apgd_linf_generic(self.model, crit, x, y, self.eps, self.n_iter, step0, False, x_init=start)
 
-    def perturb(self, x, y=None, best_loss=False, x_init=None):
-        """:param best_loss: if True the points attaining highest loss are returned, otherwise
-        adversarial examples (autopgd_base.py:453-548)."""
-        assert self.loss in ['ce', 'dlr']
+    # ---- shared pieces of the two perturb() flavours --------------------------------------------------------------
+    def _setup(self, x, y):
+        """Inputs on the attack device, labels (the clean prediction when y is None) and the mask of points that are
+        still classified correctly (autopgd_base.py:462-475 and :637-650 do the same preparation)."""
         _require_cuda(x, "x")
-        if y is not None and len(y.shape) == 0:
+        if y is not None and y.dim() == 0:
             x.unsqueeze_(0)
             y.unsqueeze_(0)
         self.init_hyperparam(x)
         x = x.detach().clone().float().to(self.device)
         with torch.no_grad():
-            y_pred = self.model(x).max(1)[1]
-        y = y_pred.detach().clone().long().to(self.device) if y is None \
-            else y.detach().clone().long().to(self.device)
-        adv = x.clone()
-        acc = y_pred == y
+            pred = self.model(x).max(1)[1]
+        y = (pred if y is None else y).detach().clone().long().to(self.device)
+        return x, y, pred == y
+
+    def _banner(self, acc):
         if self.verbose:
-            print('-------------------------- ', 'running {}-attack with epsilon {:.5f}'.format(
-                self.norm, self.eps), '--------------------------')
+            print('-------------------------- ', 'running {}-attack with epsilon {:.5f}'.format(self.norm, self.eps),
+                  '--------------------------')
             print('initial accuracy: {:.2%}'.format(acc.float().mean()))
-        startt = time.time()
-        if not best_loss:
-            torch.random.manual_seed(self.seed)
-            torch.cuda.random.manual_seed(self.seed)
-            for counter in range(self.n_restarts):
-                ind_to_fool = acc.nonzero().squeeze(1)
-                if ind_to_fool.numel() != 0:
-                    x_to_fool, y_to_fool = x[ind_to_fool].clone(), y[ind_to_fool].clone()
-                    _, acc_curr, _, adv_curr = self.attack_single_run(x_to_fool, y_to_fool)
-                    ind_curr = (acc_curr == 0).nonzero().squeeze(1)
-                    acc[ind_to_fool[ind_curr]] = 0
-                    adv[ind_to_fool[ind_curr]] = adv_curr[ind_curr].clone()
-                    if self.verbose:
-                        print('restart {} - robust accuracy: {:.2%}'.format(counter, acc.float().mean()),
-                              '- cum. time: {:.1f} s'.format(time.time() - startt))
-            return adv
-        adv_best = x.detach().clone()
-        loss_best = torch.ones([x.shape[0]]).to(self.device) * (-float('inf'))
-        for counter in range(self.n_restarts):
-            best_curr, _, loss_curr, _ = self.attack_single_run(x, y)
-            ind_curr = (loss_curr > loss_best).nonzero().squeeze(1)
-            adv_best[ind_curr] = best_curr[ind_curr] + 0.
-            loss_best[ind_curr] = loss_curr[ind_curr] + 0.
+
+    def _reseed(self):
+        torch.random.manual_seed(self.seed)
+        torch.cuda.random.manual_seed(self.seed)
+
+    def _attack_survivors(self, x, y, acc, adv, pick_target=None):
+        """One run over the points that are still robust; fooled points leave ``acc`` and get their adversarial
+        example written into ``adv`` (the loop body of autopgd_base.py:490-507 / :660-686)."""
+        todo = acc.nonzero().squeeze(1)
+        if todo.numel() == 0:
+            return
+        xs, ys = x[todo].clone(), y[todo].clone()
+        if pick_target is not None:
+            self.y_target = pick_target(xs)
+        _, still, _, cand = self.attack_single_run(xs, ys)
+        broken = (still == 0).nonzero().squeeze(1)
+        acc[todo[broken]] = 0
+        adv[todo[broken]] = cand[broken].clone()
+
+    def perturb(self, x, y=None, best_loss=False, x_init=None):
+        """:param best_loss: if True the points attaining highest loss are returned, otherwise
+        adversarial examples (autopgd_base.py:453-548)."""
+        assert self.loss in ['ce', 'dlr']
+        x, y, acc = self._setup(x, y)
+        self._banner(acc)
+        t_start = time.time()
+        if best_loss:
+            best = x.detach().clone()
+            best_val = torch.full([x.shape[0]], -float('inf'), device=self.device)
+            for r in range(self.n_restarts):
+                cand, _, val, _ = self.attack_single_run(x, y)
+                better = (val > best_val).nonzero().squeeze(1)
+                best[better] = cand[better] + 0.
+                best_val[better] = val[better] + 0.
+                if self.verbose:
+                    print('restart {} - loss: {:.5f}'.format(r, best_val.sum()))
+            return best
+        adv = x.clone()
+        self._reseed()
+        for r in range(self.n_restarts):
+            self._attack_survivors(x, y, acc, adv)
             if self.verbose:
-                print('restart {} - loss: {:.5f}'.format(counter, loss_best.sum()))
-        return adv_best
+                print('restart {} - robust accuracy: {:.2%}'.format(r, acc.float().mean()),
+                      '- cum. time: {:.1f} s'.format(time.time() - t_start))
+        return adv
 
 
 class APGDAttack_targeted(APGDAttack):
@@ -171,39 +190,21 @@ class APGDAttack_targeted(APGDAttack):
     def perturb(self, x, y=None, x_init=None):
         """:param x: clean images  :param y: clean labels, if None we use the predicted labels"""
         assert self.loss in ['dlr-targeted']
-        _require_cuda(x, "x")
-        if y is not None and len(y.shape) == 0:
-            x.unsqueeze_(0)
-            y.unsqueeze_(0)
-        self.init_hyperparam(x)
-        x = x.detach().clone().float().to(self.device)
-        with torch.no_grad():
-            y_pred = self.model(x).max(1)[1]
-        y = y_pred.detach().clone().long().to(self.device) if y is None \
-            else y.detach().clone().long().to(self.device)
+        x, y, acc = self._setup(x, y)
         adv = x.clone()
-        acc = y_pred == y
-        if self.verbose:
-            print('-------------------------- ', 'running {}-attack with epsilon {:.5f}'.format(
-                self.norm, self.eps), '--------------------------')
-            print('initial accuracy: {:.2%}'.format(acc.float().mean()))
-        startt = time.time()
-        torch.random.manual_seed(self.seed)
-        torch.cuda.random.manual_seed(self.seed)
-        for target_class in range(2, self.n_target_classes + 2):
-            for counter in range(self.n_restarts):
-                ind_to_fool = acc.nonzero().squeeze(1)
-                if ind_to_fool.numel() != 0:
-                    x_to_fool, y_to_fool = x[ind_to_fool].clone(), y[ind_to_fool].clone()
-                    with torch.no_grad():
-                        output = self.model(x_to_fool)
-                    self.y_target = output.sort(dim=1)[1][:, -target_class]
-                    _, acc_curr, _, adv_curr = self.attack_single_run(x_to_fool, y_to_fool)
-                    ind_curr = (acc_curr == 0).nonzero().squeeze(1)
-                    acc[ind_to_fool[ind_curr]] = 0
-                    adv[ind_to_fool[ind_curr]] = adv_curr[ind_curr].clone()
-                    if self.verbose:
-                        print('target class {}'.format(target_class),
-                              '- restart {} - robust accuracy: {:.2%}'.format(counter, acc.float().mean()),
-                              '- cum. time: {:.1f} s'.format(time.time() - startt))
+        self._banner(acc)
+        t_start = time.time()
+        self._reseed()
+        for rank in range(2, self.n_target_classes + 2):        # the rank-th most likely class of each point
+
+            def kth_class(xs, rank=rank):
+                with torch.no_grad():
+                    return self.model(xs).sort(dim=1)[1][:, -rank]
+
+            for r in range(self.n_restarts):
+                self._attack_survivors(x, y, acc, adv, pick_target=kth_class)
+                if self.verbose:
+                    print('target class {}'.format(rank),
+                          '- restart {} - robust accuracy: {:.2%}'.format(r, acc.float().mean()),
+                          '- cum. time: {:.1f} s'.format(time.time() - t_start))
         return adv
