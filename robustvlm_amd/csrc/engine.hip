@@ -152,6 +152,7 @@ static int conv_w(rvlm_vit* h, bf16_t** nk, bf16_t** t, const float* src, int ro
         int rc = dev_alloc(h, (void**)nk, (size_t)rows * cols_pad * 2); if (rc) return rc;
         rc = dev_alloc(h, (void**)t, (size_t)cols_pad * rows * 2); if (rc) return rc;
     }
+    if (convert_f32_to_bf16_pair(src, cols, *nk, cols_pad, *t, rows, rows, cols, s)) { RVLM_CHECK_LAUNCH(); return RVLM_OK; }
     int rc = convert_f32_to_bf16(src, cols, *nk, cols_pad, rows, cols, 0, s); if (rc) return rc;
     return convert_f32_to_bf16(src, cols, *t, rows, rows, cols, 1, s);
 }

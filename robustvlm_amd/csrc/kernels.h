@@ -128,7 +128,9 @@ int attn_cls_bwd_bf16(const bf16_t* qkv, long ldqkv, const bf16_t* o, long ldo, 
 // misc
 // ---------------------------------------------------------------------------------------------
 int convert_f32_to_bf16(const float* src, long lds_, bf16_t* dst, long ldd, int rows, int cols,
-                        int transpose, hipStream_t s);  // dst[c,r] if transpose
+                        int transpose, hipStream_t s);
+bool convert_f32_to_bf16_pair(const float* src, long lds_, bf16_t* nk, long ld_nk, bf16_t* t, long ld_t, int rows,
+                              int cols, hipStream_t s);  // dst[c,r] if transpose
 int scale_copy_f32(const float* src, float* dst, size_t n, float alpha, hipStream_t s);
 int fill_f32(float* dst, size_t n, float v, hipStream_t s);
 
