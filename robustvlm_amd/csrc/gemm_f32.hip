@@ -81,23 +81,25 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32 p) {
 
 // ---- few-row problems (the projection head: M = batch).  The 64x64-tile kernel gives them a couple of dozen
 // workgroups (220 us for 128 x 768 x 1024); here every wave owns a 4-row strip and the chip is covered.
-// NN: C[m, n] = alpha * sum_k A[m, k] B[k, n]  (A row-major, B with n contiguous).  Lanes = 64 consecutive n; the A
-// values are wave-uniform.  Same k-ordered fmaf chain as the tiled kernel -> identical results.
+// NN: C[m, n] = alpha * sum_k A[m, k] B[k, n]  (A row-major, B with n contiguous).  A workgroup owns 4 rows x 64
+// columns; its 4 waves split K (the chip holds ~1.5 of these waves per CU, so the loop is bound by load latency: K/4
+// steps per wave instead of K), lanes = 64 consecutive n, the A values are wave-uniform scalar loads; the four partial
+// sums are combined in wave order through LDS (deterministic; associates differently from the tiled kernel).
 __global__ void __launch_bounds__(256) gemm_f32_skinny_nn_kernel(GemmF32 p) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ float part[4][4][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = blockIdx.x * 64 + lane;
-    const int m0 = (blockIdx.y * 4 + wave) * 4;
-    if (m0 >= p.M) return;
+    const int m0 = blockIdx.y * 4;
     const int nc = min(n, p.N - 1);
+    const int kc = (p.K + 3) >> 2, k0 = wave * kc, k1 = min(p.K, k0 + kc);
     const float* __restrict__ Bp = p.B + (long)nc * p.sbn;
     const float* __restrict__ A0 = p.A + (long)min(m0, p.M - 1) * p.sam;
     const float* __restrict__ A1 = p.A + (long)min(m0 + 1, p.M - 1) * p.sam;
     const float* __restrict__ A2 = p.A + (long)min(m0 + 2, p.M - 1) * p.sam;
     const float* __restrict__ A3 = p.A + (long)min(m0 + 3, p.M - 1) * p.sam;
     float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f;
-    int k = 0;
-    // 32 independent B loads in flight per wave: with ~1.5 waves per CU the loop is bound by load latency
-    for (; k + 32 <= p.K; k += 32) {
+    int k = k0;
+    for (; k + 32 <= k1; k += 32) {
         float b[32];
 #pragma unroll
         for (int u = 0; u < 32; ++u) b[u] = Bp[(long)(k + u) * p.sbk];
@@ -107,15 +109,17 @@ __global__ void __launch_bounds__(256) gemm_f32_skinny_nn_kernel(GemmF32 p) {
             c2 = fmaf(A2[k + u], b[u], c2); c3 = fmaf(A3[k + u], b[u], c3);
         }
     }
-    for (; k < p.K; ++k) {
+    for (; k < k1; ++k) {
         const float b = Bp[(long)k * p.sbk];
         c0 = fmaf(A0[k], b, c0); c1 = fmaf(A1[k], b, c1); c2 = fmaf(A2[k], b, c2); c3 = fmaf(A3[k], b, c3);
     }
-    if (n >= p.N) return;
-    const float c[4] = {c0, c1, c2, c3};
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-        if (m0 + i < p.M) p.C[(long)(m0 + i) * p.scm + n] = p.alpha * c[i];
+    part[wave][0][lane] = c0; part[wave][1][lane] = c1; part[wave][2][lane] = c2; part[wave][3][lane] = c3;
+    __syncthreads();
+    const int m = m0 + wave;               // wave w finishes row w
+    if (n < p.N && m < p.M) {
+        const float v = ((part[0][wave][lane] + part[1][wave][lane]) + part[2][wave][lane]) + part[3][wave][lane];
+        p.C[(long)m * p.scm + n] = p.alpha * v;
+    }
 }
 // NT: C[m, n] = alpha * sum_k A[m, k] B[n, k]  (both K-contiguous).  A wave owns a 4 x 4 output block, lanes stride K.
 __global__ void __launch_bounds__(256) gemm_f32_skinny_nt_kernel(GemmF32 p) {
@@ -159,7 +163,7 @@ int gemm_f32(const GemmF32& p, hipStream_t s) {
                        p.scn == 1;
     if (plain && p.M <= 512 && p.K >= 256 && p.sak == 1 && (long)cdiv(p.N, 64) * cdiv(p.M, 64) < 128) {
         if (p.sbn == 1) {
-            hipLaunchKernelGGL(gemm_f32_skinny_nn_kernel, dim3(cdiv(p.N, 64), cdiv(p.M, 16)), dim3(256), 0, s, p);
+            hipLaunchKernelGGL(gemm_f32_skinny_nn_kernel, dim3(cdiv(p.N, 64), cdiv(p.M, 4)), dim3(256), 0, s, p);
             RVLM_CHECK_LAUNCH();
             return RVLM_OK;
         }
