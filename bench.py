@@ -255,7 +255,7 @@ def main():
             except Exception:
                 traffic = None
         res["roofline"] = {
-            "bound": "mfma", "kernel": "gemm_bf16_nt_256p_kernel (QKV/out-proj/fc1/fc2, fwd + dgrad; + 128-row remainder launches)",
+            "bound": "mfma", "kernel": "gemm_bf16_nt_256p_kernel (QKV/out-proj/fc1/fc2, fwd + dgrad; the 128 remainder rows ride in the same launch)",
             "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
             "traffic": traffic, "traffic_unit": "bytes per GEMM launch (fabric side: 2*FETCH_SIZE + WRITE_SIZE)",
             "traffic_source": traffic_src,

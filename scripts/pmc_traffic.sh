@@ -38,8 +38,8 @@ out = {
     "gemm_logical_launches": logical,
     "gemm_bytes_per_logical_launch": round(total / max(logical, 1)),
     "note": "gemm_bytes_per_logical_launch = sum over every gemm_bf16 / splitk_reduce kernel of launches x (2*FETCH_SIZE + "
-            "WRITE_SIZE) x 1024, divided by the number of persistent-kernel launches (a logical GEMM = its 256x256 launch + "
-            "its 128-row remainder launches)",
+            "WRITE_SIZE) x 1024, divided by the number of persistent-kernel launches (a logical GEMM = its 256x256 launch; the few-row "
+            "class-token-tail launches are included in the numerator)",
 }
 json.dump(out, open(f"{root}/gpurun_out/pmc_hbm_traffic.json", "w"), indent=1)
 print(json.dumps({k: out[k] for k in ("gemm_logical_launches", "gemm_bytes_per_logical_launch")}))
