@@ -36,7 +36,11 @@ template <int EPI, int ACT>
 __device__ __forceinline__ void strip_tail(const GemmBf16& p, int m_done, int m_total, char* lds, int w, int lane) {
     constexpr int UMAX = 2;
     const int rem = m_total - m_done;
-    const int row_groups = (rem + 31) >> 5, col_groups = p.N >> 5;
+    const int col_groups = p.N >> 5;
+    // 32-row groups; 16-row groups (the upper MFMA rows duplicate the lower ones) when that is what it takes to give
+    // every workgroup a unit - the strip is bound by the bytes one CU can pull, not by MFMA work
+    const int RG = (((rem + 31) >> 5) * col_groups < (int)gridDim.x) ? 16 : 32;
+    const int row_groups = (rem + RG - 1) / RG;
     int u = (row_groups * col_groups + (int)gridDim.x - 1) / (int)gridDim.x;
     u = u < 1 ? 1 : (u > UMAX ? UMAX : u);
     const int units_per_row = (col_groups + u - 1) / u, total_units = row_groups * units_per_row;
@@ -45,9 +49,9 @@ __device__ __forceinline__ void strip_tail(const GemmBf16& p, int m_done, int m_
     float* red = (float*)lds;                       // [8 waves][UMAX][64 lanes][16]
     for (int unit = blockIdx.x; unit < total_units; unit += gridDim.x) {
         const int rg = unit / units_per_row, cu = unit - rg * units_per_row;
-        const int m0 = m_done + rg * 32, n0 = cu * u * 32;
+        const int m0 = m_done + rg * RG, n0 = cu * u * 32;
         const int nsub = min(u, col_groups - cu * u);
-        const bf16_t* ap = p.A + (long)min(m0 + l31, m_total - 1) * p.lda + w * kw + hi * 8;
+        const bf16_t* ap = p.A + (long)min(m0 + (l31 & (RG - 1)), m_total - 1) * p.lda + w * kw + hi * 8;
         const bf16_t* bp = p.Bw + (long)(n0 + l31) * p.ldb + w * kw + hi * 8;
         f32x16 acc[UMAX];
 #pragma unroll
@@ -111,7 +115,7 @@ __device__ __forceinline__ void strip_tail(const GemmBf16& p, int m_done, int m_
             }
             const int r = 2 * w;
             const int n = n0 + j * 32 + 8 * (r >> 2) + 4 * hi + (r & 3);
-            if (m >= m_total) continue;
+            if (m >= m_total || l31 >= RG) continue;
             if (p.bias) { v0 += p.bias[n]; v1 += p.bias[n + 1]; }
             const long o = (long)m * p.ldo + n;
             if (EPI == EPI_BF16) {
