@@ -56,7 +56,7 @@ struct rvlm_vit {
     float* dres;  void* dres_lp;  void* d_o;  void* dqkv;  void* dh;  void* d_ln;  void* d_patch;
     float* dA0;   float* dsum;   float *d_raw, *d_pooled;
     float *scores, *dscores;   // fp32 mode [B,H,S,S]
-    float* splitk_scratch;     // fp32 slabs for the split-K remainder GEMMs (+ weight-gradient GEMMs when trainable)
+    float* splitk_scratch;     // fp32 slabs of the split-K few-row GEMMs (+ weight-gradient GEMMs when trainable)
     size_t splitk_bytes = 0;
     // class-token tail (bf16 mode): in the last block only the class token's row is live downstream of the attention
     // (the output is ln_post(x[:, 0]) @ proj), so out-proj / MLP / their LayerNorm run on B rows and the attention on
@@ -874,7 +874,7 @@ extern "C" int rvlm_vit_create(const rvlm_vit_config* cfg, const rvlm_vit_weight
         }
     }
     {
-        // split-K slabs: 8 x <=256 rows x 4W columns for the remainder GEMMs; trainable handles also run
+        // split-K slabs: 8 x <=256 rows x 4W columns for the few-row GEMMs; trainable handles also run
         // the weight-gradient GEMMs split-K (few output tiles, K = all tokens): up to 3 x [3W, W] slabs
         size_t sk = (size_t)8 * 256 * 4 * W * sizeof(float);
         if (cfg->trainable > 0) sk = std::max(sk, (size_t)16 * W * W * sizeof(float));

@@ -130,11 +130,12 @@ gemm_bf16_nt_kernel(GemmBf16 p, int tiles_m, int tiles_n, int a_rows, int desync
     gemm_epilogue<EPI, 2, 2>(acc, p, m0 + wm * 64, n0 + wn * 64, lane, lds + w * EPI_LDS_BYTES_PER_WAVE);
 }
 
-// ---- split-K for the short "remainder" GEMMs ---------------------------------------------------------
-// The 256x256 kernel covers floor(M/256)*256 rows; the <=255 remaining rows (the 128 CLS-token rows at
-// B=128) are 0.4 % of the FLOPs but, as N/128 workgroups walking the whole K serially, cost 46-61 us at
-// K = 3072/4096 (latency-bound: ~1 us per 64-deep K-step).  They are split SPLITK ways along K into
-// fp32 slabs (deterministic: no atomics) and combined by a tiny reduce+epilogue kernel.
+// ---- split-K for few-row GEMMs ------------------------------------------------------------------------------
+// Few-row problems (the class-token tail: M = batch rows; with RVLM_GEMM_TAIL=0 also the <=255 remainder rows of a big
+// problem, which the persistent kernel otherwise computes in its own launch) are a handful of 128x128 tiles: as N/128
+// workgroups walking the whole K serially they cost 46-61 us at K = 3072/4096 (latency-bound: ~1 us per 64-deep
+// K-step).  They are split SPLITK ways along K into fp32 slabs (deterministic: no atomics) and combined by a tiny
+// reduce+epilogue kernel.
 template <int EPI>
 __global__ void __launch_bounds__(256)
 splitk_reduce_kernel(const float* __restrict__ slabs, int splitk, GemmBf16 p) {
@@ -333,7 +334,7 @@ int gemm_bf16_nt(const GemmBf16& p, hipStream_t s) {
     int done = 0;
     const int variant = gemm_variant();
     // few-row problems (the class-token rows of the last block: M = batch): a handful of 256x256 tiles cannot fill the
-    // chip - they take the 128x128 kernel with split-K below, like the remainder rows of the big problems
+    // chip - they take the 128x128 kernel with split-K below
     const bool small_m = p.M <= 512;
     // 1 or 2 (default): the persistent 256x256 kernel wherever the shape qualifies (N % 256 == 0, K % 128 == 0); it
     // beats both older kernels on every encoder shape (scripts/gemm_bench.py, profiles/).  RVLM_GEMM_PERSIST=0
