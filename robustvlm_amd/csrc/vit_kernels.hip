@@ -302,25 +302,26 @@ template int layernorm_bwd<float, bf16_t>(const float*, long, const float*, long
 // =============================================================================================
 // Patch im2col with (x + delta) and Normalize fused:  A0[row, col]
 // =============================================================================================
-template <typename T>
+// I = index type: int whenever every linear index fits 31 bits (64-bit div / mod cost ~100 instructions each here)
+template <typename T, typename I>
 __global__ void __launch_bounds__(256)
 im2col_kernel(const float* __restrict__ x, const float* __restrict__ delta, int B, int img, int P,
               float m0, float m1, float m2, float s0, float s1, float s2, T* __restrict__ A0,
               long lda, int Kpad) {
     const int g = img / P, PP = P * P, K = 3 * PP;
-    const long total = (long)B * g * g * Kpad;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (long)gridDim.x * blockDim.x) {
+    const I total = (I)B * g * g * Kpad;
+    for (I idx = (I)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (I)gridDim.x * blockDim.x) {
         const int col = (int)(idx % Kpad);
-        const long row = idx / Kpad;
+        const I row = idx / Kpad;
         float v = 0.0f;
         if (col < K) {
             const int c = col / PP, r = col - c * PP, i = r / P, j = r - i * P;
             const int px = (int)(row % g);
-            const long t = row / g;
+            const I t = row / g;
             const int py = (int)(t % g);
-            const long b = t / g;
-            const long xi = ((b * 3 + c) * img + (long)py * P + i) * img + (long)px * P + j;
+            const I b = t / g;
+            const I xi = ((b * 3 + c) * img + (I)py * P + i) * img + (I)px * P + j;
             float pix = x[xi];
             if (delta) pix = pix + delta[xi];                 // pgd_train.py:32  data_clean + perturbation
             const float mu = c == 0 ? m0 : (c == 1 ? m1 : m2);
@@ -337,8 +338,14 @@ int im2col_normalize(const float* x, const float* delta, int B, int img, int P, 
     const long total = (long)B * (img / P) * (img / P) * Kpad;
     int grid = (int)((total + 255) / 256);
     if (grid > 256 * 16) grid = 256 * 16;
-    hipLaunchKernelGGL((im2col_kernel<T>), dim3(grid), dim3(256), 0, s, x, delta, B, img, P,
-                       mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], A0, lda, Kpad);
+    const bool small = total < (1L << 30) && (long)B * 3 * img * img < (1L << 30) &&
+                       (long)B * (img / P) * (img / P) * lda < (1L << 30);
+    if (small)
+        hipLaunchKernelGGL((im2col_kernel<T, int>), dim3(grid), dim3(256), 0, s, x, delta, B, img, P,
+                           mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], A0, lda, Kpad);
+    else
+        hipLaunchKernelGGL((im2col_kernel<T, long>), dim3(grid), dim3(256), 0, s, x, delta, B, img, P,
+                           mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], A0, lda, Kpad);
     RVLM_CHECK_LAUNCH();
     return RVLM_OK;
 }
@@ -347,22 +354,22 @@ template int im2col_normalize<float>(const float*, const float*, int, int, int, 
 template int im2col_normalize<bf16_t>(const float*, const float*, int, int, int, const float*,
                                       const float*, bf16_t*, long, int, hipStream_t);
 
-template <typename T>
+template <typename T, typename I>
 __global__ void __launch_bounds__(256)
 col2im_kernel(const T* __restrict__ dA0, long lda, int B, int img, int P, float s0, float s1,
               float s2, float* __restrict__ grad_x) {
     const int g = img / P, PP = P * P;
-    const long total = (long)B * 3 * img * img;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (long)gridDim.x * blockDim.x) {
+    const I total = (I)B * 3 * img * img;
+    for (I idx = (I)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (I)gridDim.x * blockDim.x) {
         const int xx = (int)(idx % img);
-        long t = idx / img;
+        I t = idx / img;
         const int yy = (int)(t % img);
         t /= img;
         const int c = (int)(t % 3);
-        const long b = t / 3;
+        const I b = t / 3;
         const int py = yy / P, i = yy - py * P, px = xx / P, j = xx - px * P;
-        const long row = (b * g + py) * g + px;
+        const I row = (b * g + py) * g + px;
         const int col = c * PP + i * P + j;
         const float sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
         grad_x[idx] = to_f32(dA0[row * lda + col]) / sd;
@@ -375,8 +382,13 @@ int col2im_grad(const T* dA0, long lda, int B, int img, int P, const float* std3
     const long total = (long)B * 3 * img * img;
     int grid = (int)((total + 255) / 256);
     if (grid > 256 * 16) grid = 256 * 16;
-    hipLaunchKernelGGL((col2im_kernel<T>), dim3(grid), dim3(256), 0, s, dA0, lda, B, img, P, std3[0],
-                       std3[1], std3[2], grad_x);
+    const bool small = total < (1L << 30) && (long)B * (img / P) * (img / P) * lda < (1L << 30);
+    if (small)
+        hipLaunchKernelGGL((col2im_kernel<T, int>), dim3(grid), dim3(256), 0, s, dA0, lda, B, img, P, std3[0],
+                           std3[1], std3[2], grad_x);
+    else
+        hipLaunchKernelGGL((col2im_kernel<T, long>), dim3(grid), dim3(256), 0, s, dA0, lda, B, img, P, std3[0],
+                           std3[1], std3[2], grad_x);
     RVLM_CHECK_LAUNCH();
     return RVLM_OK;
 }
