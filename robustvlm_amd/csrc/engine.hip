@@ -14,10 +14,6 @@
 
 namespace rvlm {
 void attn_set_use_tr(int on);
-void gemm_set_splitk_scratch(float* ptr, size_t bytes);
-void gemm_get_splitk_scratch(float** ptr, size_t* bytes);
-void set_reduce_scratch(float* p, size_t floats);
-void get_reduce_scratch(float** p, size_t* floats);
 
 struct Layer {
     float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *b_in, *b_out, *b_fc, *b_proj;
@@ -195,6 +191,9 @@ static int load_weights(rvlm_vit* h, const rvlm_vit_weights* w, hipStream_t s, b
     return RVLM_OK;
 }
 
+// every GEMM descriptor carries its handle's split-K slab scratch (no process-wide state: handles coexist)
+static inline void with_scratch(const rvlm_vit* h, GemmBf16& g) { g.splitk = h->splitk_scratch; g.splitk_bytes = h->splitk_bytes; }
+
 // ---- linear layers (dispatch on precision) ---------------------------------------------------
 // forward: out[M,N] = epi(A[M,K] @ Wt[N,K]^T + bias)
 template <typename T>
@@ -209,6 +208,7 @@ int linear_fwd<bf16_t>(rvlm_vit* h, hipStream_t s, const void* A, long lda, int 
     g.A = (const bf16_t*)A; g.lda = lda; g.Bw = w_nk; g.ldb = K; g.M = M; g.N = N; g.K = K;
     g.a_rows = a_rows > 0 ? a_rows : (int)round_up(M, 128); g.epi = epi; g.bias = bias; g.out = out; g.ldo = ldo;
     g.out_pre = (bf16_t*)out_pre; g.residual = residual; g.act = h->cfg.act;
+    with_scratch(h, g);
     return gemm_bf16_nt(g, s);
 }
 template <>
@@ -236,6 +236,7 @@ int linear_dgrad<bf16_t>(rvlm_vit* h, hipStream_t s, const void* dY, long lddy, 
     g.A = (const bf16_t*)dY; g.lda = lddy; g.Bw = w_t; g.ldb = N; g.M = M; g.N = K; g.K = N;
     g.a_rows = a_rows > 0 ? a_rows : (int)round_up(M, 128); g.epi = epi; g.out = out; g.ldo = ldo;
     g.h_pre = (const bf16_t*)h_pre; g.act = h->cfg.act;
+    with_scratch(h, g);
     return gemm_bf16_nt(g, s);
 }
 template <>
@@ -335,12 +336,14 @@ static int qkv_tail_fwd(rvlm_vit* h, hipStream_t s, const void* ln1o, const Laye
     g.A = (const bf16_t*)ln1o; g.lda = W; g.Bw = y.w_in_nk + (size_t)W * W; g.ldb = W;
     g.M = M; g.N = 2 * W; g.K = W; g.a_rows = (int)round_up(M, 128); g.epi = EPI_BF16;
     g.bias = y.b_in + W; g.out = (bf16_t*)qkv + W; g.ldo = 3 * W; g.act = h->cfg.act;
+    with_scratch(h, g);
     int rc = gemm_bf16_nt(g, s);
     if (rc) return rc;
     GemmBf16 q;
     q.A = (const bf16_t*)ln1o; q.lda = (long)S * W; q.Bw = y.w_in_nk; q.ldb = W;
     q.M = B; q.N = W; q.K = W; q.a_rows = B; q.epi = EPI_BF16;
     q.bias = y.b_in; q.out = qkv; q.ldo = (long)S * 3 * W; q.act = h->cfg.act;
+    with_scratch(h, q);
     return gemm_bf16_nt(q, s);
 }
 static int qkv_tail_bwd(rvlm_vit* h, hipStream_t s, const void* dqkv, const Layer& y, void* d_ln, int B) {
@@ -349,30 +352,24 @@ static int qkv_tail_bwd(rvlm_vit* h, hipStream_t s, const void* dqkv, const Laye
     g.A = (const bf16_t*)dqkv + W; g.lda = 3 * W; g.Bw = y.w_in_t + W; g.ldb = 3 * W;
     g.M = M; g.N = W; g.K = 2 * W; g.a_rows = (int)round_up(M, 128); g.epi = EPI_BF16;
     g.out = d_ln; g.ldo = W; g.act = h->cfg.act;
+    with_scratch(h, g);
     int rc = gemm_bf16_nt(g, s);
     if (rc) return rc;
     GemmBf16 q;
     q.A = (const bf16_t*)dqkv; q.lda = (long)S * 3 * W; q.Bw = y.w_in_t; q.ldb = 3 * W;
     q.M = B; q.N = W; q.K = 3 * W; q.a_rows = B; q.epi = EPI_BF16;
     q.out = d_ln; q.ldo = (long)S * W; q.act = h->cfg.act;
+    with_scratch(h, q);
     return gemm_bf16_nt(q, s);
 }
 
 // ---- forward -----------------------------------------------------------------------------------
-// The GEMM / reduction scratch pointers are process-wide: every entry that launches encoder kernels points them at
-// this handle's buffers first (several handles coexist - e.g. the frozen original encoder next to the trained one).
-static void bind_scratch(rvlm_vit* h) {
-    gemm_set_splitk_scratch(h->splitk_scratch, h->splitk_bytes);
-    set_reduce_scratch(h->red_scratch, h->red_floats);
-}
-
 template <typename T>
 static int forward_impl(rvlm_vit* h, const float* x, const float* delta, int B, int normalize, int save,
                         float* out_emb, hipStream_t s) {
     const int S = h->S, W = h->W, L = h->L, D = h->D, M = B * S, M0 = B * h->G * h->G;
     const double attn_flops = 4.0 * B * h->H * (double)S * S * 64;
     int rc;
-    bind_scratch(h);
     {
         PROF("patch_im2col", 0, (double)B * 3 * h->img * h->img * (delta ? 8 : 4) + (double)M0 * h->Kpad * sizeof(T));
         if ((rc = im2col_normalize<T>(x, delta, B, h->img, h->P, h->cfg.mean, h->cfg.std, (T*)h->A0, h->Kpad, h->Kpad, s))) return rc;
@@ -383,6 +380,7 @@ static int forward_impl(rvlm_vit* h, const float* x, const float* delta, int B, 
             GemmBf16 g;
             g.A = (const bf16_t*)h->A0; g.lda = h->Kpad; g.Bw = h->conv_nk; g.ldb = h->Kpad;
             g.M = M0; g.N = W; g.K = h->Kpad; g.a_rows = h->Mp0; g.epi = EPI_F32; g.out = h->patch_out; g.ldo = W;
+            with_scratch(h, g);
             rc = gemm_bf16_nt(g, s);
         } else {
             rc = linear_fwd<float>(h, s, h->A0, h->Kpad, M0, W, h->Kp, h->conv_f32, nullptr, nullptr, EPI_F32,
@@ -488,7 +486,6 @@ static int backward_impl(rvlm_vit* h, const float* d_emb, int B, float* grad_x, 
     const double attn_flops = 8.0 * B * h->H * (double)S * S * 64;
     constexpr bool LP = !std::is_same<T, float>::value;
     int rc;
-    bind_scratch(h);
     {
         PROF("head_bwd", 2.0 * B * W * D, 0);
         const float* d_raw = d_emb;
@@ -586,6 +583,7 @@ static int backward_impl(rvlm_vit* h, const float* d_emb, int B, float* grad_x, 
             GemmBf16 g;
             g.A = (const bf16_t*)h->d_patch; g.lda = W; g.Bw = h->conv_t; g.ldb = W;
             g.M = M0; g.N = h->Kpad; g.K = W; g.a_rows = h->Mp0; g.epi = EPI_F32; g.out = h->dA0; g.ldo = h->Kpad;
+            with_scratch(h, g);
             rc = gemm_bf16_nt(g, s);
         } else {
             GemmF32 g;
@@ -616,13 +614,16 @@ int wgrad<bf16_t>(rvlm_vit* h, hipStream_t s, const void* dY, long lddy, const v
     // contraction over the token dimension: both operands are transposed so that it is the contiguous (MFMA k)
     // dimension.  Encoder shapes: token chunks [splits][.][Kc] + one batched launch of the persistent kernel.
     int rc, splits = 0, Kc = 0;
-    if (wgrad_split_plan(M, N, K, &splits, &Kc) && (long)splits * Kc <= h->Mpt) {
-        if ((rc = transpose_split((const bf16_t*)dY, lddy, M, N, (bf16_t*)h->tA, Kc, splits, dbias, accumulate, s))) return rc;
-        if ((rc = transpose_split((const bf16_t*)X, ldx, M, K, (bf16_t*)h->tB, Kc, splits, nullptr, 0, s))) return rc;
-        return gemm_bf16_wgrad_split((const bf16_t*)h->tA, (const bf16_t*)h->tB, splits, Kc, N, K, dW, lddw, accumulate, s);
+    if (wgrad_split_plan(M, N, K, h->splitk_bytes, &splits, &Kc) && (long)splits * Kc <= h->Mpt) {
+        if ((rc = transpose_split((const bf16_t*)dY, lddy, M, N, (bf16_t*)h->tA, Kc, splits, dbias, accumulate, h->red_scratch,
+                                  h->red_floats, s))) return rc;
+        if ((rc = transpose_split((const bf16_t*)X, ldx, M, K, (bf16_t*)h->tB, Kc, splits, nullptr, 0, nullptr, 0, s))) return rc;
+        return gemm_bf16_wgrad_split((const bf16_t*)h->tA, (const bf16_t*)h->tB, splits, Kc, N, K, dW, lddw, accumulate,
+                                     h->splitk_scratch, h->splitk_bytes, s);
     }
     // other shapes (conv1: K = 3*P*P): whole-K transposes zero-padded to a multiple of 64, NT GEMM as usual
-    if (dbias && (rc = colsum<bf16_t>((const bf16_t*)dY, lddy, M, N, dbias, accumulate, s))) return rc;
+    if (dbias && (rc = colsum<bf16_t>((const bf16_t*)dY, lddy, M, N, dbias, accumulate, h->red_scratch, h->red_floats, s)))
+        return rc;
     const int Mk = (int)round_up(M, 64);
     if ((rc = transpose_pad<bf16_t>((const bf16_t*)dY, lddy, M, N, (bf16_t*)h->tA, h->Mpt, Mk, s))) return rc;
     if ((rc = transpose_pad<bf16_t>((const bf16_t*)X, ldx, M, K, (bf16_t*)h->tB, h->Mpt, Mk, s))) return rc;
@@ -631,13 +632,15 @@ int wgrad<bf16_t>(rvlm_vit* h, hipStream_t s, const void* dY, long lddy, const v
     g.M = N; g.N = K; g.K = Mk; g.a_rows = 4 * h->W;
     g.epi = accumulate ? EPI_F32_RESID : EPI_F32; g.residual = accumulate ? dW : nullptr;
     g.out = dW; g.ldo = lddw;
+    with_scratch(h, g);
     return gemm_bf16_nt(g, s);
 }
 template <>
-int wgrad<float>(rvlm_vit*, hipStream_t s, const void* dY, long lddy, const void* X, long ldx, int M, int N, int K,
+int wgrad<float>(rvlm_vit* h, hipStream_t s, const void* dY, long lddy, const void* X, long ldx, int M, int N, int K,
                  float* dW, long lddw, int accumulate, float* dbias) {
     int rc;
-    if (dbias && (rc = colsum<float>((const float*)dY, lddy, M, N, dbias, accumulate, s))) return rc;
+    if (dbias && (rc = colsum<float>((const float*)dY, lddy, M, N, dbias, accumulate, h->red_scratch, h->red_floats, s)))
+        return rc;
     GemmF32 g;
     g.A = (const float*)dY; g.sam = 1; g.sak = lddy;      // (m_out = n, k = token)
     g.B = (const float*)X; g.sbn = 1; g.sbk = ldx;        // (n_out = k, k = token)
@@ -654,7 +657,6 @@ static int backward_params_impl(rvlm_vit* h, const float* d_emb, int B, const rv
     constexpr bool LP = !std::is_same<T, float>::value;
     auto G = [](const float* p) { return const_cast<float*>(p); };
     int rc;
-    bind_scratch(h);
     // ---- head ----
     const float* d_raw = d_emb;
     if (h->saved_norm) {
@@ -679,7 +681,8 @@ static int backward_params_impl(rvlm_vit* h, const float* d_emb, int B, const rv
         if ((rc = gemm_f32(g, s))) return rc;
     }
     if ((rc = ln_param_grad<float>(h->d_pooled, W, h->xs[2 * L], (long)S * W, h->mean_at(2 * L + 1),
-                                   h->rstd_at(2 * L + 1), B, W, G(gw->ln_post_weight), G(gw->ln_post_bias), acc, s)))
+                                   h->rstd_at(2 * L + 1), B, W, G(gw->ln_post_weight), G(gw->ln_post_bias), acc,
+                                   h->red_scratch, h->red_floats, s)))
         return rc;
     if (!h->cls_tail) {
         RVLM_HIP(hipMemsetAsync(h->dres, 0, (size_t)h->Mp * W * 4, s));
@@ -707,7 +710,8 @@ static int backward_params_impl(rvlm_vit* h, const float* d_emb, int B, const rv
         if ((rc = linear_dgrad<T>(h, s, h->dh, 4 * W, Mr, 4 * W, W, y.w_fc, W, y.w_fc_t, EPI_BF16, h->d_ln, W, nullptr)))
             return rc;
         if ((rc = ln_param_grad<T>((const T*)h->d_ln, W, h->xs[2 * l + 1], ldr, h->mean_at(2 + 2 * l),
-                                   h->rstd_at(2 + 2 * l), Mr, W, G(gb.ln_2_weight), G(gb.ln_2_bias), acc, s))) return rc;
+                                   h->rstd_at(2 + 2 * l), Mr, W, G(gb.ln_2_weight), G(gb.ln_2_bias), acc,
+                                   h->red_scratch, h->red_floats, s))) return rc;
         if ((rc = layernorm_bwd<T, T>((const T*)h->d_ln, W, h->xs[2 * l + 1], ldr, y.ln2_w, h->mean_at(2 + 2 * l),
                                       h->rstd_at(2 + 2 * l), h->dres, ldr, LP ? (T*)h->dres_lp : nullptr, ldr, 1, Mr, W, s)))
             return rc;
@@ -729,7 +733,8 @@ static int backward_params_impl(rvlm_vit* h, const float* d_emb, int B, const rv
         if ((rc = linear_dgrad<T>(h, s, h->dqkv, 3 * W, M, 3 * W, W, y.w_in, W, y.w_in_t, EPI_BF16, h->d_ln, W, nullptr)))
             return rc;
         if ((rc = ln_param_grad<T>((const T*)h->d_ln, W, h->xs[2 * l], W, h->mean_at(1 + 2 * l), h->rstd_at(1 + 2 * l),
-                                   M, W, G(gb.ln_1_weight), G(gb.ln_1_bias), acc, s))) return rc;
+                                   M, W, G(gb.ln_1_weight), G(gb.ln_1_bias), acc, h->red_scratch, h->red_floats, s)))
+            return rc;
         if ((rc = layernorm_bwd<T, T>((const T*)h->d_ln, W, h->xs[2 * l], W, y.ln1_w, h->mean_at(1 + 2 * l),
                                       h->rstd_at(1 + 2 * l), h->dres, W, LP ? (T*)h->dres_lp : nullptr, W,
                                       tail ? -S : 1, M, W, s)))
@@ -737,7 +742,7 @@ static int backward_params_impl(rvlm_vit* h, const float* d_emb, int B, const rv
     }
     // ---- embeddings: ln_pre, positional / class embedding, conv1 ----
     if ((rc = ln_param_grad<float>(h->dres, W, h->tokens, W, h->mean_at(0), h->rstd_at(0), M, W, G(gw->ln_pre_weight),
-                                   G(gw->ln_pre_bias), acc, s))) return rc;
+                                   G(gw->ln_pre_bias), acc, h->red_scratch, h->red_floats, s))) return rc;
     if ((rc = layernorm_bwd<float, float>(h->dres, W, h->tokens, W, h->lnpre_w, h->mean_at(0), h->rstd_at(0), h->dtok,
                                           W, nullptr, W, 0, M, W, s))) return rc;
     if ((rc = pos_cls_grad(h->dtok, W, B, S, W, G(gw->positional_embedding), G(gw->class_embedding), acc, s))) return rc;
@@ -913,13 +918,6 @@ extern "C" int rvlm_vit_destroy(rvlm_vit* h) {
     if (!h) return RVLM_OK;
     (void)hipDeviceSynchronize();
     for (auto& r : h->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
-    {   // the process-wide scratch pointers must not outlive this handle's buffers
-        float* p; size_t n;
-        gemm_get_splitk_scratch(&p, &n);
-        if (p && p == h->splitk_scratch) gemm_set_splitk_scratch(nullptr, 0);
-        get_reduce_scratch(&p, &n);
-        if (p && p == h->red_scratch) set_reduce_scratch(nullptr, 0);
-    }
     for (void* p : h->allocs) (void)hipFree(p);
     delete h;
     return RVLM_OK;

@@ -182,10 +182,6 @@ splitk_reduce_kernel(const float* __restrict__ slabs, int splitk, GemmBf16 p) {
     }
 }
 
-static float* g_splitk_scratch = nullptr;
-static size_t g_splitk_bytes = 0;
-void gemm_set_splitk_scratch(float* ptr, size_t bytes) { g_splitk_scratch = ptr; g_splitk_bytes = bytes; }
-void gemm_get_splitk_scratch(float** ptr, size_t* bytes) { *ptr = g_splitk_scratch; *bytes = g_splitk_bytes; }
 
 int gemm_bf16_nt_256(const GemmBf16& p, int* rows_done, hipStream_t s);
 int gemm_bf16_nt_256p(const GemmBf16& p, int* rows_done, hipStream_t s);
@@ -255,18 +251,20 @@ static int gemm_bf16_nt_128(const GemmBf16& p, hipStream_t s) {
 // tB = [splits][K][Kc] (token chunks of the transposed operands, written by transpose_split): one batched launch of
 // splits * (N/256) * (K/256) work items, fp32 slabs [splits][N][K], then the deterministic slab reduce.
 // Plan: enough splits to give every CU one work item (the W x W out-projection gradient has 16 output tiles).
-int wgrad_split_plan(int M, int N, int K, int* splits, int* Kc) {
+int wgrad_split_plan(int M, int N, int K, size_t slab_bytes, int* splits, int* Kc) {
     if (N % 256 != 0 || K % 256 != 0 || M < 256) return 0;
     const int tiles = (N / 256) * (K / 256), nk128 = cdiv(M, 128);
     int sp = std::max(1, std::min(16, 256 / tiles));
     sp = std::min(sp, nk128);
-    if (sp > 1 && (size_t)sp * N * K * sizeof(float) > g_splitk_bytes) return 0;
+    if (sp > 1 && (size_t)sp * N * K * sizeof(float) > slab_bytes) return 0;
     *splits = sp;
     *Kc = cdiv(nk128, sp) * 128;
     return 1;
 }
 int gemm_bf16_wgrad_split(const bf16_t* tA, const bf16_t* tB, int splits, int Kc, int N, int K, float* dW, long lddw,
-                          int accumulate, hipStream_t s) {
+                          int accumulate, float* slab, size_t slab_bytes, hipStream_t s) {
+    if (splits > 1 && (!slab || (size_t)splits * N * K * sizeof(float) > slab_bytes))
+        return fail(RVLM_ERR_STATE, "gemm_bf16_wgrad_split: slab scratch too small");
     GemmBf16 g;
     g.A = tA; g.lda = Kc; g.Bw = tB; g.ldb = Kc;
     g.M = splits * N; g.N = K; g.K = Kc;
@@ -275,7 +273,7 @@ int gemm_bf16_wgrad_split(const bf16_t* tA, const bf16_t* tB, int splits, int Kc
         g.epi = accumulate ? EPI_F32_RESID : EPI_F32; g.residual = accumulate ? dW : nullptr;
         g.out = dW; g.ldo = lddw;
     } else {
-        g.epi = EPI_F32; g.out = g_splitk_scratch; g.ldo = K;
+        g.epi = EPI_F32; g.out = slab; g.ldo = K;
     }
     int done = 0;
     int rc = gemm_bf16_nt_256p(g, &done, s);
@@ -286,9 +284,9 @@ int gemm_bf16_wgrad_split(const bf16_t* tA, const bf16_t* tB, int splits, int Kc
         r.M = N; r.N = K; r.out = dW; r.ldo = lddw; r.residual = accumulate ? dW : nullptr;
         const int rb = cdiv((long)N * (K / 4), 256);
         if (accumulate)
-            hipLaunchKernelGGL((splitk_reduce_kernel<EPI_F32_RESID>), dim3(rb), dim3(256), 0, s, g_splitk_scratch, splits, r);
+            hipLaunchKernelGGL((splitk_reduce_kernel<EPI_F32_RESID>), dim3(rb), dim3(256), 0, s, slab, splits, r);
         else
-            hipLaunchKernelGGL((splitk_reduce_kernel<EPI_F32>), dim3(rb), dim3(256), 0, s, g_splitk_scratch, splits, r);
+            hipLaunchKernelGGL((splitk_reduce_kernel<EPI_F32>), dim3(rb), dim3(256), 0, s, slab, splits, r);
         RVLM_CHECK_LAUNCH();
     }
     return RVLM_OK;
@@ -303,19 +301,19 @@ int gemm_bf16_nt(const GemmBf16& p, hipStream_t s) {
     if (p.epi == EPI_BF16_DACT && !p.h_pre) return fail(RVLM_ERR_ARG, "gemm_bf16_nt: h_pre");
     // deep-K, few-tile problems (the weight-gradient GEMMs: K = all tokens, <= 256 output tiles): split K so
     // that >= 2 workgroups per CU are busy, fp32 slabs + deterministic reduce/epilogue kernel
-    if (p.K >= 8192 && (p.epi == EPI_F32 || p.epi == EPI_F32_RESID) && g_splitk_scratch) {
+    if (p.K >= 8192 && (p.epi == EPI_F32 || p.epi == EPI_F32_RESID) && p.splitk) {
         const int tiles = cdiv(p.M, GB_M) * cdiv(p.N, GB_N);
         int splitk = 1;
         const int nk64 = p.K / GB_K;
         for (int cand : {2, 3, 4, 6, 12}) {
-            if (nk64 % cand == 0 && (size_t)cand * p.M * p.N * sizeof(float) <= g_splitk_bytes) {
+            if (nk64 % cand == 0 && (size_t)cand * p.M * p.N * sizeof(float) <= p.splitk_bytes) {
                 splitk = cand;
                 if (tiles * cand >= 512) break;
             }
         }
         if (splitk > 1) {
             GemmBf16 part = p;
-            part.epi = EPI_F32; part.bias = nullptr; part.residual = nullptr; part.out = g_splitk_scratch;
+            part.epi = EPI_F32; part.bias = nullptr; part.residual = nullptr; part.out = p.splitk;
             part.ldo = p.N; part.out_pre = nullptr; part.h_pre = nullptr;
             part.a_rows = p.a_rows > 0 ? p.a_rows : p.M;
             const int tiles_m = cdiv(p.M, GB_M), tiles_n = cdiv(p.N, GB_N);
@@ -324,9 +322,9 @@ int gemm_bf16_nt(const GemmBf16& p, hipStream_t s) {
             RVLM_CHECK_LAUNCH();
             const int rb = cdiv((long)p.M * (p.N / 4), 256);
             if (p.epi == EPI_F32_RESID)
-                hipLaunchKernelGGL((splitk_reduce_kernel<EPI_F32_RESID>), dim3(rb), dim3(256), 0, s, g_splitk_scratch, splitk, p);
+                hipLaunchKernelGGL((splitk_reduce_kernel<EPI_F32_RESID>), dim3(rb), dim3(256), 0, s, p.splitk, splitk, p);
             else
-                hipLaunchKernelGGL((splitk_reduce_kernel<EPI_F32>), dim3(rb), dim3(256), 0, s, g_splitk_scratch, splitk, p);
+                hipLaunchKernelGGL((splitk_reduce_kernel<EPI_F32>), dim3(rb), dim3(256), 0, s, p.splitk, splitk, p);
             RVLM_CHECK_LAUNCH();
             return RVLM_OK;
         }
@@ -369,15 +367,15 @@ int gemm_bf16_nt(const GemmBf16& p, hipStream_t s) {
             const int nk64 = p.K / GB_K, tiles = cdiv(r.M, GB_M) * cdiv(p.N, GB_N);
             for (int cand : {2, 3, 4, 6, 8, 12, 16}) {
                 if (nk64 % cand != 0 || nk64 / cand < 2 || tiles * cand > 512) continue;
-                if ((size_t)cand * r.M * p.N * sizeof(float) > g_splitk_bytes) continue;
+                if ((size_t)cand * r.M * p.N * sizeof(float) > p.splitk_bytes) continue;
                 splitk = cand;
                 if (tiles * cand >= 128) break;
             }
         }
         const size_t need = (size_t)splitk * r.M * p.N * sizeof(float);
-        if (splitk > 1 && r.M <= 512 && g_splitk_scratch && need <= g_splitk_bytes && p.K % (splitk * GB_K) == 0) {
+        if (splitk > 1 && r.M <= 512 && p.splitk && need <= p.splitk_bytes && p.K % (splitk * GB_K) == 0) {
             GemmBf16 part = r;
-            part.epi = EPI_F32; part.bias = nullptr; part.residual = nullptr; part.out = g_splitk_scratch;
+            part.epi = EPI_F32; part.bias = nullptr; part.residual = nullptr; part.out = p.splitk;
             part.ldo = p.N; part.out_pre = nullptr; part.h_pre = nullptr;
             part.a_rows = r.a_rows > 0 ? r.a_rows : r.M;
             const int tiles_m = cdiv(part.M, GB_M), tiles_n = cdiv(part.N, GB_N);
@@ -386,11 +384,11 @@ int gemm_bf16_nt(const GemmBf16& p, hipStream_t s) {
             RVLM_CHECK_LAUNCH();
             const int rb = cdiv((long)r.M * (p.N / 4), 256);
             switch (p.epi) {
-                case EPI_BF16: hipLaunchKernelGGL((splitk_reduce_kernel<EPI_BF16>), dim3(rb), dim3(256), 0, s, g_splitk_scratch, splitk, r); break;
-                case EPI_F32_RESID: hipLaunchKernelGGL((splitk_reduce_kernel<EPI_F32_RESID>), dim3(rb), dim3(256), 0, s, g_splitk_scratch, splitk, r); break;
-                case EPI_BF16_ACT: hipLaunchKernelGGL((splitk_reduce_kernel<EPI_BF16_ACT>), dim3(rb), dim3(256), 0, s, g_splitk_scratch, splitk, r); break;
-                case EPI_BF16_DACT: hipLaunchKernelGGL((splitk_reduce_kernel<EPI_BF16_DACT>), dim3(rb), dim3(256), 0, s, g_splitk_scratch, splitk, r); break;
-                default: hipLaunchKernelGGL((splitk_reduce_kernel<EPI_F32>), dim3(rb), dim3(256), 0, s, g_splitk_scratch, splitk, r); break;
+                case EPI_BF16: hipLaunchKernelGGL((splitk_reduce_kernel<EPI_BF16>), dim3(rb), dim3(256), 0, s, p.splitk, splitk, r); break;
+                case EPI_F32_RESID: hipLaunchKernelGGL((splitk_reduce_kernel<EPI_F32_RESID>), dim3(rb), dim3(256), 0, s, p.splitk, splitk, r); break;
+                case EPI_BF16_ACT: hipLaunchKernelGGL((splitk_reduce_kernel<EPI_BF16_ACT>), dim3(rb), dim3(256), 0, s, p.splitk, splitk, r); break;
+                case EPI_BF16_DACT: hipLaunchKernelGGL((splitk_reduce_kernel<EPI_BF16_DACT>), dim3(rb), dim3(256), 0, s, p.splitk, splitk, r); break;
+                default: hipLaunchKernelGGL((splitk_reduce_kernel<EPI_F32>), dim3(rb), dim3(256), 0, s, p.splitk, splitk, r); break;
             }
             RVLM_CHECK_LAUNCH();
             return RVLM_OK;

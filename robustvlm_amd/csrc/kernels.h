@@ -50,6 +50,8 @@ struct GemmBf16 {
     const float* residual = nullptr;    // EPI_F32_RESID (ld = ldo)
     int act = RVLM_ACT_QUICK_GELU;
     unsigned long long* trace = nullptr;   // persistent kernel only: per-tile s_memtime stamps (test hook)
+    float* splitk = nullptr;            // fp32 slab scratch for the split-K paths (few-row GEMMs); null: no split-K
+    size_t splitk_bytes = 0;
     int stagger = 0;                    // persistent kernel only: odd workgroup groups start stagger x ~4 us late
     int batch_m_rows = 0;               // persistent kernel only, > 0: batched form - rows [b*batch_m_rows, ...) of A meet
                                         // rows [b*N, (b+1)*N) of Bw (the split-K weight-gradient GEMM, gemm_bf16_wgrad)
@@ -141,17 +143,18 @@ template <typename T>
 int transpose_pad(const T* in, long ldi, int R, int C, T* out, long ldo, int Rp, hipStream_t s);
 // split-K weight gradient (bf16): plan -> (splits, Kc), 0 when the shape is not covered; operands transposed into
 // [splits][C][Kc] token chunks (optionally emitting the bias gradient = column sums); batched persistent GEMM + reduce
-int wgrad_split_plan(int M, int N, int K, int* splits, int* Kc);
+int wgrad_split_plan(int M, int N, int K, size_t slab_bytes, int* splits, int* Kc);
 int transpose_split(const bf16_t* in, long ldi, int R, int C, bf16_t* out, int Kc, int splits, float* dbias,
-                    int accumulate, hipStream_t s);
+                    int accumulate, float* red, size_t red_floats, hipStream_t s);
 int gemm_bf16_wgrad_split(const bf16_t* tA, const bf16_t* tB, int splits, int Kc, int N, int K, float* dW, long lddw,
-                          int accumulate, hipStream_t s);
-void set_reduce_scratch(float* p, size_t floats);
+                          int accumulate, float* slab, size_t slab_bytes, hipStream_t s);
+// `red` / `red_floats`: caller-owned scratch for the partial column sums (no process-wide state)
 template <typename T>
-int colsum(const T* in, long ld, int R, int C, float* out, int accumulate, hipStream_t s);
+int colsum(const T* in, long ld, int R, int C, float* out, int accumulate, float* red, size_t red_floats,
+           hipStream_t s);
 template <typename T>
 int ln_param_grad(const T* dy, long lddy, const float* x, long ldx, const float* mean, const float* rstd, int R,
-                  int C, float* dgamma, float* dbeta, int accumulate, hipStream_t s);
+                  int C, float* dgamma, float* dbeta, int accumulate, float* red, size_t red_floats, hipStream_t s);
 int pos_cls_grad(const float* dtok, long ld, int B, int S, int W, float* dpos, float* dcls, int accumulate,
                  hipStream_t s);
 template <typename T>

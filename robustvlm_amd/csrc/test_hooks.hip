@@ -8,10 +8,6 @@ void attn_set_use_tr(int on);
 void gemm_set_variant(int v);
 void gemm_set_trace(unsigned long long* ptr);
 void gemm_set_ablate(int v);
-void gemm_set_splitk_scratch(float* ptr, size_t bytes);
-void gemm_get_splitk_scratch(float** ptr, size_t* bytes);
-void set_reduce_scratch(float* p, size_t floats);
-void get_reduce_scratch(float** p, size_t* floats);
 int attn_occupancy(int S, int* out3);
 
 __global__ void probe_tr16_kernel(const bf16_t* __restrict__ src, const int32_t* __restrict__ offs,
@@ -31,16 +27,15 @@ extern "C" int rvlm_k_gemm_bf16_nt(const uint16_t* A, long lda, const uint16_t* 
                                    int K, int a_rows, int epi, const float* bias, void* out, long ldo,
                                    uint16_t* out_pre, const uint16_t* h_pre, const float* residual, int act,
                                    rvlm_stream_t stream) {
-    // split-K slabs for few-row problems (test surface only).  Bound on EVERY call: the pointer is process-wide and an
-    // engine handle created (and destroyed) by an earlier test may have left its own buffer there.
+    // split-K slabs for few-row problems (test surface only; allocated once, never freed)
     static float* scratch = nullptr;
     const size_t bytes = (size_t)8 * 512 * 4096 * sizeof(float);
     if (!scratch && hipMalloc((void**)&scratch, bytes) != hipSuccess) scratch = nullptr;
-    gemm_set_splitk_scratch(scratch, scratch ? bytes : 0);
     GemmBf16 g;
     g.A = (const bf16_t*)A; g.lda = lda; g.Bw = (const bf16_t*)Bw; g.ldb = ldb; g.M = M; g.N = N; g.K = K;
     g.a_rows = a_rows; g.epi = epi; g.bias = bias; g.out = out; g.ldo = ldo; g.out_pre = (bf16_t*)out_pre;
     g.h_pre = (const bf16_t*)h_pre; g.residual = residual; g.act = act;
+    g.splitk = scratch; g.splitk_bytes = scratch ? bytes : 0;
     return gemm_bf16_nt(g, (hipStream_t)stream);
 }
 extern "C" int rvlm_k_gemm_f32(const float* A, long sam, long sak, const float* B, long sbn, long sbk,
@@ -93,9 +88,6 @@ extern "C" int rvlm_k_wgrad_bf16(const uint16_t* dY, long lddy, const uint16_t* 
                                  float* dW, long lddw, int accumulate, float* dbias, void* work, size_t work_bytes,
                                  rvlm_stream_t stream) {
     int splits = 0, Kc = 0;
-    float* old_sk; size_t old_skb; float* old_red; size_t old_redf;
-    gemm_get_splitk_scratch(&old_sk, &old_skb);
-    get_reduce_scratch(&old_red, &old_redf);
     const size_t Mpt = (size_t)round_up(M, 128) + 16 * 128;
     char* w = (char*)work;
     bf16_t* tA = (bf16_t*)w; w += Mpt * N * 2;
@@ -103,14 +95,10 @@ extern "C" int rvlm_k_wgrad_bf16(const uint16_t* dY, long lddy, const uint16_t* 
     float* red = (float*)w; const size_t redf = (Mpt / 64) * (size_t)N; w += redf * 4;
     float* slab = (float*)w; const size_t slab_bytes = (size_t)16 * N * K * 4;
     if ((size_t)(w - (char*)work) + slab_bytes > work_bytes) return fail(RVLM_ERR_ARG, "rvlm_k_wgrad_bf16: work buffer too small");
-    gemm_set_splitk_scratch(slab, slab_bytes);
-    set_reduce_scratch(red, redf);
     int rc = RVLM_OK;
-    if (!wgrad_split_plan(M, N, K, &splits, &Kc)) rc = fail(RVLM_ERR_UNSUPPORTED, "rvlm_k_wgrad_bf16: N, K % 256, M >= 256");
-    if (!rc) rc = transpose_split((const bf16_t*)dY, lddy, M, N, tA, Kc, splits, dbias, accumulate, (hipStream_t)stream);
-    if (!rc) rc = transpose_split((const bf16_t*)X, ldx, M, K, tB, Kc, splits, nullptr, 0, (hipStream_t)stream);
-    if (!rc) rc = gemm_bf16_wgrad_split(tA, tB, splits, Kc, N, K, dW, lddw, accumulate, (hipStream_t)stream);
-    gemm_set_splitk_scratch(old_sk, old_skb);
-    set_reduce_scratch(old_red, old_redf);
+    if (!wgrad_split_plan(M, N, K, slab_bytes, &splits, &Kc)) rc = fail(RVLM_ERR_UNSUPPORTED, "rvlm_k_wgrad_bf16: N, K % 256, M >= 256");
+    if (!rc) rc = transpose_split((const bf16_t*)dY, lddy, M, N, tA, Kc, splits, dbias, accumulate, red, redf, (hipStream_t)stream);
+    if (!rc) rc = transpose_split((const bf16_t*)X, ldx, M, K, tB, Kc, splits, nullptr, 0, nullptr, 0, (hipStream_t)stream);
+    if (!rc) rc = gemm_bf16_wgrad_split(tA, tB, splits, Kc, N, K, dW, lddw, accumulate, slab, slab_bytes, (hipStream_t)stream);
     return rc;
 }

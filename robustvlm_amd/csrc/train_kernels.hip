@@ -8,10 +8,6 @@
 namespace rvlm {
 
 constexpr int RED_NCH = 128;
-static float* g_red_scratch = nullptr;     // partial column sums, provided by the engine
-static size_t g_red_floats = 0;
-void set_reduce_scratch(float* p, size_t floats) { g_red_scratch = p; g_red_floats = floats; }
-void get_reduce_scratch(float** p, size_t* floats) { *p = g_red_scratch; *floats = g_red_floats; }
 
 // out[c, r] = in[r, c] for r < R, zero for R <= r < Rp (the GEMM's K padding).  64x64 tiles via LDS.
 template <typename T>
@@ -109,13 +105,13 @@ reduce_partials16_kernel(const float* __restrict__ partial, int nch, int C, floa
 }
 // transposes one wgrad operand into the split layout; dbias != null: dbias[c] (+)= sum_r in[r, c] on the way
 int transpose_split(const bf16_t* in, long ldi, int R, int C, bf16_t* out, int Kc, int splits, float* dbias,
-                    int accumulate, hipStream_t s) {
+                    int accumulate, float* red, size_t red_floats, hipStream_t s) {
     if (C % 64 != 0 || Kc % 64 != 0 || ldi % 8 != 0) return fail(RVLM_ERR_ARG, "transpose_split: C, Kc % 64, ldi % 8");
     const int rt = splits * Kc / 64;
     float* part = nullptr;
     if (dbias) {
-        if (!g_red_scratch || (size_t)rt * C > g_red_floats) return fail(RVLM_ERR_STATE, "transpose_split: no reduce scratch");
-        part = g_red_scratch;
+        if (!red || (size_t)rt * C > red_floats) return fail(RVLM_ERR_STATE, "transpose_split: no reduce scratch");
+        part = red;
     }
     hipLaunchKernelGGL(transpose_split_kernel, dim3(C / 64, rt), dim3(256), 0, s, in, ldi, R, C, out, Kc, part);
     RVLM_CHECK_LAUNCH();
@@ -174,26 +170,26 @@ ln_param_partial_kernel(const T* __restrict__ dy, long lddy, const float* __rest
     }
 }
 template <typename T>
-int colsum(const T* in, long ld, int R, int C, float* out, int accumulate, hipStream_t s) {
+int colsum(const T* in, long ld, int R, int C, float* out, int accumulate, float* red, size_t red_floats, hipStream_t s) {
     const int nch = R >= 4096 ? RED_NCH : (R >= 256 ? 16 : 1);
-    if (!g_red_scratch || (size_t)nch * C > g_red_floats) return fail(RVLM_ERR_STATE, "colsum: no reduce scratch");
-    hipLaunchKernelGGL((colsum_partial_kernel<T>), dim3(cdiv(C, 64), nch), dim3(256), 0, s, in, ld, R, C, g_red_scratch);
+    if (!red || (size_t)nch * C > red_floats) return fail(RVLM_ERR_STATE, "colsum: no reduce scratch");
+    hipLaunchKernelGGL((colsum_partial_kernel<T>), dim3(cdiv(C, 64), nch), dim3(256), 0, s, in, ld, R, C, red);
     RVLM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(reduce_partials16_kernel, dim3(cdiv(C, 16)), dim3(256), 0, s, g_red_scratch, nch, C, out, accumulate);
+    hipLaunchKernelGGL(reduce_partials16_kernel, dim3(cdiv(C, 16)), dim3(256), 0, s, red, nch, C, out, accumulate);
     RVLM_CHECK_LAUNCH();
     return RVLM_OK;
 }
-template int colsum<float>(const float*, long, int, int, float*, int, hipStream_t);
-template int colsum<bf16_t>(const bf16_t*, long, int, int, float*, int, hipStream_t);
+template int colsum<float>(const float*, long, int, int, float*, int, float*, size_t, hipStream_t);
+template int colsum<bf16_t>(const bf16_t*, long, int, int, float*, int, float*, size_t, hipStream_t);
 
 // LayerNorm affine gradients: dgamma[c] (+)= sum_r dy[r,c] * (x[r,c]-mean[r])*rstd[r]; dbeta[c] (+)= sum_r dy[r,c]
 template <typename T>
 int ln_param_grad(const T* dy, long lddy, const float* x, long ldx, const float* mean, const float* rstd, int R,
-                  int C, float* dgamma, float* dbeta, int accumulate, hipStream_t s) {
+                  int C, float* dgamma, float* dbeta, int accumulate, float* red, size_t red_floats, hipStream_t s) {
     const int nch = R >= 4096 ? RED_NCH : (R >= 256 ? 16 : 1);
-    if (!g_red_scratch || (size_t)2 * nch * C > g_red_floats) return fail(RVLM_ERR_STATE, "ln_param_grad: no reduce scratch");
-    float* pg = g_red_scratch;
-    float* pb = g_red_scratch + (size_t)nch * C;
+    if (!red || (size_t)2 * nch * C > red_floats) return fail(RVLM_ERR_STATE, "ln_param_grad: no reduce scratch");
+    float* pg = red;
+    float* pb = red + (size_t)nch * C;
     hipLaunchKernelGGL((ln_param_partial_kernel<T>), dim3(cdiv(C, 64), nch), dim3(256), 0, s, dy, lddy, x, ldx, mean,
                        rstd, R, C, pg, pb);
     RVLM_CHECK_LAUNCH();
@@ -204,9 +200,9 @@ int ln_param_grad(const T* dy, long lddy, const float* x, long ldx, const float*
     return RVLM_OK;
 }
 template int ln_param_grad<float>(const float*, long, const float*, long, const float*, const float*, int, int,
-                                  float*, float*, int, hipStream_t);
+                                  float*, float*, int, float*, size_t, hipStream_t);
 template int ln_param_grad<bf16_t>(const bf16_t*, long, const float*, long, const float*, const float*, int, int,
-                                   float*, float*, int, hipStream_t);
+                                   float*, float*, int, float*, size_t, hipStream_t);
 
 // positional-embedding gradient: dpos[s, c] (+)= sum_b dtok[b*S + s, c]; class embedding = row s = 0
 __global__ void __launch_bounds__(256)
