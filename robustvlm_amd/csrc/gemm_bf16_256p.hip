@@ -145,9 +145,13 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const int ntiles = tiles_m * tiles_n;
     constexpr bool OUT_F32 = (EPI == EPI_F32_RESID || EPI == EPI_F32);
-    // phase offset (performance only): with every workgroup in lockstep the fp32 epilogues' HBM bursts coincide chip-wide
-    if (p.stagger > 0 && ((blockIdx.x >> 3) & 1))
-        for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    // phase offset (performance only): with every workgroup in lockstep the epilogues' HBM bursts coincide chip-wide.  On
+    // by default for the fc2 dgrad only (8 tiles per workgroup, epilogue reads act' from HBM: -3 %); measured neutral to
+    // slightly negative for the other epilogues (2 tiles per workgroup: the offset costs as much tail as it hides)
+    if (p.stagger > 0) {
+        const int phase = (blockIdx.x >> 3) & 3;            // 4 phases per XCD (blockIdx & 7 = XCD)
+        for (int i = 0; i < p.stagger * phase; ++i) __builtin_amdgcn_s_sleep(127);
+    }
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -611,8 +615,10 @@ int gemm_bf16_nt_256p(const GemmBf16& p, int* rows_done, hipStream_t s) {
     static int tail_on = -1;
     if (tail_on < 0) { const char* e = getenv("RVLM_GEMM_TAIL"); tail_on = e ? atoi(e) : 1; }
     static int stagger = -1;
-    if (stagger < 0) { const char* e = getenv("RVLM_GEMM_STAGGER"); stagger = e ? atoi(e) : 0; }
-    if (q.epi == EPI_F32_RESID) q.stagger = stagger;
+    if (stagger < 0) { const char* e = getenv("RVLM_GEMM_STAGGER"); stagger = e ? atoi(e) : 2; }
+    static int stagger_mask = -1;   // bit e: apply to epilogue kind e
+    if (stagger_mask < 0) { const char* e = getenv("RVLM_GEMM_STAGGER_EPI"); stagger_mask = e ? atoi(e) : 8; }
+    if ((stagger_mask >> q.epi) & 1) q.stagger = stagger;
     const bool tail = tail_on && g_persist_ablate == 0 && p.batch_m_rows == 0 && p.M > q.M;
     const int m_total = tail ? p.M : q.M;
     int rc;
