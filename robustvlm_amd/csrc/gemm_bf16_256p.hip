@@ -149,8 +149,8 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
     // by default for the fc2 dgrad only (8 tiles per workgroup, epilogue reads act' from HBM: -3 %); measured neutral to
     // slightly negative for the other epilogues (2 tiles per workgroup: the offset costs as much tail as it hides)
     if (p.stagger > 0) {
-        const int phase = (blockIdx.x >> 3) & 3;            // 4 phases per XCD (blockIdx & 7 = XCD)
-        for (int i = 0; i < p.stagger * phase; ++i) __builtin_amdgcn_s_sleep(127);
+        const int phase = (blockIdx.x >> 3) & (p.stagger >> 8);   // phases per XCD (blockIdx & 7 = XCD): mask in the high bits
+        for (int i = 0; i < (p.stagger & 255) * phase; ++i) __builtin_amdgcn_s_sleep(127);
     }
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -618,7 +618,9 @@ int gemm_bf16_nt_256p(const GemmBf16& p, int* rows_done, hipStream_t s) {
     if (stagger < 0) { const char* e = getenv("RVLM_GEMM_STAGGER"); stagger = e ? atoi(e) : 2; }
     static int stagger_mask = -1;   // bit e: apply to epilogue kind e
     if (stagger_mask < 0) { const char* e = getenv("RVLM_GEMM_STAGGER_EPI"); stagger_mask = e ? atoi(e) : 8; }
-    if ((stagger_mask >> q.epi) & 1) q.stagger = stagger;
+    static int stagger_ph = -1;     // phase mask: 3 = 4 phases
+    if (stagger_ph < 0) { const char* e = getenv("RVLM_GEMM_STAGGER_PH"); stagger_ph = e ? atoi(e) : 3; }
+    if (((stagger_mask >> q.epi) & 1) && stagger > 0) q.stagger = (stagger & 255) | (stagger_ph << 8);
     const bool tail = tail_on && g_persist_ablate == 0 && p.batch_m_rows == 0 && p.M > q.M;
     const int m_total = tail ? p.M : q.M;
     int rc;
