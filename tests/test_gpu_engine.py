@@ -279,8 +279,9 @@ def test_full_size_properties_vit_l14_bf16():
     eng.close()
 
 
-@pytest.mark.parametrize("cfg,B,norm", [(V.VIT_TINY2, 5, True), (V.VIT_B_32, 3, False),
-                                        (V.VitConfig(64, 8, 1024, 2, 16, 64), 8, True)])
+@pytest.mark.parametrize("cfg,B,norm", [(V.VIT_TINY2, 5, True), (V.VIT_B_32, 3, False), (V.VIT_TINY2, 1, False),
+                                        (V.VitConfig(64, 8, 1024, 2, 16, 64), 8, True),
+                                        (V.VitConfig(64, 8, 1024, 1, 16, 64), 7, True)])
 def test_class_token_tail_matches_full_last_block(cfg, B, norm, monkeypatch):
     """The last block evaluated on the class-token rows only (default) against the same engine running the last block
     on every row (RVLM_CLS_TAIL=0): the dead rows do not reach the output, so embedding and input gradient agree to
