@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RVLM_VERSION 101
+#define RVLM_VERSION 102
 
 typedef void* rvlm_stream_t; /* hipStream_t */
 typedef struct rvlm_vit rvlm_vit;
@@ -182,6 +182,16 @@ int rvlm_apgd_select(float* x_adv, float* grad, float* x_best, float* grad_best,
 /* APGDAttack random start (autopgd_base.py:210-214,180-183): x + eps * t / (max_b|t| + 1e-12). */
 int rvlm_linf_random_start(const float* x, const float* t, float eps, size_t n_per_sample, int B,
                            float* x_adv, rvlm_stream_t stream);
+/* Square Attack, L-inf: one query of SquareAttack.attack_single_run (autoattack/square.py:256-263).  Candidates of the
+ * n_active still-robust images idx[a] (int64 indices into x / x_best [*, C, H, W]), written compactly to x_new
+ * [n_active, C, H, W]:  clamp(min(max(x_best + window, x - eps), x + eps), 0, 1), window = 2*eps*sign[c] on rows
+ * [vh, vh+s) x columns [vw, vw+s) and 0 elsewhere (one window per query for the whole batch).  sign: C floats. */
+int rvlm_square_linf_propose(const float* x, const float* x_best, const int64_t* idx, int n_active, int C, int H,
+                             int W, int vh, int vw, int s, float eps, const float* sign, float* x_new,
+                             rvlm_stream_t stream);
+/* square.py:288-291: x_best[idx[a]] = x_new[a] for the candidates with take[a] != 0 (loss improved or misclassified). */
+int rvlm_square_accept(float* x_best, const float* x_new, const int64_t* idx, const float* take, int n_active,
+                       size_t n_per_image, rvlm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Whole loops, device resident (no host sync inside): replace

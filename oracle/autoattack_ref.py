@@ -58,6 +58,9 @@ class AutoAttackRef:
                                   seed=seed, alpha=alpha, use_rs=use_rs)                      # autoattack.py:34-36
         self.apgd_targeted = APGDAttackTargetedRef(model, n_restarts=1, n_iter=iterations_apgd, eps=eps, norm=norm,
                                                    eot_iter=1, rho=.75, seed=seed, alpha=alpha, use_rs=use_rs)  # :47-49
+        from .square_ref import SquareAttackRef
+        self.square = SquareAttackRef(model, p_init=.8, n_queries=5000, eps=eps, norm=norm, n_restarts=1, seed=seed,
+                                      resc_schedule=False)                                    # :42-44
 
     def get_seed(self):
         return time.time() if self.seed is None else self.seed                    # :79-80
@@ -117,6 +120,9 @@ class AutoAttackRef:
                         self.apgd_targeted.seed = self.get_seed()
                         with torch.enable_grad():
                             adv_curr = self.apgd_targeted.perturb(x, y)
+                    elif attack == "square":                                      # :202-205
+                        self.square.seed = self.get_seed()
+                        adv_curr = self.square.perturb(x, y)
                     else:
                         raise ValueError("Attack not supported")
                     output = self.model(adv_curr).max(dim=1)[1]                   # :221-229

@@ -22,6 +22,7 @@ from .pgd_train import pgd
 from .apgd_train import apgd_train
 from .autopgd import APGDAttack, APGDAttack_targeted
 from .autoattack import AutoAttack, EvaluationState
+from .square import SquareAttack
 from .eval_utils import compute_accuracy_no_dataloader, zeroshot_head
 from .preprocess import ResizeCenterCropToTensor
 from .checkpoint import load_visual_state_dict, CheckpointWriter, resume_paths
@@ -29,4 +30,4 @@ from .checkpoint import load_visual_state_dict, CheckpointWriter, resume_paths
 __all__ = ["VitConfig", "CONFIGS", "CLIP_MEAN", "CLIP_STD", "random_state_dict", "state_dict_shapes",
            "VitEngine", "ClipVisionModel", "ComputeLossWrapper", "ClassificationModel", "compute_loss",
            "l2", "ce", "compute_acc", "project_perturbation", "normalize_grad", "pgd", "apgd_train",
-           "APGDAttack", "APGDAttack_targeted", "AutoAttack", "EvaluationState", "compute_accuracy_no_dataloader", "zeroshot_head", "ResizeCenterCropToTensor", "load_visual_state_dict", "CheckpointWriter", "resume_paths"]
+           "APGDAttack", "APGDAttack_targeted", "AutoAttack", "EvaluationState", "SquareAttack", "compute_accuracy_no_dataloader", "zeroshot_head", "ResizeCenterCropToTensor", "load_visual_state_dict", "CheckpointWriter", "resume_paths"]

@@ -118,6 +118,9 @@ _SIGS = {
     "rvlm_vit_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "rvlm_vit_get_profile": (C.c_int, [C.c_void_p, C.POINTER(ProfileEntryC), C.POINTER(C.c_int)]),
     "rvlm_vit_reset_profile": (C.c_int, [C.c_void_p]),
+    "rvlm_square_linf_propose": (C.c_int, [c_f32p, c_f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.c_int, C.c_int, C.c_float, c_f32p, c_f32p, c_stream]),
+    "rvlm_square_accept": (C.c_int, [c_f32p, c_f32p, C.c_void_p, c_f32p, C.c_int, C.c_size_t, c_stream]),
     # kernel-level test surface (include/rvlm_kernels.h)
     "rvlm_k_gemm_bf16_nt": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_int, C.c_int,
                                       C.c_int, C.c_int, C.c_int, c_f32p, C.c_void_p, C.c_long,

@@ -6,9 +6,10 @@ iterations_apgd=..., use_rs=...)`` then ``run_standard_evaluation(x, y, bs=...)`
 native :class:`~robustvlm_amd.autopgd.APGDAttack` / :class:`~robustvlm_amd.autopgd.APGDAttack_targeted` (whole loops on
 the device when ``model`` is a :class:`~robustvlm_amd.clip_model.ClassificationModel` over the engine).
 
-Built: ``apgd-ce``, ``apgd-dlr``, ``apgd-t``.  NOT built (outside the hot path, the reference's configs for this path
-never select them): ``fab``, ``fab-t``, ``square`` -> NotImplementedError when they would run; their hyper-parameter
-holders exist so that ``set_version`` and user code that tweaks ``adversary.fab.n_restarts`` keep working.
+Built: ``apgd-ce``, ``apgd-dlr``, ``apgd-t`` and ``square`` (the black-box route of clip_robustbench.py:150-151, L-inf;
+:class:`~robustvlm_amd.square.SquareAttack`).  NOT built (the reference's configs for this path never select them):
+``fab``, ``fab-t`` -> NotImplementedError when they would run; their hyper-parameter holder exists so that
+``set_version`` and user code that tweaks ``adversary.fab.n_restarts`` keep working.
 """
 from __future__ import annotations
 
@@ -25,9 +26,10 @@ import numpy as np
 import torch
 
 from .autopgd import APGDAttack, APGDAttack_targeted
+from .square import SquareAttack
 
-_BUILT = ("apgd-ce", "apgd-dlr", "apgd-t")
-_KNOWN = _BUILT + ("fab", "fab-t", "square")
+_BUILT = ("apgd-ce", "apgd-dlr", "apgd-t", "square")
+_KNOWN = _BUILT + ("fab", "fab-t")
 
 
 class EvaluationState:
@@ -133,7 +135,11 @@ class AutoAttack():
         self.apgd_targeted = APGDAttack_targeted(model, n_restarts=1, **common)     # :47-49
         # hyper-parameter holders of the attacks that are not built (see module docstring)
         self.fab = SimpleNamespace(n_restarts=5, n_iter=100, n_target_classes=9, targeted=False, seed=seed)
-        self.square = SimpleNamespace(p_init=.8, n_queries=5000, n_restarts=1, seed=seed)
+        if norm == 'Linf':                                                          # autoattack.py:42-44
+            self.square = SquareAttack(model, p_init=.8, n_queries=5000, eps=eps, norm=norm, n_restarts=1, seed=seed,
+                                       verbose=False, device=device, resc_schedule=False)
+        else:
+            self.square = SimpleNamespace(p_init=.8, n_queries=5000, n_restarts=1, seed=seed)
         if version in ['standard', 'plus', 'rand']:
             self.set_version(version)
 
@@ -205,6 +211,9 @@ class AutoAttack():
         if attack == 'apgd-t':
             self.apgd_targeted.seed = self.get_seed()
             return self.apgd_targeted.perturb(x, y)
+        if attack == 'square' and isinstance(self.square, SquareAttack):
+            self.square.seed = self.get_seed()
+            return self.square.perturb(x, y)
         if attack in _KNOWN:
             raise NotImplementedError(f"attack '{attack}' is not part of the native path (built: {', '.join(_BUILT)})")
         raise ValueError('Attack not supported')
@@ -270,6 +279,15 @@ class AutoAttack():
                 state.add_run_attack(attack)
                 self._say('robust accuracy after {}: {:.2%} (total time {:.1f} s)'.format(
                     attack.upper(), acc_by_attack[attack], time.time() - t0))
+            # checks.py:73-87: Square is the weakest attack of the ensemble - if it alone lowers the robust accuracy the
+            # white-box attacks are probably failing (gradient masking)
+            if 'square' in acc_by_attack and len(acc_by_attack) > 2:
+                floor = min(v for k, v in acc_by_attack.items() if k != 'square')
+                if acc_by_attack['square'] < floor - .002:
+                    self._warn('Square Attack has decreased the robust accuracy of {:.2%}. This might indicate that the '
+                               'robustness evaluation using AutoAttack is unreliable. Consider running Square Attack '
+                               'with more iterations and restarts or an adaptive attack.'.format(
+                                   floor - acc_by_attack['square']))
             state.to_disk(force=True)
             if self.verbose:
                 d = (x_adv - x_orig).reshape(n, -1)

@@ -200,6 +200,37 @@ static inline int ew_grid(size_t n, int per_thread = 4) {
 
 using namespace rvlm;
 
+// ---- Square Attack, L-inf (autoattack/square.py:256-263, 288-291) --------------------------------------------------
+// One query: candidates for the n_active still-robust images idx[a], written compactly (the model runs on them next):
+//   x_new[a] = clamp(min(max(x_best[idx[a]] + window, x[idx[a]] - eps), x[idx[a]] + eps), 0, 1)
+// window = two_eps * sign[c] on rows [vh, vh+s) x columns [vw, vw+s) of every channel c, 0 elsewhere - ONE window per
+// query for the whole batch, as in the reference.  Same fp32 operations in the same order (no contraction).
+__global__ void __launch_bounds__(256)
+square_linf_propose_kernel(const float* __restrict__ x, const float* __restrict__ x_best, const long long* __restrict__ idx,
+                           int C, int H, int W, int vh, int vw, int s, float eps, float two_eps,
+                           const float* __restrict__ sign, float* __restrict__ x_new) {
+    const long n_img = (long)C * H * W;
+    const long src = (long)idx[blockIdx.y] * n_img, dst = (long)blockIdx.y * n_img;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n_img; e += (long)gridDim.x * blockDim.x) {
+        const int col = (int)(e % W), row = (int)((e / W) % H), c = (int)(e / ((long)W * H));
+        const bool in = row >= vh && row < vh + s && col >= vw && col < vw + s;
+        const float w = in ? two_eps * sign[c] : 0.0f;
+        const float xv = x[src + e];
+        float v = x_best[src + e] + w;
+        v = fminf(fmaxf(v, xv - eps), xv + eps);
+        x_new[dst + e] = fminf(fmaxf(v, 0.0f), 1.0f);
+    }
+}
+// accepted candidates replace the incumbent: x_best[idx[a]] = x_new[a] where take[a] != 0
+__global__ void __launch_bounds__(256)
+square_accept_kernel(float* __restrict__ x_best, const float* __restrict__ x_new, const long long* __restrict__ idx,
+                     const float* __restrict__ take, long n_img) {
+    if (take[blockIdx.y] == 0.0f) return;
+    const long dst = (long)idx[blockIdx.y] * n_img, src = (long)blockIdx.y * n_img;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n_img; e += (long)gridDim.x * blockDim.x)
+        x_best[dst + e] = x_new[src + e];
+}
+
 extern "C" int rvlm_check_image_range(const float* x, size_t n, int32_t* flags,
                                       rvlm_stream_t stream) {
     RVLM_REQUIRE(x && flags, "rvlm_check_image_range: null pointer");
@@ -281,6 +312,29 @@ extern "C" int rvlm_linf_random_start(const float* x, const float* t, float eps,
     RVLM_REQUIRE(x && t && x_adv && B > 0, "rvlm_linf_random_start: bad args");
     hipLaunchKernelGGL(linf_random_start_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, t,
                        eps, n_per_sample, x_adv);
+    RVLM_CHECK_LAUNCH();
+    return RVLM_OK;
+}
+
+extern "C" int rvlm_square_linf_propose(const float* x, const float* x_best, const int64_t* idx, int n_active, int C,
+                                        int H, int W, int vh, int vw, int s, float eps, const float* sign,
+                                        float* x_new, rvlm_stream_t stream) {
+    RVLM_REQUIRE(x && x_best && idx && sign && x_new && n_active > 0 && C > 0 && H > 0 && W > 0,
+                 "rvlm_square_linf_propose: bad args");
+    RVLM_REQUIRE(s >= 1 && vh >= 0 && vw >= 0 && vh + s <= H && vw + s <= W, "rvlm_square_linf_propose: window outside the image");
+    const long n_img = (long)C * H * W;
+    const int gx = (int)std::min<long>((n_img + 255) / 256, 64);
+    hipLaunchKernelGGL(square_linf_propose_kernel, dim3(gx, n_active), dim3(256), 0, (hipStream_t)stream, x, x_best,
+                       (const long long*)idx, C, H, W, vh, vw, s, eps, 2.0f * eps, sign, x_new);
+    RVLM_CHECK_LAUNCH();
+    return RVLM_OK;
+}
+extern "C" int rvlm_square_accept(float* x_best, const float* x_new, const int64_t* idx, const float* take, int n_active,
+                                  size_t n_per_image, rvlm_stream_t stream) {
+    RVLM_REQUIRE(x_best && x_new && idx && take && n_active > 0 && n_per_image > 0, "rvlm_square_accept: bad args");
+    const int gx = (int)std::min<size_t>((n_per_image + 255) / 256, 64);
+    hipLaunchKernelGGL(square_accept_kernel, dim3(gx, n_active), dim3(256), 0, (hipStream_t)stream, x_best, x_new,
+                       (const long long*)idx, take, (long)n_per_image);
     RVLM_CHECK_LAUNCH();
     return RVLM_OK;
 }

@@ -7,7 +7,7 @@ Needs /root/reference (read-only) and therefore never runs on the GPU box; only 
 
 What is executed from the reference (nothing is copied into this repo):
   * train.pgd_train.pgd, train.apgd_train.apgd_train, vlm_eval.attacks.utils.*,
-    autoattack.autopgd_base.APGDAttack / APGDAttack_targeted, autoattack.AutoAttack
+    autoattack.autopgd_base.APGDAttack / APGDAttack_targeted, autoattack.AutoAttack, autoattack.square.SquareAttack
                                                 - imported from /root/reference
   * l2 / ce / compute_loss / ComputeLossWrapper / compute_acc of
     train/adversarial_training_clip.py          - that module needs torchvision/open_clip/wandb to
@@ -401,6 +401,70 @@ def g7_autoattack():
             out[f"{tag}_robust_after_ce"] = (clf(xa1).max(1)[1] == yy).numpy()
     save("autoattack_tiny.npz", **out)
 
+# ------------------------------------------------------------------ G9: Square Attack (section 8(f) rank 3, black-box route)
+def g9_square():
+    """SquareAttack(L-inf).perturb and AutoAttack(version='custom', ['square']).run_standard_evaluation of the
+    reference on the tiny ViT + 10-class head (CLIP_eval/clip_robustbench.py:150-151 is the caller): adversarial
+    images, per-sample query counts, model-call count.  Two settings: margin loss with the rescaled p schedule, and
+    the AutoAttack configuration (resc_schedule=False)."""
+    from autoattack.square import SquareAttack as RefSquare
+    from autoattack import AutoAttack as RefAutoAttack
+    cfg = vit_ref.VIT_TINY
+    w = init_weights(cfg, seed=3)
+    g = torch.Generator().manual_seed(80)
+    Bx = 7
+    x = torch.rand(Bx, 3, cfg.image_size, cfg.image_size, generator=g)
+    T = torch.randn(cfg.out_dim, 10, generator=g)
+    T = T / T.norm(dim=0, keepdim=True)
+    clf = vit_ref.ClassificationModelRef(cfg, w, T, 100.0).eval()
+    with torch.no_grad():
+        yy = clf(x).max(1)[1]
+    calls = []
+
+    def predict(v):
+        calls.append(tuple(v.shape))
+        with torch.no_grad():
+            return clf(v)
+
+    out = dict(x=x.numpy(), y=yy.numpy(), T=T.numpy(), weights_seed=np.int64(3),
+               weights_sha256=np.array(weights_digest(w)))
+    for tag, eps, nq, loss, resc in (("m", 12 / 255, 60, "margin", True), ("c", 20 / 255, 40, "ce", True),
+                                      ("a", 8 / 255, 50, "margin", False)):
+        calls.clear()
+        atk = RefSquare(predict, norm="Linf", n_queries=nq, eps=eps, p_init=.8, n_restarts=2, seed=5, verbose=False,
+                        loss=loss, resc_schedule=resc, device="cpu")
+        adv = atk.perturb(x.clone(), yy.clone())
+        with torch.no_grad():
+            pred = clf(adv).max(1)[1]
+        out[f"{tag}_eps"] = np.float64(eps)
+        out[f"{tag}_n_queries"] = np.int64(nq)
+        out[f"{tag}_adv"] = adv.numpy()
+        out[f"{tag}_robust"] = (pred == yy).numpy()
+        out[f"{tag}_n_model_calls"] = np.int64(len(calls))
+        # one single run on every sample (the per-query trajectory: x_best and the query counters of all of them)
+        torch.random.manual_seed(11)
+        nq_used, xb = atk.attack_single_run(x.clone(), yy.clone())
+        out[f"{tag}_run_queries"] = nq_used.numpy()
+        out[f"{tag}_run_x_best"] = xb.numpy()
+        print("square", tag, "robust", (pred == yy).numpy().astype(int), "calls", len(calls), "queries", nq_used.numpy())
+    # through AutoAttack (its own SquareAttack instance: p_init .8, n_restarts 1, resc_schedule False)
+    calls.clear()
+    aa = RefAutoAttack(predict, norm="Linf", eps=8 / 255, seed=0, verbose=False, version="custom",
+                       attacks_to_run=["square"], device="cpu")
+    aa.square.n_queries = 50
+    x_adv, y_adv = aa.run_standard_evaluation(x.clone(), yy.clone(), bs=4, return_labels=True)
+    with torch.no_grad():
+        pred = clf(x_adv).max(1)[1]
+    out["aa_eps"] = np.float64(8 / 255)
+    out["aa_n_queries"] = np.int64(50)
+    out["aa_x_adv"] = x_adv.numpy()
+    out["aa_y_adv"] = y_adv.numpy()
+    out["aa_robust"] = (pred == yy).numpy()
+    out["aa_n_model_calls"] = np.int64(len(calls))
+    print("square aa robust", (pred == yy).numpy().astype(int), "calls", len(calls))
+    save("square_tiny.npz", **out)
+
+
 # ------------------------------------------------------------------ G8: input transform (section 8(f) rank 4)
 def g8_preprocess():
     """Resize(size, bicubic) -> CenterCrop(size) -> ToTensor on synthetic 'decoded' images, computed by Pillow (the
@@ -432,8 +496,8 @@ def g8_preprocess():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
     fns = dict(g1=g1_pgd_elementwise, g2=g2_apgd_controller, g3=g3_tiny_vit_attacks,
-               g4=g4_autopgd, g5=g5_vit_vs_hf, g6=g6_losses, g7=g7_autoattack, g8=g8_preprocess)
+               g4=g4_autopgd, g5=g5_vit_vs_hf, g6=g6_losses, g7=g7_autoattack, g8=g8_preprocess, g9=g9_square)
     for k in which:
         fns[k]()

@@ -302,3 +302,102 @@ def test_class_token_tail_matches_full_last_block(cfg, B, norm, monkeypatch):
     assert cos_sim(out["0"][0].cpu(), out["1"][0].cpu()) > 0.99995
     assert rel_max(out["1"][0].cpu(), out["0"][0].cpu()) < 2e-2
     assert cos_sim(out["0"][1].cpu(), out["1"][1].cpu()) > 0.999
+
+
+# ------------------------------------------------------------------ Square Attack (black-box route of AutoAttack)
+def test_square_kernels_bit_exact_vs_torch():
+    """rvlm_square_linf_propose / rvlm_square_accept against the reference's tensor expressions (square.py:256-263,
+    288-291) on random data: windows at every border, a subset of active images, mixed accept flags."""
+    lib = L.load()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    n, c, h, w = 9, 3, 20, 28
+    eps = 8 / 255
+    x = torch.rand(n, c, h, w, generator=g, device=dev())
+    x[0, :, :3] = 0.0
+    x[1, :, -3:] = 1.0
+    sgn0 = torch.sign(2 * torch.rand(n, c, 1, w, generator=g, device=dev()) - 1)
+    x_best = torch.clamp(x + eps * sgn0, 0., 1.).contiguous()
+    for vh, vw, s in ((0, 0, 5), (15, 23, 5), (0, 8, 20), (7, 0, 1), (3, 4, 13)):
+        idx = torch.tensor([0, 1, 3, 4, 8], device=dev())
+        sign = torch.sign(2 * torch.rand(c, generator=g, device=dev()) - 1)
+        window = torch.zeros(c, h, w, device=dev())
+        window[:, vh:vh + s, vw:vw + s] = 2. * eps * sign.view(c, 1, 1)
+        ref_new = torch.clamp(torch.min(torch.max(x_best[idx] + window, x[idx] - eps), x[idx] + eps), 0., 1.)
+        x_new = torch.empty(idx.numel(), c, h, w, device=dev())
+        L.check(lib.rvlm_square_linf_propose(x.data_ptr(), x_best.data_ptr(), idx.data_ptr(), idx.numel(), c, h, w, vh, vw,
+                                             s, eps, sign.contiguous().data_ptr(), x_new.data_ptr(), L.stream_ptr()))
+        torch.cuda.synchronize()
+        assert torch.equal(x_new, ref_new)
+        take = torch.tensor([1., 0., 1., 0., 1.], device=dev())
+        t4 = take.view(-1, 1, 1, 1)
+        ref_best = x_best.clone()
+        ref_best[idx] = t4 * x_new + (1. - t4) * x_best[idx]
+        L.check(lib.rvlm_square_accept(x_best.data_ptr(), x_new.data_ptr(), idx.data_ptr(), take.data_ptr(), idx.numel(),
+                                       c * h * w, L.stream_ptr()))
+        torch.cuda.synchronize()
+        assert torch.equal(x_best, ref_best)
+
+
+@pytest.mark.parametrize("tag", ["m", "c", "a"])
+def test_square_attack_vs_reference_golden(tag):
+    """robustvlm_amd.SquareAttack (device tensors, HIP propose / accept kernels, CPU random stream) driven with the
+    reference's own classifier as ``predict`` (evaluated on the host, so every accept decision sees the reference's
+    logits): bit-identical adversarial images, query counters and model-call count with tests/golden/square_tiny.npz.
+    Then on the native engine + head: same robust flags, perturbation inside the eps ball."""
+    z = load_golden("square_tiny.npz")
+    cfg = V.VIT_TINY
+    w = V.init_weights(cfg, seed=int(z["weights_seed"]))
+    clf_ref = V.ClassificationModelRef(cfg, w, torch.from_numpy(z["T"]), 100.0).eval()
+    calls = []
+
+    def predict(v):
+        calls.append(tuple(v.shape))
+        with torch.no_grad():
+            return clf_ref(v.cpu()).to(v.device)
+
+    x, y = torch.from_numpy(z["x"]).to(dev()), torch.from_numpy(z["y"]).to(dev())
+    loss, resc = {"m": ("margin", True), "c": ("ce", True), "a": ("margin", False)}[tag]
+    eps, nq = float(z[tag + "_eps"]), int(z[tag + "_n_queries"])
+    atk = R.SquareAttack(predict, norm="Linf", n_queries=nq, eps=eps, p_init=.8, n_restarts=2, seed=5, loss=loss,
+                         resc_schedule=resc)
+    adv = atk.perturb(x.clone(), y.clone())
+    assert len(calls) == int(z[tag + "_n_model_calls"])
+    assert np.array_equal(adv.cpu().numpy(), z[tag + "_adv"])
+    torch.random.manual_seed(11)
+    used, xb = atk.attack_single_run(x.clone(), y.clone())
+    assert np.array_equal(used.cpu().numpy(), z[tag + "_run_queries"])
+    assert np.array_equal(xb.cpu().numpy(), z[tag + "_run_x_best"])
+    # native route: fp32 engine + zero-shot head
+    eng = make_engine(cfg, w, "fp32")
+    clf = R.ClassificationModel(eng, torch.from_numpy(z["T"]).to(dev())).eval()
+    atk2 = R.SquareAttack(clf, norm="Linf", n_queries=nq, eps=eps, p_init=.8, n_restarts=2, seed=5, loss=loss,
+                          resc_schedule=resc)
+    adv2 = atk2.perturb(x.clone(), y.clone())
+    with torch.no_grad():
+        robust = (clf(adv2).max(1)[1] == y).cpu().numpy()
+    assert np.array_equal(robust, z[tag + "_robust"])
+    assert float((adv2 - x).abs().max()) <= float(np.float32(eps)) + 1e-7
+    assert float(adv2.min()) >= 0.0 and float(adv2.max()) <= 1.0
+    eng.close()
+
+
+def test_square_through_autoattack_vs_reference_golden():
+    z = load_golden("square_tiny.npz")
+    cfg = V.VIT_TINY
+    w = V.init_weights(cfg, seed=int(z["weights_seed"]))
+    clf_ref = V.ClassificationModelRef(cfg, w, torch.from_numpy(z["T"]), 100.0).eval()
+    calls = []
+
+    def predict(v):
+        calls.append(tuple(v.shape))
+        with torch.no_grad():
+            return clf_ref(v.cpu()).to(v.device)
+
+    x, y = torch.from_numpy(z["x"]).to(dev()), torch.from_numpy(z["y"]).to(dev())
+    aa = R.AutoAttack(predict, norm="Linf", eps=float(z["aa_eps"]), seed=0, verbose=False, version="custom",
+                      attacks_to_run=["square"], device=dev())
+    aa.square.n_queries = int(z["aa_n_queries"])
+    x_adv, y_adv = aa.run_standard_evaluation(x.clone(), y.clone(), bs=4, return_labels=True)
+    assert len(calls) == int(z["aa_n_model_calls"])
+    assert np.array_equal(x_adv.cpu().numpy(), z["aa_x_adv"])
+    assert np.array_equal(y_adv.cpu().numpy(), z["aa_y_adv"])

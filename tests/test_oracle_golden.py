@@ -196,6 +196,60 @@ def test_autoattack_orchestration_bit_exact(tag):
         assert np.array_equal((clf(x_adv).max(1)[1] == y).numpy(), z[tag + "_robust"])
 
 
+@pytest.mark.parametrize("tag", ["m", "c", "a"])
+def test_square_attack_bit_exact(tag):
+    """oracle/square_ref.py against what the reference's SquareAttack produced (tests/golden/square_tiny.npz):
+    perturb() with two restarts (adversarial images, number of model calls) and one single run on every sample (the
+    per-query accept / reject trajectory: x_best and the query counters)."""
+    from oracle.square_ref import SquareAttackRef
+    z = load_golden("square_tiny.npz")
+    cfg = V.VIT_TINY
+    w = V.init_weights(cfg, seed=int(z["weights_seed"]))
+    assert weights_digest(w) == str(z["weights_sha256"])
+    clf = V.ClassificationModelRef(cfg, w, torch.from_numpy(z["T"]), 100.0).eval()
+    calls = []
+
+    def predict(v):
+        calls.append(tuple(v.shape))
+        with torch.no_grad():
+            return clf(v)
+
+    x, y = torch.from_numpy(z["x"]), torch.from_numpy(z["y"])
+    loss, resc = {"m": ("margin", True), "c": ("ce", True), "a": ("margin", False)}[tag]
+    atk = SquareAttackRef(predict, norm="Linf", n_queries=int(z[tag + "_n_queries"]), eps=float(z[tag + "_eps"]),
+                          p_init=.8, n_restarts=2, seed=5, loss=loss, resc_schedule=resc)
+    adv = atk.perturb(x.clone(), y.clone())
+    assert len(calls) == int(z[tag + "_n_model_calls"])
+    assert np.array_equal(adv.numpy(), z[tag + "_adv"])
+    torch.random.manual_seed(11)
+    nq, xb = atk.attack_single_run(x.clone(), y.clone())
+    assert np.array_equal(nq.numpy(), z[tag + "_run_queries"])
+    assert np.array_equal(xb.numpy(), z[tag + "_run_x_best"])
+
+
+def test_square_through_autoattack_bit_exact():
+    from oracle import autoattack_ref as AA
+    z = load_golden("square_tiny.npz")
+    cfg = V.VIT_TINY
+    w = V.init_weights(cfg, seed=int(z["weights_seed"]))
+    clf = V.ClassificationModelRef(cfg, w, torch.from_numpy(z["T"]), 100.0).eval()
+    calls = []
+
+    def predict(v):
+        calls.append(tuple(v.shape))
+        with torch.no_grad():
+            return clf(v)
+
+    x, y = torch.from_numpy(z["x"]), torch.from_numpy(z["y"])
+    aa = AA.AutoAttackRef(predict, norm="Linf", eps=float(z["aa_eps"]), seed=0, version="custom",
+                          attacks_to_run=["square"])
+    aa.square.n_queries = int(z["aa_n_queries"])
+    x_adv, y_adv = aa.run_standard_evaluation(x.clone(), y.clone(), bs=4, return_labels=True)
+    assert len(calls) == int(z["aa_n_model_calls"])
+    assert np.array_equal(x_adv.numpy(), z["aa_x_adv"])
+    assert np.array_equal(y_adv.numpy(), z["aa_y_adv"])
+
+
 # ------------------------------------------------------------------ section 8(f) rank 4: input transform
 def test_preprocess_oracle_bit_exact_vs_pillow_golden():
     from oracle import preprocess_ref as P
