@@ -37,9 +37,10 @@ def parse():
     ap.add_argument("--batch", type=int, default=128, help="images per GPU per step")
     ap.add_argument("--iterations", type=int, default=10)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--attack", default="pgd", choices=["pgd", "apgd", "autopgd"],
+    ap.add_argument("--attack", default="pgd", choices=["pgd", "apgd", "autopgd", "square"],
                     help="pgd: BASELINE configs 2/4 (FARE); apgd: config 3 (TeCoA apgd_train); autopgd: config 5 "
-                         "(APGDAttack CE on the zero-shot head, use --iterations 100 --batch 256)")
+                         "(APGDAttack CE on the zero-shot head, use --iterations 100 --batch 256); square: the black-box "
+                         "route (SquareAttack, --iterations = queries; forward passes only)")
     ap.add_argument("--mode", default="attack", choices=["attack", "train"],
                     help="attack (default, the BASELINE metric): one pgd()/apgd call per step; train: one full "
                          "FARE/TeCoA optimizer step per step (e0 + attack + fwd + wgrad backward + grad all-reduce + AdamW)")
@@ -173,6 +174,17 @@ def main():
 
         def step():
             return R.apgd_train(model, x, y, "linf", eps, n_iter=args.iterations, loss_fn=wrap)
+    elif args.attack == "square":
+        T = torch.randn(cfg.out_dim, 1000, generator=g, device=dev)
+        T = T / T.norm(dim=0, keepdim=True)
+        clf = R.ClassificationModel(eng, T).eval()
+        with torch.no_grad():
+            y = clf(x).max(1)[1]
+        atk = R.SquareAttack(clf, norm="Linf", n_queries=args.iterations, eps=eps, p_init=.8, n_restarts=1, seed=0,
+                             resc_schedule=False)
+
+        def step():
+            return atk.perturb(x, y)
     else:
         T = torch.randn(cfg.out_dim, 1000, generator=g, device=dev)
         T = T / T.norm(dim=0, keepdim=True)
@@ -215,15 +227,21 @@ def main():
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"{'FARE' if args.attack == 'pgd' else 'TeCoA-CE'} {args.attack.upper()} {args.iterations}-step eps=4/255 on {args.model} "
-                                   f"{args.precision}, batch={B} per GPU, 224x224x3 synthetic, seeded random-init weights "
-                                   f"(BASELINE configs[{(1 if world == 1 else 3) if args.attack == 'pgd' else 2 if args.attack == 'apgd' else 4}])",
+            "config": {"workload": (f"{'FARE' if args.attack == 'pgd' else 'TeCoA-CE'} {args.attack.upper()} {args.iterations}-step eps=4/255 on {args.model} "
+                                    f"{args.precision}, batch={B} per GPU, 224x224x3 synthetic, seeded random-init weights "
+                                    f"(BASELINE configs[{(1 if world == 1 else 3) if args.attack == 'pgd' else 2 if args.attack == 'apgd' else 4}])")
+                                   if args.attack != "square" else
+                                   (f"black-box SquareAttack, {args.iterations} queries, eps=4/255 on {args.model} {args.precision} + "
+                                    f"1000-class zero-shot head, batch={B} per GPU (clip_robustbench.py --blackbox_only route; "
+                                    f"forward passes only, samples leave the batch once fooled)"),
                        "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world} (no data-path collective)",
-                       "loss": "l2/mean" if args.attack == "pgd" else "ce/none"},
-            # pgd: I x (fwd+bwd); apgd_train: (I+1) fwd + I bwd; APGDAttack: (I+2) fwd + (I+1) bwd  ~ I+1 pairs
+                       "loss": "l2/mean" if args.attack == "pgd" else "margin" if args.attack == "square" else "ce/none"},
+            # pgd: I x (fwd+bwd); apgd_train: (I+1) fwd + I bwd; APGDAttack: (I+2) fwd + (I+1) bwd  ~ I+1 pairs;
+            # square: at most I + 3 forwards (0.49 of a pair each; fewer once samples are fooled)
             "whole_loop_tflops_per_gpu": value / world * FLOP_PER_IMG_ITER.get(args.model, 0) *
                                          (args.iterations if args.attack == "pgd" else args.iterations + 0.5 if
-                                          args.attack == "apgd" else args.iterations + 1.5) / 1e12,
+                                          args.attack == "apgd" else 0.49 * (args.iterations + 3) if
+                                          args.attack == "square" else args.iterations + 1.5) / 1e12,
         }
         res["whole_loop_frac_of_peak"] = res["whole_loop_tflops_per_gpu"] / PEAK_BF16_TFLOPS
         res["whole_loop_flop_basis"] = ("reference model FLOPs per image (SURVEY.md Appendix C); the engine's class-token "

@@ -101,14 +101,15 @@ class SquareAttack():
             if (margin_min < 0.0).all():
                 return n_queries, x_best
             x_new_buf = torch.empty_like(x)
+            todo = (margin_min > 0.0).nonzero().flatten()           # the one host sync per query
             for it in range(self.n_queries):
-                todo = (margin_min > 0.0).nonzero().flatten()
                 m = int(todo.numel())
                 p = p_selection(it, self.n_queries, self.p_init, self.rescale_schedule)
                 s = min(max(int(round(math.sqrt(p * n_features / c))), 1), min(h, w))
-                vh = int(self.random_int(0, h - s))
-                vw = int(self.random_int(0, w - s))
-                sign = self.random_choice([c, 1, 1]).reshape(c).contiguous()
+                # the reference's draws, in its order, on the CPU generator; only the signs travel to the device
+                vh = int((0 + (h - s - 0) * torch.rand([1])).long())
+                vw = int((0 + (w - s - 0) * torch.rand([1])).long())
+                sign = torch.sign(2 * torch.rand([c, 1, 1]) - 1).reshape(c).to(x.device, non_blocking=True)
                 if m > 0:
                     x_new = x_new_buf[:m]
                     L.check(lib.rvlm_square_linf_propose(x.data_ptr(), x_best.data_ptr(), todo.data_ptr(), m, c, h, w,
@@ -122,13 +123,14 @@ class SquareAttack():
                     L.check(lib.rvlm_square_accept(x_best.data_ptr(), x_new.data_ptr(), todo.data_ptr(),
                                                    take.data_ptr(), m, n_features, L.stream_ptr()), "rvlm_square_accept")
                     n_queries[todo] += 1.
-                done = (margin_min <= 0.).nonzero().flatten()
-                if self.verbose and done.numel() != 0:
+                todo = (margin_min > 0.0).nonzero().flatten()
+                if self.verbose and todo.numel() != n:
+                    done = (margin_min <= 0.).nonzero().flatten()
                     print('{}'.format(it + 1), '- success rate={}/{} ({:.2%})'.format(done.numel(), n, done.numel() / n),
                           '- avg # queries={:.1f}'.format(n_queries[done].mean().item()),
                           '- med # queries={:.1f}'.format(n_queries[done].median().item()),
                           '- loss={:.3f}'.format(loss_min.mean()))
-                if done.numel() == n:
+                if todo.numel() == 0:
                     break
         return n_queries, x_best
 
