@@ -429,7 +429,7 @@ static int forward_impl(rvlm_vit* h, const float* x, const float* delta, int B, 
                 if ((rc = layernorm_fwd<T>(x_mid, SW, y.ln2_w, y.ln2_b, (T*)ln2o, W, h->mean_at(2 + 2 * l),
                                            h->rstd_at(2 + 2 * l), B, W, s))) return rc;
                 if ((rc = linear_fwd<T>(h, s, ln2o, W, B, 4 * W, W, y.w_fc, y.w_fc_nk, y.b_fc, EPI_BF16_ACT,
-                                        gact, 4 * W, h->h_pre[sl], nullptr))) return rc;
+                                        gact, 4 * W, save ? h->h_pre[sl] : nullptr, nullptr))) return rc;
                 if ((rc = linear_fwd<T>(h, s, gact, 4 * W, B, W, 4 * W, y.w_proj, y.w_proj_nk, y.b_proj,
                                         EPI_F32_RESID, x_out, SW, nullptr, x_mid))) return rc;
             }
@@ -452,7 +452,7 @@ static int forward_impl(rvlm_vit* h, const float* x, const float* delta, int B, 
         {
             PROF("gemm_fc1_fwd", 2.0 * M * W * 4 * W, 0);
             if ((rc = linear_fwd<T>(h, s, ln2o, W, M, 4 * W, W, y.w_fc, y.w_fc_nk, y.b_fc, EPI_BF16_ACT,
-                                    gact, 4 * W, h->h_pre[sl], nullptr))) return rc;
+                                    gact, 4 * W, save ? h->h_pre[sl] : nullptr, nullptr))) return rc;
         }
         {
             PROF("gemm_fc2_fwd", 2.0 * M * W * 4 * W, 0);

@@ -168,7 +168,7 @@ splitk_reduce_kernel(const float* __restrict__ slabs, int splitk, GemmBf16 p) {
                 pv[e] = (bf16_t)dv;
                 ov[e] = (bf16_t)av;
             }
-            *(bf16x4*)(p.out_pre + o) = pv;
+            if (p.out_pre) *(bf16x4*)(p.out_pre + o) = pv;
             *(bf16x4*)((bf16_t*)p.out + o) = ov;
         } else if (EPI == EPI_BF16_DACT) {
             const bf16x4 hv = *(const bf16x4*)(p.h_pre + o);
@@ -297,7 +297,6 @@ int gemm_bf16_nt(const GemmBf16& p, hipStream_t s) {
         return fail(RVLM_ERR_ARG, "gemm_bf16_nt: bad arguments");
     if (p.K % GB_K != 0 || p.N % 4 != 0 || p.lda % 8 != 0 || p.ldb % 8 != 0 || p.ldo % 4 != 0)
         return fail(RVLM_ERR_UNSUPPORTED, "gemm_bf16_nt: need K%64==0, N%4==0, lda/ldb%8==0, ldo%4==0");
-    if (p.epi == EPI_BF16_ACT && !p.out_pre) return fail(RVLM_ERR_ARG, "gemm_bf16_nt: out_pre");
     if (p.epi == EPI_BF16_DACT && !p.h_pre) return fail(RVLM_ERR_ARG, "gemm_bf16_nt: h_pre");
     // deep-K, few-tile problems (the weight-gradient GEMMs: K = all tokens, <= 256 output tiles): split K so
     // that >= 2 workgroups per CU are busy, fp32 slabs + deterministic reduce/epilogue kernel
@@ -338,7 +337,8 @@ int gemm_bf16_nt(const GemmBf16& p, hipStream_t s) {
     // beats both older kernels on every encoder shape (scripts/gemm_bench.py, profiles/).  RVLM_GEMM_PERSIST=0
     // restores the per-shape choice between the one-tile-per-workgroup 256x256 kernel and the 128x128 kernel.
     if (variant != 0 && gemm_persist() && !small_m) {
-        int rc = gemm_waves() == 4 ? gemm_bf16_nt_256q(p, &done, s) : gemm_bf16_nt_256p(p, &done, s);
+        const bool no_pre = p.epi == EPI_BF16_ACT && !p.out_pre;   // only the default kernel knows the one-output form
+        int rc = (gemm_waves() == 4 && !no_pre) ? gemm_bf16_nt_256q(p, &done, s) : gemm_bf16_nt_256p(p, &done, s);
         if (rc) return rc;
         if (done >= p.M) return RVLM_OK;
     }

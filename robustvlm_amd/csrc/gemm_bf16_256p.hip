@@ -125,7 +125,7 @@ __device__ __forceinline__ void strip_tail(const GemmBf16& p, int m_done, int m_
             } else if (EPI == EPI_BF16_ACT) {
                 float a0v, d0v, a1v, d1v;
                 actp_pair<ACT>(v0, a0v, d0v); actp_pair<ACT>(v1, a1v, d1v);
-                p.out_pre[o] = (bf16_t)d0v; p.out_pre[o + 1] = (bf16_t)d1v;
+                if (p.out_pre) { p.out_pre[o] = (bf16_t)d0v; p.out_pre[o + 1] = (bf16_t)d1v; }
                 ((bf16_t*)p.out)[o] = (bf16_t)a0v; ((bf16_t*)p.out)[o + 1] = (bf16_t)a1v;
             } else if (EPI == EPI_BF16_DACT) {
                 ((bf16_t*)p.out)[o] = (bf16_t)(v0 * (float)p.h_pre[o]);
@@ -493,7 +493,9 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
                     store16(t2, rs, st16_loff, so + 32 * ldo);
                     store16(t3, rs, st16_loff, so + 48 * ldo);
                 };
-                stage_flush(EPI == EPI_BF16_ACT ? pre_rs : o_rs, EPI == EPI_BF16_ACT ? 2 : EPI == EPI_BF16_DACT ? 3 : 0);
+                // forward-only callers (no backward to come) pass out_pre = null: act'(h) is then not written
+                if (EPI != EPI_BF16_ACT || p.out_pre)
+                    stage_flush(EPI == EPI_BF16_ACT ? pre_rs : o_rs, EPI == EPI_BF16_ACT ? 2 : EPI == EPI_BF16_DACT ? 3 : 0);
                 if (EPI == EPI_BF16_ACT) stage_flush(o_rs, 1);
                 init_acc(mi, 0);
                 init_acc(mi, 1);

@@ -47,7 +47,7 @@ __device__ __forceinline__ void gemm_epilogue_edge(const f32x16 (&acc)[MI][NI], 
                     for (int e = 0; e < 4; ++e) {
                         float av, dv;
                         act_pair(v[e], p.act, av, dv);
-                        p.out_pre[o + e] = (bf16_t)dv;
+                        if (p.out_pre) p.out_pre[o + e] = (bf16_t)dv;
                         ((bf16_t*)p.out)[o + e] = (bf16_t)av;
                     }
                 } else if (EPI == EPI_BF16_DACT) {
@@ -129,8 +129,10 @@ __device__ __forceinline__ void gemm_epilogue_full(const f32x16 (&acc)[MI][2], c
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) act_pair(v[ni][g][e], p.act, v[ni][g][e], d[ni][g][e]);
-            stage_bf16(buf, d, l31, hi);
-            flush_bf16(buf, p.out_pre + row0, p.ldo, lane);
+            if (p.out_pre) {
+                stage_bf16(buf, d, l31, hi);
+                flush_bf16(buf, p.out_pre + row0, p.ldo, lane);
+            }
             stage_bf16(buf, v, l31, hi);
             flush_bf16(buf, (bf16_t*)p.out + row0, p.ldo, lane);
         } else {

@@ -45,7 +45,7 @@ struct GemmBf16 {
     int epi = EPI_BF16;
     const float* bias = nullptr;        // [N] or null
     void* out = nullptr; long ldo = 0;  // bf16 or f32 per epi
-    bf16_t* out_pre = nullptr;          // EPI_BF16_ACT: act'(h) (ld = ldo)
+    bf16_t* out_pre = nullptr;          // EPI_BF16_ACT: act'(h) (ld = ldo); null: not written (forward-only callers)
     const bf16_t* h_pre = nullptr;      // EPI_BF16_DACT: act'(h) of the matching forward (ld = ldo)
     const float* residual = nullptr;    // EPI_F32_RESID (ld = ldo)
     int act = RVLM_ACT_QUICK_GELU;

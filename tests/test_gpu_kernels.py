@@ -318,3 +318,21 @@ def test_gemm_bf16_remainder_rows_in_launch(r, N, K):
         assert torch.all(tall[M:] == 7.0)
     finally:
         lib().rvlm_k_gemm_set_variant(-1)
+
+
+@pytest.mark.parametrize("M,N,K", [(256 * 3 + 100, 512, 256), (128, 256, 1024), (300, 192, 64)])
+def test_gemm_bf16_act_epilogue_without_derivative_output(M, N, K):
+    """Forward-only callers pass out_pre = NULL to the activation epilogue: act(h) is written, act'(h) is not (every
+    kernel family: persistent + strip phase, few-row split-K, 128x128 with edge tiles)."""
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g, device=dev()).bfloat16()
+    Bw = (torch.randn(N, K, generator=g, device=dev()) * K ** -0.5).bfloat16()
+    bias = torch.randn(N, generator=g, device=dev())
+    ref_out, _ = gemm_bf16(A, Bw, epi=2, bias=bias, act=0)
+    Ap = torch.zeros((M + 255) // 256 * 256, K, dtype=torch.bfloat16, device=dev())
+    Ap[:M] = A
+    out = torch.zeros(M, N, dtype=torch.bfloat16, device=dev())
+    L.check(lib().rvlm_k_gemm_bf16_nt(Ap.data_ptr(), K, Bw.data_ptr(), K, M, N, K, Ap.shape[0], 2, bias.data_ptr(),
+                                      out.data_ptr(), N, None, None, None, 0, st()), "gemm")
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref_out)
