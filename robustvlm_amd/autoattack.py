@@ -234,6 +234,11 @@ class AutoAttack():
             if state_path is not None:
                 self._say("Created state in {}".format(state_path))
         todo = [a for a in self.attacks_to_run if a not in state.run_attacks]
+        missing = [a for a in todo if a in _KNOWN and (a not in _BUILT or (a == 'square' and not isinstance(
+            self.square, SquareAttack)))]
+        if missing:       # fail before hours of attack time are spent, not when the unbuilt attack's turn comes
+            raise NotImplementedError(f"attack(s) {missing} are not part of the native path (built: {', '.join(_BUILT)}; "
+                                      f"square is L-inf only)")
         self._say('using {} version including {}.'.format(self.version, ', '.join(todo)))
         if state.run_attacks:
             self._say('{} was/were already run.'.format(', '.join(state.run_attacks)))
