@@ -242,7 +242,8 @@ attn_fwd_odd_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict_
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Kt = smem;
     char* Vt = smem + (size_t)Sp * 128;
-    float* mrg = (float*)(smem + (size_t)Sp * 256);     // [NK][66]: m, sum, O[64] of the odd query per key tile
+    float* mrg = (float*)(smem + (size_t)Sp * 256);     // [NK][66]: m, sum, O[64] of the odd query per key tile; then NK x 32
+                                                          // bf16: p of the odd query, staged into B-operand order
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -336,18 +337,39 @@ attn_fwd_odd_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict_
             }
         if (hi == 0 && lse2) lse2[((long)b * H + h) * Sp + q] = m + log2f(ltot);
     }
-    {   // ---- the odd query against key tile w (every MFMA column carries the same query) ----
+    {   // ---- the odd query against key tile w, in the TRANSPOSED orientation: S = q K^T has the keys on the lanes and the
+        // (identical) query rows on the registers, so the softmax costs one exp per lane instead of sixteen; p goes
+        // through 64 B of LDS into the B-operand layout of the P.V product ----
         bf16x8 qf[4];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) qf[kk] = frag_global(base, ld, S - 1, kk, lane);
+        f32x16 st = zero16();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) st = MFMA(qf[kk], frag_rm(Kt, w * 32, fo.rm[kk]), st);
+        const float sc = st[0] * scale_log2;                  // key w*32 + l31 (same value on both lane halves)
+        float m = sc;
+#pragma unroll
+        for (int off = 1; off < 32; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+        const float pj = EXP2(sc - m);
+        float l = pj;
+#pragma unroll
+        for (int off = 1; off < 32; off <<= 1) l += __shfl_xor(l, off, 64);
+        bf16_t* pst = (bf16_t*)(mrg + NK * 66) + w * 32;
+        if (hi == 0) pst[l31] = (bf16_t)pj;
         f32x16 oacc[2] = {zero16(), zero16()};
-        float m = -INFINITY, l = 0.0f;
-        block(qf, w, m, l, oacc);
-        if (w == 0) odd_key(qf, m, l, oacc);
-        const float ltot = l + __shfl_xor(l, 32, 64);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x4 lo = *(const bf16x4*)(pst + 16 * ks + 4 * hi), up = *(const bf16x4*)(pst + 16 * ks + 8 + 4 * hi);
+            bf16x8 pb;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { pb[t] = lo[t]; pb[4 + t] = up[t]; }
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) oacc[dt] = MFMA(frag_tr(Vt, w * 32 + ks * 16, fo, dt), pb, oacc[dt]);
+        }
+        if (w == 0) odd_key(qf, m, l, oacc);                  // l is the wave total here: lane 0's copy is the one kept
         if (l31 == 0) {
             float* dst = mrg + w * 66;
-            if (hi == 0) { dst[0] = m; dst[1] = ltot; }
+            if (hi == 0) { dst[0] = m; dst[1] = l; }
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -877,7 +899,7 @@ int attn_fwd_bf16(const bf16_t* qkv, long ldqkv, bf16_t* o, long ldo, float* lse
     if (odd < 0) { const char* e = getenv("RVLM_ATTN_FWD_ODD"); odd = e ? atoi(e) : 1; }
     if (odd && g_use_tr && S == 257) {   // 8 waves, no padded tiles (see attn_fwd_odd_kernel)
         constexpr int NK = 8;
-        const size_t lds_o = (size_t)(32 * NK + 32) * 256 + (size_t)NK * 66 * sizeof(float);
+        const size_t lds_o = (size_t)(32 * NK + 32) * 256 + (size_t)NK * 66 * sizeof(float) + (size_t)NK * 64;
         if ((rc = set_lds(attn_fwd_odd_kernel<NK>, lds_o))) return rc;
         hipLaunchKernelGGL((attn_fwd_odd_kernel<NK>), dim3(B * H), dim3(NK * 64), lds_o, s, qkv, ldqkv, o, ldo, lse, H, W, sl2);
         RVLM_CHECK_LAUNCH();
