@@ -225,3 +225,14 @@ def test_zeroshot_head_and_accuracy_helper():
     y = torch.zeros(10, dtype=torch.long)
     y[:3] = 1
     assert abs(compute_accuracy_no_dataloader(_toy_classifier, x, y, "cpu", batch_size=4) - 0.7) < 1e-9
+
+
+def test_square_schedule_matches_oracle():
+    """The product's closed form of the Square Attack p schedule against the oracle's threshold table (square.py:192-219),
+    with and without the rescaling to n_queries."""
+    from robustvlm_amd.square import p_selection
+    from oracle.square_ref import p_schedule
+    for nq in (50, 123, 5000, 10000):
+        for resc in (True, False):
+            for it in list(range(0, 600)) + [999, 1000, 1001, 2000, 2001, 4000, 4001, 6000, 6001, 8000, 8001, 9999]:
+                assert p_selection(it, nq, .8, resc) == p_schedule(it, nq, .8, resc), (it, nq, resc)
