@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librvlm.so")
+# RVLM_LIB_PATH: development knob for A/B runs of two builds on one box (scripts/trip_ab.sh); never a fallback
+LIB_PATH = os.path.abspath(os.environ["RVLM_LIB_PATH"]) if os.environ.get("RVLM_LIB_PATH") else os.path.join(_HERE, "librvlm.so")
 
 RVLM_OK, RVLM_ERR_ARG, RVLM_ERR_HIP, RVLM_ERR_STATE, RVLM_ERR_UNSUPPORTED = 0, 1, 2, 3, 4
 PREC_F32, PREC_BF16 = 0, 1

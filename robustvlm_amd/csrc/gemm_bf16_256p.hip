@@ -148,8 +148,8 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
     // phase offset (performance only): with every workgroup in lockstep the epilogues' HBM bursts coincide chip-wide.  On
     // by default for the fc2 dgrad only (8 tiles per workgroup, epilogue reads act' from HBM: -3 %); measured neutral to
     // slightly negative for the other epilogues (2 tiles per workgroup: the offset costs as much tail as it hides)
-    if (p.stagger > 0) {
-        const int phase = (blockIdx.x >> 3) & (p.stagger >> 8);   // phases per XCD (blockIdx & 7 = XCD): mask in the high bits
+    if ((p.stagger & 255) > 0) {
+        const int phase = (blockIdx.x >> 3) & ((p.stagger >> 8) & 255);   // phases per XCD (blockIdx & 7 = XCD): mask in the high bits
         for (int i = 0; i < (p.stagger & 255) * phase; ++i) __builtin_amdgcn_s_sleep(127);
     }
 
@@ -299,6 +299,9 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
     f32x16 acc[4][2];
     auto mma = [&](const i32x4 (&a)[4], const i32x4 (&b)[2]) {
         if (ABL & 2) return;
+#ifdef RVLM_MFMA_PRIO
+        __builtin_amdgcn_s_setprio(RVLM_MFMA_PRIO);                   // experiment: MFMA groups at raised wave priority
+#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -306,6 +309,9 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b[j]),
                                                                     __builtin_bit_cast(bf16x8, a[i]), acc[i][j],
                                                                     0, 0, 0);
+#ifdef RVLM_MFMA_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
     };
     auto init_acc = [&](int mi, int ni) {
 #pragma unroll
