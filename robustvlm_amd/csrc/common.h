@@ -82,9 +82,11 @@ __device__ __forceinline__ float act_bwd(float h, int act) {
 // epilogue is one multiply instead of an exp + rcp per element
 __device__ __forceinline__ void act_pair(float h, int act, float& a, float& d) {
     if (act == RVLM_ACT_QUICK_GELU) {
-        const float s = 1.0f / (1.0f + __expf(-1.702f * h));
+        // the SAME instruction sequence as actp_pair<QUICK_GELU> of the persistent kernel (gemm_persist.h): which GEMM
+        // kernel a shape is routed to must not change the bits of act(h) / act'(h) (batch-split invariance)
+        const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(h * (-1.702f * 1.4426950408889634f)));
         a = h * s;
-        d = s * (1.0f + 1.702f * h * (1.0f - s));
+        d = __builtin_fmaf(1.702f, __builtin_fmaf(-a, s, a), s);
     } else {
         const float cdf = 0.5f * (1.0f + erff(h * 0.70710678118654752f));
         a = h * cdf;

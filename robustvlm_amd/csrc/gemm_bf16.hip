@@ -336,14 +336,26 @@ int gemm_bf16_nt(const GemmBf16& p, hipStream_t s) {
     // 1 or 2 (default): the persistent 256x256 kernel wherever the shape qualifies (N % 256 == 0, K % 128 == 0); it
     // beats both older kernels on every encoder shape (scripts/gemm_bench.py, profiles/).  RVLM_GEMM_PERSIST=0
     // restores the per-shape choice between the one-tile-per-workgroup 256x256 kernel and the 128x128 kernel.
-    if (variant != 0 && gemm_persist() && !small_m) {
+    // how full the persistent kernel's rounds of <= 256 tiles would be: a small problem (ViT-B/32 at batch 128: 75-300
+    // tiles) leaves most CUs idle or runs a nearly empty last round - the 128x128 kernel (4x the tiles, 2 workgroups per
+    // CU) then wins (+17 % on that model) although its mainloop is slower
+    bool sparse = false;
+    if (p.N % 256 == 0 && p.M >= 256) {
+        const long t256 = (long)(p.M / 256) * (p.N / 256);
+        static float min_fill = -1.0f;
+        if (min_fill < 0.0f) { const char* e = getenv("RVLM_GEMM_MIN_FILL"); min_fill = e ? (float)atof(e) : 0.7f; }
+        const float fill = (float)t256 / (float)(((t256 + 255) / 256) * 256);
+        // deep-K tiles amortise the persistent kernel's per-tile cost: there only a really empty chip (< 45 %) switches
+        sparse = fill < 0.45f || (fill < min_fill && p.K <= 1024);
+    }
+    if (variant != 0 && gemm_persist() && !small_m && !sparse) {
         const bool no_pre = p.epi == EPI_BF16_ACT && !p.out_pre;   // only the default kernel knows the one-output form
         int rc = (gemm_waves() == 4 && !no_pre) ? gemm_bf16_nt_256q(p, &done, s) : gemm_bf16_nt_256p(p, &done, s);
         if (rc) return rc;
         if (done >= p.M) return RVLM_OK;
     }
     const bool big = variant == 1 || (variant == 2 && (p.epi == EPI_BF16 || p.K >= 2048));
-    if (done == 0 && big && !small_m) {
+    if (done == 0 && big && !small_m && !sparse) {
         int rc = gemm_bf16_nt_256(p, &done, s);
         if (rc) return rc;
         if (done >= p.M) return RVLM_OK;
