@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RVLM_VERSION 102
+#define RVLM_VERSION 103
 
 typedef void* rvlm_stream_t; /* hipStream_t */
 typedef struct rvlm_vit rvlm_vit;
@@ -126,10 +126,19 @@ int rvlm_vit_backward_input(rvlm_vit* h, const float* d_emb, int B, float* grad_
  * (same struct / shapes as the weights).  No input gradient is produced. */
 int rvlm_vit_backward_params(rvlm_vit* h, const float* d_emb, int B, const rvlm_vit_weights* grads,
                              int accumulate, rvlm_stream_t stream);
+/* The same pass cut into stages (execution order): 0 = head (proj, ln_post), 1 + j = transformer block layers-1-j,
+ * layers + 1 = embeddings (ln_pre, positional / class embedding, conv1).  Runs stages [stage_begin, stage_end); the
+ * stages of one backward must be run in order.  The host uses it to all-reduce a finished gradient bucket (RCCL,
+ * side stream) while the remaining stages compute - the reference's DataParallel reduces inside backward as well
+ * (…clip.py:184-191). */
+int rvlm_vit_backward_params_stages(rvlm_vit* h, const float* d_emb, int B, const rvlm_vit_weights* grads,
+                                    int accumulate, int stage_begin, int stage_end, rvlm_stream_t stream);
 /* torch.optim.AdamW single-tensor step on flat fp32 buffers (optimizer.step(), …clip.py:196-197,362):
- * grads are multiplied by grad_scale first (1/world_size after a sum all-reduce). `step` counts from 1. */
+ * grads are multiplied by grad_scale first (1/world_size after a sum all-reduce). `step` counts from 1.  The
+ * hyper-parameters are doubles (Python floats in torch): bias corrections and step size are formed in double and
+ * rounded to fp32 where torch rounds them. */
 int rvlm_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n,
-                    float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                    double lr, double beta1, double beta2, double eps, double weight_decay, int step,
                     float grad_scale, rvlm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -148,6 +157,22 @@ int rvlm_loss_grad(int loss_kind, int reduction, const float* emb, const float* 
                    const int64_t* targets, const int64_t* y_target, int B, int D, int C, float logit_scale,
                    float* loss_per_sample, float* loss_scalar, float* d_emb, uint8_t* pred_eq,
                    float* scratch, rvlm_stream_t stream);
+/* ce() on given logits (…clip.py:523-528 = F.cross_entropy): per-sample loss, optional scalar (mean or sum per
+ * `reduction`), d_logits [B,C] = d loss / d logits (MEAN carries the 1/B; may alias logits), optional pred_eq. */
+int rvlm_ce_logits(const float* logits, const int64_t* targets, int B, int C, int reduction,
+                   float* loss_per_sample, float* loss_scalar, float* d_logits, uint8_t* pred_eq,
+                   rvlm_stream_t stream);
+/* Zero-shot head of ClassificationModel.forward (CLIP_eval/clip_robustbench.py:66-68): logits[B,C] = (emb[B,D] @
+ * T[D,C]) * scale, and its backward d_emb = (d_logits * scale) @ T^T. */
+int rvlm_head_logits(const float* emb, const float* T, int B, int D, int C, float scale, float* logits,
+                     rvlm_stream_t stream);
+int rvlm_head_logits_bwd(const float* d_logits, const float* T, int B, int D, int C, float scale, float* d_emb,
+                         rvlm_stream_t stream);
+/* Logging metrics of the training step (…clip.py:368-387): out_per_row[b] = F.cosine_similarity(a[b], b[b]) (eps 1e-8),
+ * optional *out_mean = their mean; F.normalize(e, dim=1) (eps 1e-12) with the reciprocal norms. */
+int rvlm_cosine_rows(const float* a, const float* b, int B, int D, float* out_per_row, float* out_mean,
+                     rvlm_stream_t stream);
+int rvlm_l2_normalize_rows(const float* e, int B, int D, float* out, float* inv_norm, rvlm_stream_t stream);
 /* out[b] = (argmax_j logits[b,j] == targets[b]); ties -> first index (…clip.py:490,
  * apgd_train.py:192,301). */
 int rvlm_argmax_eq(const float* logits, const int64_t* targets, int B, int C, uint8_t* out,
@@ -228,6 +253,15 @@ int rvlm_apgd_run(rvlm_vit* h, const float* x, const float* x_init, int B,
                   int train_variant, int logits_from_head, float* x_best_adv, float* x_best,
                   float* loss_best, uint8_t* acc, rvlm_stream_t stream);
 
+/* SURVEY.md section 8(b) `rvlm_vit_fwd_inputgrad`: ONE iteration's model work in one call - forward of x (+ delta,
+ * may be NULL) with the activations kept, the bound FARE / TeCoA loss, and grad_x = d loss / d (x + delta)
+ * (pgd_train.py:33-38: out = forward(...); loss = loss_fn(out, targets); autograd.grad(loss, perturbation)).
+ * Outputs (each optional): out_emb [B,out_dim], out_loss_per_sample [B], out_loss_scalar [1] (per loss->reduction),
+ * out_grad_x [B,3,H,W].  Equivalent to rvlm_vit_forward(save=1) + rvlm_loss_grad + rvlm_vit_backward_input. */
+int rvlm_vit_fwd_inputgrad(rvlm_vit* h, const float* x, const float* delta, int B, const rvlm_loss_spec* loss,
+                           float* out_emb, float* out_loss_per_sample, float* out_loss_scalar, float* out_grad_x,
+                           rvlm_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Input front end: replaces Compose([Resize(size, bicubic), CenterCrop(size),
  * ToTensor()]) over a decoded RGB image (train/adversarial_training_clip.py:105-116; torchvision 0.15.2 over Pillow).
@@ -256,7 +290,9 @@ int rvlm_vit_get_profile(rvlm_vit* h, rvlm_profile_entry* out, int* n);
 int rvlm_vit_reset_profile(rvlm_vit* h);
 
 const char* rvlm_last_error(void);
-int rvlm_version(void);   /* 101: rvlm_loss_spec.y_target, rvlm_loss_grad(y_target), DLR losses */
+int rvlm_version(void);   /* = RVLM_VERSION.  101: rvlm_loss_spec.y_target, rvlm_loss_grad(y_target), DLR losses;
+                           * 102: square-attack kernels; 103: rvlm_vit_fwd_inputgrad, rvlm_vit_backward_params_stages,
+                           * rvlm_ce_logits, rvlm_head_logits(_bwd), double hyper-parameters in rvlm_adamw_step */
 
 #ifdef __cplusplus
 }

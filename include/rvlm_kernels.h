@@ -29,8 +29,18 @@ int rvlm_k_attn_bwd_bf16(const uint16_t* qkv, const uint16_t* o, const uint16_t*
                          float* dsum_scratch, uint16_t* dqkv, int B, int H, int S, rvlm_stream_t stream);
 /* 1: ds_read_b64_tr_b16 transposed fragments (default); 0: scalar-LDS-read validation variant */
 int rvlm_k_attn_set_use_tr(int on);
-/* 0: 128x128 GEMM kernel only; 1: 256x256 4-stage kernel (+128x128 on remainder rows); -1: env RVLM_GEMM_VARIANT */
+/* 0: 128x128 GEMM kernel only; 1 / 2: the production dispatch (persistent 256x256 kernel unless the fill rule or the
+ * few-row rule sends the shape to the 128x128 kernel); 3: persistent kernel for every shape it can take (M >= 256,
+ * N % 256 == 0, K % 128 == 0) regardless of those rules; -1: env RVLM_GEMM_VARIANT (default 2) */
 int rvlm_k_gemm_set_variant(int v);
+/* Bit mask of the kernel families the last rvlm_k_gemm_bf16_nt call (or the engine's last GEMM) launched */
+#define RVLM_GEMM_K_128 1         /* gemm_bf16_nt_kernel, 128x128 tiles */
+#define RVLM_GEMM_K_256 2         /* one-tile-per-workgroup 256x256 kernel (EXPERIMENTAL builds only) */
+#define RVLM_GEMM_K_PERSISTENT 4  /* gemm_bf16_nt_256p_kernel, the persistent 256x256 kernel */
+#define RVLM_GEMM_K_256Q 8        /* 4-wave persistent kernel (EXPERIMENTAL builds only) */
+#define RVLM_GEMM_K_SPLITK 16     /* split-K slabs on the 128x128 kernel + splitk_reduce_kernel */
+#define RVLM_GEMM_K_STRIP 32      /* remainder rows computed by the persistent kernel's strip phase (same launch) */
+int rvlm_k_gemm_last_kernels(void);
 /* persistent 256x256 kernel: device buffer of 256*8*4 uint64 receiving per-tile s_memtime stamps (tile start, first
  * K-step done, mainloop done, epilogue issued); NULL switches tracing off */
 int rvlm_k_gemm_set_trace(void* ptr);

@@ -89,8 +89,18 @@ _SIGS = {
                                    c_stream]),
     "rvlm_vit_backward_input": (C.c_int, [C.c_void_p, c_f32p, C.c_int, c_f32p, c_stream]),
     "rvlm_vit_backward_params": (C.c_int, [C.c_void_p, c_f32p, C.c_int, C.POINTER(VitWeightsC), C.c_int, c_stream]),
-    "rvlm_adamw_step": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_size_t, C.c_float, C.c_float, C.c_float,
-                                  C.c_float, C.c_float, C.c_int, C.c_float, c_stream]),
+    "rvlm_vit_backward_params_stages": (C.c_int, [C.c_void_p, c_f32p, C.c_int, C.POINTER(VitWeightsC), C.c_int, C.c_int,
+                                                  C.c_int, c_stream]),
+    "rvlm_vit_fwd_inputgrad": (C.c_int, [C.c_void_p, c_f32p, c_f32p, C.c_int, C.POINTER(LossSpecC), c_f32p, c_f32p,
+                                         c_f32p, c_f32p, c_stream]),
+    "rvlm_ce_logits": (C.c_int, [c_f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, C.c_void_p,
+                                 c_stream]),
+    "rvlm_head_logits": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_float, c_f32p, c_stream]),
+    "rvlm_head_logits_bwd": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_float, c_f32p, c_stream]),
+    "rvlm_cosine_rows": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, c_f32p, c_f32p, c_stream]),
+    "rvlm_l2_normalize_rows": (C.c_int, [c_f32p, C.c_int, C.c_int, c_f32p, c_f32p, c_stream]),
+    "rvlm_adamw_step": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_size_t, C.c_double, C.c_double, C.c_double,
+                                  C.c_double, C.c_double, C.c_int, C.c_float, c_stream]),
     "rvlm_loss_grad": (C.c_int, [C.c_int, C.c_int, c_f32p, c_f32p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                  C.c_int, C.c_float, c_f32p, c_f32p, c_f32p, C.c_void_p, c_f32p,
                                  c_stream]),
@@ -135,6 +145,7 @@ _SIGS = {
                                        C.c_void_p, C.c_int, C.c_int, C.c_int, c_stream]),
     "rvlm_k_attn_set_use_tr": (C.c_int, [C.c_int]),
     "rvlm_k_gemm_set_variant": (C.c_int, [C.c_int]),
+    "rvlm_k_gemm_last_kernels": (C.c_int, []),
     "rvlm_k_gemm_set_trace": (C.c_int, [C.c_void_p]),
     "rvlm_k_gemm_set_ablate": (C.c_int, [C.c_int]),
     "rvlm_k_attn_occupancy": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),

@@ -14,7 +14,7 @@ import torch
 
 from . import _lib as L
 from .apgd_train import _apgd_linf_generic, apgd_schedule
-from .clip_model import ClassificationModel
+from .clip_model import ClassificationModel, ce
 from .engine import _require_cuda, _f32c
 
 
@@ -102,7 +102,7 @@ class APGDAttack():
                 y_target=self.y_target if self.loss == 'dlr-targeted' else None)
             return x_best, acc.bool(), loss_best, x_best_adv
         if self.loss == 'ce':
-            crit = lambda lg, yy: torch.nn.functional.cross_entropy(lg, yy, reduction='none')   # noqa: E731
+            crit = lambda lg, yy: ce(lg, yy, reduction='none')   # noqa: E731  (rvlm_ce_logits)
         else:
             crit = self.dlr_loss if self.loss == 'dlr' else self.dlr_loss_targeted
         return _apgd_linf_generic(self.model, crit, x, y, self.eps, self.n_iter, step0, False, x_init=start)

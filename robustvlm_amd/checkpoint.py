@@ -10,8 +10,11 @@ the outputs feed ``llava/model/multimodal_encoder/clip_encoder.py:51-59`` unchan
   ``*_temp`` output dir is renamed when training finishes (:242-244), and resuming asserts that the start step
   appears in the optimizer-state file name (:98-102).
 
-The optimizer file is keyed BY PARAMETER NAME ({'step', 'exp_avg': {key: t}, 'exp_avg_sq': {key: t}}) rather than
-by torch's positional parameter index: the flat-buffer AdamW of the native trainer has no module order.
+The optimizer file is ``torch.optim.AdamW(visual.parameters()).state_dict()`` as the reference writes it ({'state':
+{index: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [...]}, …clip.py:240,471): the positional index follows
+open_clip's ``visual.parameters()`` order (robustvlm_amd.config.parameter_order), so a reference run resumes from a
+file written here and ``AdversarialTrainer.load_optimizer_state_dict`` reads the reference's files (and the name-keyed
+files round 1 of this package wrote).
 """
 from __future__ import annotations
 

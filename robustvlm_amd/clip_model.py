@@ -106,11 +106,45 @@ def l2(out, targets, reduction="none"):
     return _LossFn.apply(out, targets, None, L.LOSS_L2, red, 1.0)
 
 
+class _CeLogitsFn(torch.autograd.Function):
+    """F.cross_entropy(logits, targets, reduction) and d loss / d logits from one rvlm_ce_logits call."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, reduction: int):
+        lib = L.load()
+        lg = _f32c(logits)
+        B, Ccls = lg.shape
+        tg = targets.detach().to(torch.int64).contiguous()
+        if tg.numel() and (int(tg.min()) < 0 or int(tg.max()) >= Ccls):
+            raise IndexError(f"Target out of bounds for {Ccls} classes")           # F.cross_entropy's check
+        per = torch.empty(B, dtype=torch.float32, device=lg.device)
+        scalar = torch.empty(1, dtype=torch.float32, device=lg.device)
+        d_logits = torch.empty_like(lg)
+        with torch.cuda.device(lg.device):
+            L.check(lib.rvlm_ce_logits(lg.data_ptr(), tg.data_ptr(), B, Ccls, reduction, per.data_ptr(),
+                                       scalar.data_ptr(), d_logits.data_ptr(), None, L.stream_ptr()), "rvlm_ce_logits")
+        ctx.save_for_backward(d_logits)
+        ctx.reduction = reduction
+        return scalar.reshape(()) if reduction == L.RED_MEAN else per
+
+    @staticmethod
+    def backward(ctx, g):
+        (d_logits,) = ctx.saved_tensors
+        if ctx.reduction == L.RED_MEAN:
+            return d_logits * g, None, None
+        return d_logits * g.reshape(-1, 1), None, None
+
+
 def ce(out, targets, reduction="mean"):
-    """cross entropy on logits (…clip.py:523-528)."""
+    """cross entropy on logits (…clip.py:523-528), on the device kernel of librvlm."""
     assert out.shape[0] == targets.shape[0], (out.shape, targets.shape)
     assert out.shape[0] > 1
-    return torch.nn.functional.cross_entropy(out, targets, reduction=reduction)
+    _require_cuda(out, "out")
+    if reduction not in ("mean", "none", "sum"):
+        raise ValueError(f"reduction {reduction} not supported")
+    if reduction == "sum":
+        return _CeLogitsFn.apply(out, targets, L.RED_NONE).sum()
+    return _CeLogitsFn.apply(out, targets, L.RED_MEAN if reduction == "mean" else L.RED_NONE)
 
 
 def compute_loss(loss_str, embedding, targets, embedding_orig, logit_scale,
@@ -164,6 +198,36 @@ def compute_acc(logits, targets):
     return (preds_clean.eq(targets).sum() / targets.shape[0]).item() * 100
 
 
+class _HeadLogitsFn(torch.autograd.Function):
+    """logits = (emb @ T) * scale on rvlm_head_logits / rvlm_head_logits_bwd (clip_robustbench.py:66-68)."""
+
+    @staticmethod
+    def forward(ctx, emb, T, scale: float):
+        lib = L.load()
+        e, t = _f32c(emb), _f32c(T)
+        B, D = e.shape
+        assert t.dim() == 2 and t.shape[0] == D, f"text embedding must be [{D}, C], got {tuple(t.shape)}"
+        logits = torch.empty(B, t.shape[1], dtype=torch.float32, device=e.device)
+        with torch.cuda.device(e.device):
+            L.check(lib.rvlm_head_logits(e.data_ptr(), t.data_ptr(), B, D, t.shape[1], float(scale), logits.data_ptr(),
+                                         L.stream_ptr()), "rvlm_head_logits")
+        ctx.save_for_backward(t)
+        ctx.scale = float(scale)
+        return logits
+
+    @staticmethod
+    def backward(ctx, g):
+        (t,) = ctx.saved_tensors
+        lib = L.load()
+        g = _f32c(g)
+        B, Ccls = g.shape
+        d_emb = torch.empty(B, t.shape[0], dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            L.check(lib.rvlm_head_logits_bwd(g.data_ptr(), t.data_ptr(), B, t.shape[0], Ccls, ctx.scale,
+                                             d_emb.data_ptr(), L.stream_ptr()), "rvlm_head_logits_bwd")
+        return d_emb, None, None
+
+
 class ClassificationModel(torch.nn.Module):
     """Zero-shot head on the native encoder (CLIP_eval/clip_robustbench.py:50-69):
     logits = normalize(encode_image(Normalize(resizer(x)))) @ T  [* exp(logit_scale) = 100]."""
@@ -183,8 +247,12 @@ class ClassificationModel(torch.nn.Module):
 
     def forward(self, vision, output_normalize=True):
         assert output_normalize
-        embedding_norm_ = self.vision(self.resizer(vision), True)
-        logits = embedding_norm_ @ self.text_embedding
-        if self.logit_scale:
-            logits = logits * self.logit_scale_value
-        return logits
+        vision = self.resizer(vision)
+        mb = self.model.max_batch
+        if vision.shape[0] > mb and not (torch.is_grad_enabled() and vision.requires_grad):
+            # evaluation batches larger than the engine's workspace (AutoAttack's bs=250 on a max_batch=128 engine)
+            # are encoded in chunks; a differentiable call must fit (one saved forward per engine)
+            return torch.cat([self.forward(vision[i:i + mb]) for i in range(0, vision.shape[0], mb)], 0)
+        embedding_norm_ = self.vision(vision, True)
+        return _HeadLogitsFn.apply(embedding_norm_, self.text_embedding,
+                                   self.logit_scale_value if self.logit_scale else 1.0)

@@ -57,6 +57,31 @@ def state_dict_shapes(cfg: VitConfig) -> dict:
     return shapes
 
 
+def parameter_order(cfg: VitConfig) -> list:
+    """Keys in the order of open_clip's ``visual.parameters()`` - the positional index torch.optim.AdamW's
+    ``state_dict()`` uses for its 'state' entries (…clip.py:196-197,239-240): a module's own Parameters first
+    (class_embedding, positional_embedding, proj), then its sub-modules in registration order (conv1, ln_pre,
+    transformer, ln_post)."""
+    keys = ["class_embedding", "positional_embedding", "proj", "conv1.weight", "ln_pre.weight", "ln_pre.bias"]
+    for i in range(cfg.layers):
+        p = f"transformer.resblocks.{i}."
+        keys += [p + s for s in ("ln_1.weight", "ln_1.bias", "attn.in_proj_weight", "attn.in_proj_bias",
+                                 "attn.out_proj.weight", "attn.out_proj.bias", "ln_2.weight", "ln_2.bias",
+                                 "mlp.c_fc.weight", "mlp.c_fc.bias", "mlp.c_proj.weight", "mlp.c_proj.bias")]
+    return keys + ["ln_post.weight", "ln_post.bias"]
+
+
+def backward_stage_keys(cfg: VitConfig) -> list:
+    """Parameter keys grouped by the stage of the parameter backward that finishes their gradient
+    (rvlm_vit_backward_params_stages): [head, block L-1, ..., block 0, embeddings]."""
+    blocks = []
+    for i in reversed(range(cfg.layers)):
+        p = f"transformer.resblocks.{i}."
+        blocks.append([k for k in state_dict_shapes(cfg) if k.startswith(p)])
+    return [["proj", "ln_post.weight", "ln_post.bias"]] + blocks + \
+           [["ln_pre.weight", "ln_pre.bias", "positional_embedding", "class_embedding", "conv1.weight"]]
+
+
 def random_state_dict(cfg: VitConfig, seed: int = 0, device="cuda"):
     """Seeded random-init weights with open_clip-like scales, generated on ``device`` (used by
     bench.py: no checkpoints are reachable offline)."""

@@ -370,6 +370,10 @@ static int forward_impl(rvlm_vit* h, const float* x, const float* delta, int B, 
     const int S = h->S, W = h->W, L = h->L, D = h->D, M = B * S, M0 = B * h->G * h->G;
     const double attn_flops = 4.0 * B * h->H * (double)S * S * 64;
     int rc;
+    // EVERY forward overwrites state a pending backward reads (the shared LayerNorm statistics of all layers, slot 0 of
+    // xs / qkv / attn_o / lse, pooled, emb_raw, inv_norm): a non-saving pass therefore invalidates the saved forward
+    // instead of letting a later backward run on a mixture of two passes.
+    h->saved_B = 0;
     {
         PROF("patch_im2col", 0, (double)B * 3 * h->img * h->img * (delta ? 8 : 4) + (double)M0 * h->Kpad * sizeof(T));
         if ((rc = im2col_normalize<T>(x, delta, B, h->img, h->P, h->cfg.mean, h->cfg.std, (T*)h->A0, h->Kpad, h->Kpad, s))) return rc;
@@ -650,13 +654,18 @@ int wgrad<float>(rvlm_vit* h, hipStream_t s, const void* dY, long lddy, const vo
     return gemm_f32(g, s);
 }
 
+// Stages of the parameter backward, in execution order: 0 = head (proj, ln_post), 1 + j = transformer block L-1-j,
+// L + 1 = embeddings (ln_pre, positional / class embedding, conv1).  [stage_begin, stage_end) lets the host cut the
+// pass into gradient buckets whose all-reduce overlaps the remaining stages (robustvlm_amd/trainer.py).
 template <typename T>
 static int backward_params_impl(rvlm_vit* h, const float* d_emb, int B, const rvlm_vit_weights* gw, int acc,
-                                hipStream_t s) {
+                                int stage_begin, int stage_end, hipStream_t s) {
     const int S = h->S, W = h->W, L = h->L, D = h->D, M = B * S, M0 = B * h->G * h->G;
     constexpr bool LP = !std::is_same<T, float>::value;
     auto G = [](const float* p) { return const_cast<float*>(p); };
     int rc;
+    const void* dres_A = LP ? (const void*)h->dres_lp : (const void*)h->dres;
+    if (stage_begin <= 0 && stage_end > 0) {
     // ---- head ----
     const float* d_raw = d_emb;
     if (h->saved_norm) {
@@ -691,8 +700,9 @@ static int backward_params_impl(rvlm_vit* h, const float* d_emb, int B, const rv
     if ((rc = layernorm_bwd<float, T>(h->d_pooled, W, h->xs[2 * L], (long)S * W, h->lnpost_w, h->mean_at(2 * L + 1),
                                       h->rstd_at(2 * L + 1), h->dres, (long)S * W, LP ? (T*)h->dres_lp : nullptr,
                                       (long)S * W, 0, B, W, s))) return rc;
-    const void* dres_A = LP ? (const void*)h->dres_lp : (const void*)h->dres;
+    }
     for (int l = L - 1; l >= 0; --l) {
+        if (L - l < stage_begin || L - l >= stage_end) continue;
         Layer& y = h->layers[l];
         const rvlm_vit_block_weights& gb = gw->blocks_host[l];
         // last block with the class-token tail: only the B class-token rows are live from here up to the attention
@@ -740,6 +750,7 @@ static int backward_params_impl(rvlm_vit* h, const float* d_emb, int B, const rv
                                       tail ? -S : 1, M, W, s)))
             return rc;
     }
+    if (stage_end <= L + 1) return RVLM_OK;
     // ---- embeddings: ln_pre, positional / class embedding, conv1 ----
     if ((rc = ln_param_grad<float>(h->dres, W, h->tokens, W, h->mean_at(0), h->rstd_at(0), M, W, G(gw->ln_pre_weight),
                                    G(gw->ln_pre_bias), acc, h->red_scratch, h->red_floats, s))) return rc;
@@ -954,8 +965,21 @@ extern "C" int rvlm_vit_backward_params(rvlm_vit* h, const float* d_emb, int B, 
     if (h->saved_B != B || B <= 0 || h->saved_mode != 2)
         return fail(RVLM_ERR_STATE, "rvlm_vit_backward_params: needs a forward with save_for_backward == 2 for this batch");
     hipStream_t s = (hipStream_t)stream;
-    return h->bf16 ? backward_params_impl<bf16_t>(h, d_emb, B, grads, accumulate, s)
-                   : backward_params_impl<float>(h, d_emb, B, grads, accumulate, s);
+    return h->bf16 ? backward_params_impl<bf16_t>(h, d_emb, B, grads, accumulate, 0, h->L + 2, s)
+                   : backward_params_impl<float>(h, d_emb, B, grads, accumulate, 0, h->L + 2, s);
+}
+
+extern "C" int rvlm_vit_backward_params_stages(rvlm_vit* h, const float* d_emb, int B, const rvlm_vit_weights* grads,
+                                               int accumulate, int stage_begin, int stage_end, rvlm_stream_t stream) {
+    RVLM_REQUIRE(h && d_emb && grads && grads->blocks_host, "rvlm_vit_backward_params_stages: null argument");
+    if (!h->trainable) return fail(RVLM_ERR_STATE, "rvlm_vit_backward_params_stages: handle was not created trainable");
+    if (h->saved_B != B || B <= 0 || h->saved_mode != 2)
+        return fail(RVLM_ERR_STATE, "rvlm_vit_backward_params_stages: needs a forward with save_for_backward == 2 for this batch");
+    RVLM_REQUIRE(stage_begin >= 0 && stage_begin < stage_end && stage_end <= h->L + 2,
+                 "rvlm_vit_backward_params_stages: need 0 <= stage_begin < stage_end <= layers + 2");
+    hipStream_t s = (hipStream_t)stream;
+    return h->bf16 ? backward_params_impl<bf16_t>(h, d_emb, B, grads, accumulate, stage_begin, stage_end, s)
+                   : backward_params_impl<float>(h, d_emb, B, grads, accumulate, stage_begin, stage_end, s);
 }
 
 static int loss_step(rvlm_vit* h, const rvlm_loss_spec* ls, int B, int reduction, float* loss_scalar,
@@ -967,6 +991,27 @@ static int loss_step(rvlm_vit* h, const rvlm_loss_spec* ls, int B, int reduction
     PROF("loss", 0, 0);
     return rvlm_loss_grad(ls->loss_kind, reduction, h->emb, ls->ref, ls->targets, ls->y_target, B, h->D, ls->n_classes,
                           ls->logit_scale, h->loss_ps, loss_scalar, h->d_emb, pred_eq, h->loss_scratch, s);
+}
+
+// one call = forward (activations kept) + FARE / TeCoA loss + input gradient, i.e. what one
+// iteration of pgd_train.py:33-38 asks of the model (out = forward(x + delta); loss = loss_fn(out, targets);
+// grad = autograd.grad(loss, delta)).  Every output pointer is optional.
+extern "C" int rvlm_vit_fwd_inputgrad(rvlm_vit* h, const float* x, const float* delta, int B, const rvlm_loss_spec* loss,
+                                      float* out_emb, float* out_loss_per_sample, float* out_loss_scalar,
+                                      float* out_grad_x, rvlm_stream_t stream) {
+    RVLM_REQUIRE(h && x && loss && loss->ref, "rvlm_vit_fwd_inputgrad: null argument");
+    RVLM_REQUIRE(B > 1 && B <= h->maxB, "rvlm_vit_fwd_inputgrad: need 1 < B <= max_batch");
+    RVLM_REQUIRE(!h->inference_only, "rvlm_vit_fwd_inputgrad: inference-only handle");
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if ((rc = vit_forward(h, x, delta, B, loss->output_normalize, 1, h->emb, s))) return rc;
+    if ((rc = loss_step(h, loss, B, loss->reduction, out_loss_scalar ? h->loss_scalar : nullptr, nullptr, s))) return rc;
+    const size_t eb = (size_t)B * h->D * 4;
+    if (out_emb) RVLM_HIP(hipMemcpyAsync(out_emb, h->emb, eb, hipMemcpyDeviceToDevice, s));
+    if (out_loss_per_sample) RVLM_HIP(hipMemcpyAsync(out_loss_per_sample, h->loss_ps, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+    if (out_loss_scalar) RVLM_HIP(hipMemcpyAsync(out_loss_scalar, h->loss_scalar, 4, hipMemcpyDeviceToDevice, s));
+    if (out_grad_x && (rc = vit_backward(h, h->d_emb, B, out_grad_x, s))) return rc;
+    return RVLM_OK;
 }
 
 extern "C" int rvlm_pgd_run(rvlm_vit* h, const float* x, const float* delta0, int B,

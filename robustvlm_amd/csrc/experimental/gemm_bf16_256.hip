@@ -11,8 +11,8 @@
 //
 // Requirements: M % 256 == 0 rows handled here (the caller runs the 128x128 kernel on the remainder
 // rows), N % 256 == 0, K % 32 == 0.
-#include "kernels.h"
-#include "gemm_epilogue.h"
+#include "../kernels.h"
+#include "../gemm_epilogue.h"
 
 namespace rvlm {
 

@@ -10,8 +10,8 @@
 //
 // Everything else is gemm_bf16_256p.hip: tile order, A ring 3 x 32 KiB + B ring 2 x 32 KiB (A three K-steps ahead, B
 // two), one barrier per K-step, counted vmcnt, epilogue through the freed B slot.
-#include "kernels.h"
-#include "gemm_persist.h"
+#include "../kernels.h"
+#include "../gemm_persist.h"
 
 namespace rvlm {
 

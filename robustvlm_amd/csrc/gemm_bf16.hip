@@ -13,6 +13,7 @@
 // XCD-aware (each XCD's L2 sees a contiguous group of tiles) with GROUP_M=8 tile grouping.
 #include "kernels.h"
 #include "gemm_epilogue.h"
+#include "../../include/rvlm_kernels.h"
 
 namespace rvlm {
 
@@ -183,9 +184,16 @@ splitk_reduce_kernel(const float* __restrict__ slabs, int splitk, GemmBf16 p) {
 }
 
 
-int gemm_bf16_nt_256(const GemmBf16& p, int* rows_done, hipStream_t s);
 int gemm_bf16_nt_256p(const GemmBf16& p, int* rows_done, hipStream_t s);
+#ifdef RVLM_EXPERIMENTAL_GEMM   // ablation kernels (make EXPERIMENTAL=1): not part of the shipped library
+int gemm_bf16_nt_256(const GemmBf16& p, int* rows_done, hipStream_t s);
 int gemm_bf16_nt_256q(const GemmBf16& p, int* rows_done, hipStream_t s);
+#endif
+
+// Which kernel families the last gemm_bf16_nt() call launched (test surface: rvlm_k_gemm_last_kernels): the parity
+// tests assert that the family they name is the one that ran - a dispatch rule must not silently move them.
+static int g_last_kernels = 0;
+int gemm_last_kernels() { return g_last_kernels; }
 
 static int g_waves = -1;   // persistent kernel flavour: 8 waves x 128x64 (default) or 4 waves x 128x128
 static int gemm_waves() {
@@ -199,10 +207,11 @@ static int gemm_persist() {
     return g_persist;
 }
 
-// 0: 128x128 kernel only; 1: 256x256 kernels (+128x128 on the remainder rows) wherever they apply;
-// 2 (default): persistent 256x256 kernel where the shape qualifies, else (or with RVLM_GEMM_PERSIST=0) the older
-// per-shape choice: one-tile-per-workgroup 256x256 kernel when the mainloop dominates (plain bf16 epilogue or
-// K >= 2048), 128x128 kernel (2 workgroups per CU) under a heavy epilogue on a K=1024 mainloop.
+// 0: 128x128 kernel only; 1 / 2 (default): persistent 256x256 kernel where the shape qualifies and the fill rule
+// below does not send it to the 128x128 kernel; 3: persistent kernel for EVERY shape it can take (M >= 256,
+// N % 256 == 0, K % 128 == 0), fill rule and few-row rule off - the parity tests of the persistent kernel run under 3.
+// (EXPERIMENTAL builds with RVLM_GEMM_PERSIST=0: the older per-shape choice between the one-tile-per-workgroup 256x256
+// kernel and the 128x128 kernel.)
 static int g_gemm_variant = -1;
 void gemm_set_variant(int v) { g_gemm_variant = v; }
 static int gemm_variant() {
@@ -325,14 +334,16 @@ int gemm_bf16_nt(const GemmBf16& p, hipStream_t s) {
             else
                 hipLaunchKernelGGL((splitk_reduce_kernel<EPI_F32>), dim3(rb), dim3(256), 0, s, p.splitk, splitk, p);
             RVLM_CHECK_LAUNCH();
+            g_last_kernels = RVLM_GEMM_K_SPLITK;
             return RVLM_OK;
         }
     }
     int done = 0;
     const int variant = gemm_variant();
+    g_last_kernels = 0;
     // few-row problems (the class-token rows of the last block: M = batch): a handful of 256x256 tiles cannot fill the
     // chip - they take the 128x128 kernel with split-K below
-    const bool small_m = p.M <= 512;
+    const bool small_m = p.M <= 512 && variant != 3;
     // 1 or 2 (default): the persistent 256x256 kernel wherever the shape qualifies (N % 256 == 0, K % 128 == 0); it
     // beats both older kernels on every encoder shape (scripts/gemm_bench.py, profiles/).  RVLM_GEMM_PERSIST=0
     // restores the per-shape choice between the one-tile-per-workgroup 256x256 kernel and the 128x128 kernel.
@@ -346,20 +357,31 @@ int gemm_bf16_nt(const GemmBf16& p, hipStream_t s) {
         if (min_fill < 0.0f) { const char* e = getenv("RVLM_GEMM_MIN_FILL"); min_fill = e ? (float)atof(e) : 0.7f; }
         const float fill = (float)t256 / (float)(((t256 + 255) / 256) * 256);
         // deep-K tiles amortise the persistent kernel's per-tile cost: there only a really empty chip (< 45 %) switches
-        sparse = fill < 0.45f || (fill < min_fill && p.K <= 1024);
+        sparse = variant != 3 && (fill < 0.45f || (fill < min_fill && p.K <= 1024));
     }
     if (variant != 0 && gemm_persist() && !small_m && !sparse) {
+        int rc;
+#ifdef RVLM_EXPERIMENTAL_GEMM
         const bool no_pre = p.epi == EPI_BF16_ACT && !p.out_pre;   // only the default kernel knows the one-output form
-        int rc = (gemm_waves() == 4 && !no_pre) ? gemm_bf16_nt_256q(p, &done, s) : gemm_bf16_nt_256p(p, &done, s);
+        if (gemm_waves() == 4 && !no_pre) { rc = gemm_bf16_nt_256q(p, &done, s); if (done) g_last_kernels |= RVLM_GEMM_K_256Q; }
+        else
+#endif
+        {
+            rc = gemm_bf16_nt_256p(p, &done, s);
+            if (done) g_last_kernels |= RVLM_GEMM_K_PERSISTENT | (done > (p.M / 256) * 256 ? RVLM_GEMM_K_STRIP : 0);
+        }
         if (rc) return rc;
         if (done >= p.M) return RVLM_OK;
     }
+#ifdef RVLM_EXPERIMENTAL_GEMM
     const bool big = variant == 1 || (variant == 2 && (p.epi == EPI_BF16 || p.K >= 2048));
     if (done == 0 && big && !small_m && !sparse) {
         int rc = gemm_bf16_nt_256(p, &done, s);
         if (rc) return rc;
+        if (done) g_last_kernels |= RVLM_GEMM_K_256;
         if (done >= p.M) return RVLM_OK;
     }
+#endif
     GemmBf16 r = p;
     if (done > 0) {   // remainder rows [done, M) on the 128x128 kernel
         const bool f32out = (p.epi == EPI_F32_RESID || p.epi == EPI_F32);
@@ -403,9 +425,11 @@ int gemm_bf16_nt(const GemmBf16& p, hipStream_t s) {
                 default: hipLaunchKernelGGL((splitk_reduce_kernel<EPI_F32>), dim3(rb), dim3(256), 0, s, p.splitk, splitk, r); break;
             }
             RVLM_CHECK_LAUNCH();
+            g_last_kernels |= RVLM_GEMM_K_SPLITK;
             return RVLM_OK;
         }
     }
+    g_last_kernels |= RVLM_GEMM_K_128;
     return gemm_bf16_nt_128(r, s);
 }
 

@@ -171,6 +171,20 @@ argmax_eq_kernel(const float* __restrict__ logits, const int64_t* __restrict__ t
     if (lane == 0) out[row] = ((int64_t)mi == targets[row]) ? 1 : 0;
 }
 
+// F.cosine_similarity(a, b, dim=1, eps=1e-8) per row: a.b / sqrt(max(|a|^2 |b|^2, eps^2)); one wave per row
+__global__ void __launch_bounds__(256)
+cosine_rows_kernel(const float* __restrict__ a, const float* __restrict__ b, int B, int D, float* __restrict__ out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B) return;
+    float ab = 0.0f, aa = 0.0f, bb = 0.0f;
+    for (int c = lane; c < D; c += 64) {
+        const float x = a[(long)row * D + c], y = b[(long)row * D + c];
+        ab = fmaf(x, y, ab); aa = fmaf(x, x, aa); bb = fmaf(y, y, bb);
+    }
+    ab = wave_sum(ab); aa = wave_sum(aa); bb = wave_sum(bb);
+    if (lane == 0) out[row] = ab / sqrtf(fmaxf(aa * bb, 1e-16f));
+}
+
 }  // namespace rvlm
 
 using namespace rvlm;
@@ -244,4 +258,66 @@ extern "C" int rvlm_argmax_eq(const float* logits, const int64_t* targets, int B
                        targets, B, C, out);
     RVLM_CHECK_LAUNCH();
     return RVLM_OK;
+}
+
+// ---- plain cross entropy on given logits (ce(), train/adversarial_training_clip.py:523-528) ----------------------
+extern "C" int rvlm_ce_logits(const float* logits, const int64_t* targets, int B, int C, int reduction,
+                              float* loss_per_sample, float* loss_scalar, float* d_logits, uint8_t* pred_eq,
+                              rvlm_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    RVLM_REQUIRE(logits && targets && d_logits && loss_per_sample && B > 0 && C > 0, "rvlm_ce_logits: bad arguments");
+    RVLM_REQUIRE(B > 1, "rvlm_ce_logits: batch size must be > 1 (reference asserts out.shape[0] > 1)");
+    RVLM_REQUIRE(reduction == RVLM_RED_MEAN || reduction == RVLM_RED_NONE, "rvlm_ce_logits: unknown reduction");
+    const float gscale = (reduction == RVLM_RED_MEAN) ? 1.0f / (float)B : 1.0f;
+    if (d_logits != logits) RVLM_HIP(hipMemcpyAsync(d_logits, logits, (size_t)B * C * 4, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(ce_loss_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, d_logits, targets, B, C, gscale,
+                       loss_per_sample, pred_eq, 1);
+    RVLM_CHECK_LAUNCH();
+    if (loss_scalar) {
+        hipLaunchKernelGGL(reduce_loss_kernel, dim3(1), dim3(256), 0, s, loss_per_sample, B,
+                           reduction == RVLM_RED_MEAN ? 1.0f / (float)B : 1.0f, loss_scalar);
+        RVLM_CHECK_LAUNCH();
+    }
+    return RVLM_OK;
+}
+
+// ---- zero-shot head of ClassificationModel.forward (CLIP_eval/clip_robustbench.py:66-68): logits = (emb @ T) * scale,
+// in that order; backward d_emb = (d_logits * scale) @ T^T --------------------------------------------------------------
+extern "C" int rvlm_head_logits(const float* emb, const float* T, int B, int D, int C, float scale, float* logits,
+                                rvlm_stream_t stream) {
+    RVLM_REQUIRE(emb && T && logits && B > 0 && D > 0 && C > 0, "rvlm_head_logits: bad arguments");
+    GemmF32 g;
+    g.A = emb; g.sam = D; g.sak = 1;
+    g.B = T; g.sbn = 1; g.sbk = C;
+    g.C = logits; g.scm = C; g.scn = 1;
+    g.M = B; g.N = C; g.K = D; g.alpha = scale;     // alpha multiplies the finished fp32 dot product: (emb @ T) * scale
+    return gemm_f32(g, (hipStream_t)stream);
+}
+extern "C" int rvlm_head_logits_bwd(const float* d_logits, const float* T, int B, int D, int C, float scale,
+                                    float* d_emb, rvlm_stream_t stream) {
+    RVLM_REQUIRE(d_logits && T && d_emb && B > 0 && D > 0 && C > 0, "rvlm_head_logits_bwd: bad arguments");
+    GemmF32 h;
+    h.A = d_logits; h.sam = C; h.sak = 1;
+    h.B = T; h.sbn = C; h.sbk = 1;          // (n = d, k = c)
+    h.C = d_emb; h.scm = D; h.scn = 1;
+    h.M = B; h.N = D; h.K = C; h.alpha = scale;
+    return gemm_f32(h, (hipStream_t)stream);
+}
+
+// ---- logging metrics of the training step (train/adversarial_training_clip.py:368-387) -------------------------------
+extern "C" int rvlm_cosine_rows(const float* a, const float* b, int B, int D, float* out_per_row, float* out_mean,
+                                rvlm_stream_t stream) {
+    RVLM_REQUIRE(a && b && out_per_row && B > 0 && D > 0, "rvlm_cosine_rows: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(cosine_rows_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, a, b, B, D, out_per_row);
+    RVLM_CHECK_LAUNCH();
+    if (out_mean) {
+        hipLaunchKernelGGL(reduce_loss_kernel, dim3(1), dim3(256), 0, s, out_per_row, B, 1.0f / (float)B, out_mean);
+        RVLM_CHECK_LAUNCH();
+    }
+    return RVLM_OK;
+}
+extern "C" int rvlm_l2_normalize_rows(const float* e, int B, int D, float* out, float* inv_norm, rvlm_stream_t stream) {
+    RVLM_REQUIRE(e && out && inv_norm && B > 0 && D > 0, "rvlm_l2_normalize_rows: bad arguments");
+    return l2_normalize_fwd(e, out, inv_norm, B, D, (hipStream_t)stream);
 }

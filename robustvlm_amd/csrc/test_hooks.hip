@@ -6,6 +6,7 @@
 namespace rvlm {
 void attn_set_use_tr(int on);
 void gemm_set_variant(int v);
+int gemm_last_kernels();
 void gemm_set_trace(unsigned long long* ptr);
 void gemm_set_ablate(int v);
 int attn_occupancy(int S, int* out3);
@@ -58,6 +59,7 @@ extern "C" int rvlm_k_attn_bwd_bf16(const uint16_t* qkv, const uint16_t* o, cons
 }
 extern "C" int rvlm_k_attn_set_use_tr(int on) { attn_set_use_tr(on); return RVLM_OK; }
 extern "C" int rvlm_k_gemm_set_variant(int v) { gemm_set_variant(v); return RVLM_OK; }
+extern "C" int rvlm_k_gemm_last_kernels(void) { return gemm_last_kernels(); }
 extern "C" int rvlm_k_gemm_set_ablate(int v) { gemm_set_ablate(v); return RVLM_OK; }
 extern "C" int rvlm_k_gemm_set_trace(void* ptr) { gemm_set_trace((unsigned long long*)ptr); return RVLM_OK; }
 extern "C" int rvlm_k_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y,

@@ -254,16 +254,18 @@ template int gather_patch_rows<bf16_t>(const float*, long, int, int, int, bf16_t
 //   p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
 __global__ void __launch_bounds__(256)
 adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-             size_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+             size_t n, float decay, float w1, float b2, float w2, float eps, float step_size, float bc2_sqrt,
              float grad_scale) {
+    // torch.optim.AdamW, single-tensor path: every scalar below is a Python double in torch, rounded to fp32 when it
+    // meets the fp32 tensor - the host computes them in double and passes the rounded values
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float gi = g[i] * grad_scale;
         float pi = p[i];
-        pi = pi * (1.0f - lr * wd);
-        const float mi = m[i] + (gi - m[i]) * (1.0f - b1);          // lerp form used by torch
-        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        pi = pi * decay;                                             // param.mul_(1 - lr * weight_decay)
+        const float mi = m[i] + (gi - m[i]) * w1;                    // exp_avg.lerp_(grad, 1 - beta1)
+        const float vi = b2 * v[i] + w2 * gi * gi;                   // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
         const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        pi = pi - (lr / bc1) * (mi / denom);
+        pi = pi - step_size * (mi / denom);                          // param.addcdiv_(exp_avg, denom, value=-step_size)
         p[i] = pi; m[i] = mi; v[i] = vi;
     }
 }
@@ -273,16 +275,18 @@ adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restri
 using namespace rvlm;
 
 extern "C" int rvlm_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n,
-                               float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                               double lr, double beta1, double beta2, double eps, double weight_decay, int step,
                                float grad_scale, rvlm_stream_t stream) {
     RVLM_REQUIRE(params && grads && exp_avg && exp_avg_sq && step >= 1, "rvlm_adamw_step: bad arguments");
-    const float bc1 = 1.0f - powf(beta1, (float)step);
-    const float bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
+    // bias corrections in double, like torch's Python scalars (fp32 powf was a ~1e-5 relative step error early on)
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2_sqrt = sqrt(1.0 - pow(beta2, (double)step));
     size_t blocks = (n + 1023) / 1024;
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(adamw_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
-                       exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_scale);
+                       exp_avg_sq, n, (float)(1.0 - lr * weight_decay), (float)(1.0 - beta1), (float)beta2,
+                       (float)(1.0 - beta2), (float)eps, (float)(lr / bc1), (float)bc2_sqrt, grad_scale);
     RVLM_CHECK_LAUNCH();
     return RVLM_OK;
 }

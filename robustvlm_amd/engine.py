@@ -36,6 +36,8 @@ class VitEngine:
         self.precision = precision
         self.max_batch = int(max_batch)
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        if self.device.index is None:
+            self.device = torch.device(f"cuda:{torch.cuda.current_device()}")
         self.mean, self.std = tuple(float(v) for v in mean), tuple(float(v) for v in std)
         self.generation = 0
         self._h = C.c_void_p()
@@ -103,6 +105,8 @@ class VitEngine:
             raise ValueError(f"expected [B,3,{c.image_size},{c.image_size}] images, got {tuple(x.shape)}")
         if x.shape[0] > self.max_batch:
             raise ValueError(f"batch {x.shape[0]} exceeds the engine's max_batch {self.max_batch}")
+        if x.device != self.device:
+            raise ValueError(f"images live on {x.device}, the engine on {self.device}")
 
     def forward(self, x, delta=None, output_normalize=False, save=False) -> torch.Tensor:
         self._check_images(x)
@@ -114,20 +118,32 @@ class VitEngine:
             L.check(self.lib.rvlm_vit_forward(self._h, x.data_ptr(), L.ptr(d), B, int(bool(output_normalize)),
                                               int(save), out.data_ptr(), L.stream_ptr()),
                     "rvlm_vit_forward")
-        if save:
-            self.generation += 1
+        # every forward (saving or not) overwrites state a pending backward would read: rvlm_vit_forward invalidates the
+        # saved pass on the C side, the generation counter lets _EncodeFn.backward say so in Python terms
+        self.generation += 1
         return out
 
-    def backward_params(self, d_emb, grads: dict, accumulate: bool = False):
+    @property
+    def n_stages(self) -> int:
+        """Stages of the parameter backward: head, one per transformer block (last block first), embeddings."""
+        return self.cfg.layers + 2
+
+    def backward_params(self, d_emb, grads: dict, accumulate: bool = False, stages=None):
         """Weight gradients of the last ``forward(..., save=2)`` into the fp32 tensors of ``grads``
-        (state_dict keys / shapes); rvlm_vit_backward_params."""
+        (state_dict keys / shapes); rvlm_vit_backward_params.  ``stages=(begin, end)`` runs that slice of the pass
+        only (rvlm_vit_backward_params_stages; slices of one backward must be run in order, begin 0 first)."""
         _require_cuda(d_emb, "d_emb")
         d = _f32c(d_emb)
         with torch.cuda.device(d.device):
             w, keep = self._weights_struct(grads, inplace=True)
-            L.check(self.lib.rvlm_vit_backward_params(self._h, d.data_ptr(), d.shape[0], C.byref(w),
-                                                      int(bool(accumulate)), L.stream_ptr()),
-                    "rvlm_vit_backward_params")
+            if stages is None:
+                L.check(self.lib.rvlm_vit_backward_params(self._h, d.data_ptr(), d.shape[0], C.byref(w),
+                                                          int(bool(accumulate)), L.stream_ptr()),
+                        "rvlm_vit_backward_params")
+            else:
+                L.check(self.lib.rvlm_vit_backward_params_stages(self._h, d.data_ptr(), d.shape[0], C.byref(w),
+                                                                 int(bool(accumulate)), int(stages[0]), int(stages[1]),
+                                                                 L.stream_ptr()), "rvlm_vit_backward_params_stages")
         del keep
 
     def backward_input(self, d_emb) -> torch.Tensor:
@@ -141,8 +157,55 @@ class VitEngine:
                     "rvlm_vit_backward_input")
         return g
 
+    def fwd_inputgrad(self, x, delta, loss_kind, reduction, ref, targets, output_normalize, logit_scale=100.0):
+        """One iteration's model work in one native call (rvlm_vit_fwd_inputgrad): returns
+        (emb, loss_per_sample, loss_scalar, grad_x)."""
+        self._check_images(x)
+        x = _f32c(x)
+        d = _f32c(delta) if delta is not None else None
+        ref = _f32c(ref)
+        tg = targets.detach().to(torch.int64).contiguous() if isinstance(targets, torch.Tensor) else None
+        B = x.shape[0]
+        ls = self._loss_spec(loss_kind, reduction, output_normalize, ref, tg, logit_scale, B=B)
+        emb = torch.empty(B, self.cfg.out_dim, device=x.device, dtype=torch.float32)
+        per = torch.empty(B, device=x.device, dtype=torch.float32)
+        scalar = torch.empty(1, device=x.device, dtype=torch.float32)
+        g = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            L.check(self.lib.rvlm_vit_fwd_inputgrad(self._h, x.data_ptr(), L.ptr(d), B, C.byref(ls), emb.data_ptr(),
+                                                    per.data_ptr(), scalar.data_ptr(), g.data_ptr(), L.stream_ptr()),
+                    "rvlm_vit_fwd_inputgrad")
+        self.generation += 1
+        return emb, per, scalar.reshape(()), g
+
     # ---- fused loops -----------------------------------------------------------------------------
-    def _loss_spec(self, loss_kind, reduction, output_normalize, ref, targets, logit_scale, y_target=None):
+    def _loss_spec(self, loss_kind, reduction, output_normalize, ref, targets, logit_scale, y_target=None, B=None):
+        """The C loops take raw device pointers: everything the reference would catch with an assert / a shape error /
+        F.cross_entropy's label check is caught HERE (l2: `out.shape == targets.shape`, …clip.py:512; head losses:
+        T is [out_dim, C] and labels lie in [0, C))."""
+        D = self.cfg.out_dim
+        for name, t in (("loss reference", ref), ("targets", targets), ("y_target", y_target)):
+            if t is None:
+                continue
+            _require_cuda(t, name)
+            if t.device != self.device:
+                raise ValueError(f"{name} lives on {t.device}, the engine on {self.device}")
+        if loss_kind == "l2":
+            assert B is None or tuple(ref.shape) == (B, D), f"{(B, D)} != {tuple(ref.shape)}"
+        else:
+            assert ref.dim() == 2 and ref.shape[0] == D, f"text embedding must be [{D}, C], got {tuple(ref.shape)}"
+            if not 0 < ref.shape[1] <= 1024:
+                raise ValueError(f"head losses support up to 1024 classes, got {ref.shape[1]}")
+            if targets is None:
+                raise ValueError(f"loss {loss_kind!r} needs integer targets")
+        for name, t in (("targets", targets), ("y_target", y_target)):
+            if t is None:
+                continue
+            assert B is None or t.shape[0] == B, f"{name}: {tuple(t.shape)} for a batch of {B}"
+            if loss_kind != "l2" and t.numel():
+                lo, hi = int(t.min()), int(t.max())
+                if lo < 0 or hi >= ref.shape[1]:
+                    raise IndexError(f"{name} out of range: [{lo}, {hi}] for {ref.shape[1]} classes")
         ls = L.LossSpecC()
         ls.loss_kind = {"l2": L.LOSS_L2, "ce": L.LOSS_CE, "dlr": L.LOSS_DLR, "dlr-targeted": L.LOSS_DLR_TARGETED}[loss_kind]
         ls.reduction = {"mean": L.RED_MEAN, "none": L.RED_NONE}[reduction]
@@ -162,7 +225,7 @@ class VitEngine:
         d0 = _f32c(delta0) if delta0 is not None else None
         ref = _f32c(ref)
         tg = targets.detach().to(torch.int64).contiguous() if isinstance(targets, torch.Tensor) else None
-        ls = self._loss_spec(loss_kind, reduction, output_normalize, ref, tg, logit_scale)
+        ls = self._loss_spec(loss_kind, reduction, output_normalize, ref, tg, logit_scale, B=x.shape[0])
         out = torch.empty_like(x)
         flags = torch.zeros(1, dtype=torch.int32, device=x.device)
         trace = torch.zeros(max(iterations, 1), dtype=torch.float32, device=x.device) if want_trace else None
@@ -186,8 +249,8 @@ class VitEngine:
         yt = y_target.detach().to(torch.int64).contiguous() if y_target is not None else None
         if (loss_kind == "dlr-targeted") != (yt is not None):
             raise ValueError("y_target goes with loss_kind='dlr-targeted'")
-        ls = self._loss_spec(loss_kind, "none", output_normalize, ref, tg, logit_scale, yt)
         B = x.shape[0]
+        ls = self._loss_spec(loss_kind, "none", output_normalize, ref, tg, logit_scale, yt, B=B)
         x_best_adv = torch.empty_like(x)
         x_best = torch.empty_like(x) if want_extra else None
         loss_best = torch.empty(B, dtype=torch.float32, device=x.device) if want_extra else None

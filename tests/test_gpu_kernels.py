@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 def test_library_is_the_in_tree_hip_build():
     l = lib()
-    assert l.rvlm_version() == 102
+    assert l.rvlm_version() == 103
     assert L.LIB_PATH.endswith("robustvlm_amd/librvlm.so")
 
 
