@@ -1,8 +1,9 @@
 """CPU oracle: one FARE / TeCoA optimizer step (TEST INFRASTRUCTURE, see oracle/__init__.py).
 
-Restates the part of ``train_one_epoch`` after the attack (train/adversarial_training_clip.py:338-366):
-clean / adversarial forward, ``compute_loss``, ``loss_total.backward()``, ``torch.optim.AdamW`` (:196-197)
-and the third-party open_clip ``cosine_lr`` (:211).  The reference module cannot be imported here
+Restates the part of ``train_one_epoch`` after the attack (train/adversarial_training_clip.py:338-387):
+clean / adversarial forward, ``compute_loss`` (``--loss_clean`` with T=None for the clean term, ``--trades``),
+``loss_total.backward()``, ``torch.optim.AdamW`` (:196-197), the third-party open_clip ``cosine_lr`` (:211) and the
+logging metrics cos-sim-clean / cos-sim / acc / racc (:368-387).  The reference module cannot be imported here
 (torchvision / open_clip / wandb missing), so this file is pinned by construction only: it is plain torch
 autograd + torch.optim.AdamW over oracle/vit_ref.py (itself pinned against HF transformers) - "parity
 unpinned" by reference outputs for this row.
@@ -26,12 +27,14 @@ def cosine_lr_ref(step, base_lr, warmup_length, steps):
 
 class TrainStepRef:
     def __init__(self, cfg, weights, lr=1e-5, wd=1e-4, warmup=1400, steps=20000, loss="l2",
-                 output_normalize=False, clean_weight=0.0, T=None):
+                 output_normalize=False, clean_weight=0.0, T=None, loss_clean="l2", trades=False):
         self.cfg = cfg
         self.w = {k: v.clone().requires_grad_(True) for k, v in weights.items()}
         self.opt = torch.optim.AdamW(list(self.w.values()), lr=lr, weight_decay=wd)
         self.lr, self.warmup, self.steps = lr, warmup, steps
         self.loss, self.on, self.cw, self.T = loss, output_normalize, clean_weight, T
+        self.loss_clean, self.trades = loss_clean, trades
+        self.last_metrics = {}
         self.step_total = 0
         self._set_lr(cosine_lr_ref(0, lr, warmup, steps))
 
@@ -44,15 +47,28 @@ class TrainStepRef:
         return torch.nn.functional.normalize(e, dim=-1) if self.on else e
 
     def step(self, x, x_adv, targets, e0):
+        emb_clean = self.forward(x)                                                    # :340
         loss_clean = 0.0
-        if self.cw > 0.:
-            loss_clean = compute_loss_ref(self.loss, self.forward(x), targets, e0, 100., None)
-        loss = compute_loss_ref(self.loss, self.forward(x_adv), targets, e0, 100., self.T)
-        total = self.cw * loss_clean + (1 - self.cw) * loss
+        if self.cw > 0.:                                                               # :341-347
+            loss_clean = compute_loss_ref(self.loss_clean, emb_clean, targets, e0, 100., None)
+        emb_adv = self.forward(x_adv)                                                  # :349
+        e_ref = emb_clean.detach().clone() if self.trades else e0                      # :352-358
+        loss = compute_loss_ref(self.loss, emb_adv, targets, e_ref, 100., self.T)
+        total = self.cw * loss_clean + (1 - self.cw) * loss                            # :360
         self.opt.zero_grad()
         total.backward()
         grads = {k: v.grad.detach().clone() for k, v in self.w.items()}
         self.opt.step()
         self.step_total += 1
         self._set_lr(cosine_lr_ref(self.step_total, self.lr, self.warmup, self.steps))
+        with torch.no_grad():                                                          # :368-387
+            F = torch.nn.functional
+            m = {"cos_sim_clean": float(F.cosine_similarity(emb_clean, e0, dim=1).mean()),
+                 "cos_sim": float(F.cosine_similarity(emb_adv, e0, dim=1).mean()),
+                 "loss_total": float(total), "loss_clean": float(loss_clean)}
+            if isinstance(targets, torch.Tensor) and self.T is not None:
+                acc = lambda lg: (lg.max(dim=1)[1].eq(targets).sum() / targets.shape[0]).item() * 100   # noqa: E731
+                m["racc"] = acc(emb_adv @ self.T)
+                m["acc"] = acc(F.normalize(emb_clean, dim=1) @ self.T)
+            self.last_metrics = m
         return float(loss.detach()), grads

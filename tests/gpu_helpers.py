@@ -37,8 +37,33 @@ def pad_rows(t, mult=128):
     return buf
 
 
-def gemm_bf16(A, Bw, epi=0, bias=None, residual=None, h_pre=None, act=0):
-    """A [M,K] bf16, Bw [N,K] bf16 (cuda).  Returns (out, out_pre)."""
+K_128, K_256, K_PERSISTENT, K_256Q, K_SPLITK, K_STRIP = 1, 2, 4, 8, 16, 32   # include/rvlm_kernels.h RVLM_GEMM_K_*
+
+
+def persistent_expected(M, N, K):
+    """Kernel families rvlm_k_gemm_set_variant(3) must launch for an [M,K] x [N,K]^T problem."""
+    if M >= 256 and N % 256 == 0 and K % 128 == 0:
+        return K_PERSISTENT | (K_STRIP if M % 256 else 0)
+    return None
+
+
+def record(name, **values):
+    """Append measured parity numbers to gpurun_out/parity_metrics.jsonl (evidence for DESIGN.md / profiles/)."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = os.path.join(root, "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "parity_metrics.jsonl"), "a") as f:
+            f.write(json.dumps(dict(test=name, **{k: float(v) for k, v in values.items()})) + "\n")
+    except OSError:
+        pass
+
+
+def gemm_bf16(A, Bw, epi=0, bias=None, residual=None, h_pre=None, act=0, expect=None):
+    """A [M,K] bf16, Bw [N,K] bf16 (cuda).  Returns (out, out_pre).  ``expect``: bit mask of kernel families
+    (K_*) that must have run - the dispatcher may not silently route a test to another kernel."""
     l = lib()
     M, K = A.shape
     N = Bw.shape[0]
@@ -51,6 +76,10 @@ def gemm_bf16(A, Bw, epi=0, bias=None, residual=None, h_pre=None, act=0):
                                   L.ptr(bias), out.data_ptr(), N, L.ptr(out_pre), L.ptr(h_pre),
                                   L.ptr(residual), act, st()), "gemm_bf16")
     torch.cuda.synchronize()
+    if expect is not None:
+        ran = l.rvlm_k_gemm_last_kernels()
+        assert ran == expect, \
+            f"GEMM [{M},{K}]x[{N},{K}]^T epi {epi}: kernel families {ran:#x} ran, expected {expect:#x}"
     return out, out_pre
 
 

@@ -401,3 +401,187 @@ def test_square_through_autoattack_vs_reference_golden():
     assert len(calls) == int(z["aa_n_model_calls"])
     assert np.array_equal(x_adv.cpu().numpy(), z["aa_x_adv"])
     assert np.array_equal(y_adv.cpu().numpy(), z["aa_y_adv"])
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# round 2: the headline model against the oracle, API-contract checks of the fused loops
+# --------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def l14():
+    """ViT-L/14 with seeded oracle weights (CPU copy for oracle/vit_ref.py, device copy for the engines)."""
+    torch.set_num_threads(32)
+    cfg = V.VIT_L_14
+    w = V.init_weights(cfg, seed=3)
+    wd = {k: v.to(dev()) for k, v in w.items()}
+    yield cfg, w, wd
+    torch.set_num_threads(8)
+
+
+@pytest.mark.parametrize("precision,norm", [("bf16", False), ("bf16", True), ("fp32", False)])
+def test_vit_l14_engine_vs_oracle(l14, precision, norm):
+    """The headline model itself (24 layers, W = 1024, S = 257 attention kernels, class-token tail, the persistent GEMM
+    on M = 1028 rows and the few-row / strip paths) against oracle/vit_ref.py on the CPU: embeddings and the input
+    gradient.  north_star: fp32 embeddings within 1e-4 relative; bf16 tolerance stated below."""
+    from tests.gpu_helpers import record
+    cfg, w, wd = l14
+    B = 4
+    ref = V.ClipVisionModelRef(cfg, w).eval()
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(B, 3, 224, 224, generator=g)
+    cot = torch.randn(B, cfg.out_dim, generator=g)
+    xr = x.clone().requires_grad_(True)
+    e_ref = ref(xr, norm)
+    (g_ref,) = torch.autograd.grad((e_ref * cot).sum(), xr)
+    eng = R.VitEngine(to_cfg(cfg), wd, precision=precision, max_batch=B)
+    emb = eng.forward(x.to(dev()), None, norm, save=True)
+    gx = eng.backward_input(cot.to(dev()))
+    torch.cuda.synchronize()
+    e_rel, g_rel = rel_max(emb.cpu(), e_ref.detach()), rel_max(gx.cpu(), g_ref)
+    e_cos, g_cos = cos_sim(emb.cpu(), e_ref.detach()), cos_sim(gx.cpu(), g_ref)
+    sign = float(np.mean(np.sign(gx.cpu().numpy()) == np.sign(g_ref.numpy())))
+    record(f"vit_l14_engine_vs_oracle[{precision},norm={norm}]", emb_rel=e_rel, grad_rel=g_rel, emb_cos=e_cos,
+           grad_cos=g_cos, grad_sign_agree=sign)
+    if precision == "fp32":
+        assert e_rel < 1e-4, e_rel
+        assert g_rel < 1e-3, g_rel
+        assert sign > 0.99, sign
+    else:
+        assert e_cos > 0.999, e_cos
+        assert g_cos > 0.98, g_cos
+        assert sign > 0.85, sign
+    eng.close()
+
+
+def test_forward_without_save_invalidates_the_saved_pass():
+    """`out = model(x_adv)` then `with no_grad: model(x)` then `loss.backward()` must not silently mix two
+    passes (a non-saving forward overwrites the shared LayerNorm statistics and slot 0 of every activation)."""
+    cfg = V.VIT_TINY2
+    w = V.init_weights(cfg, seed=9)
+    eng = make_engine(cfg, w, "bf16")
+    model = R.ClipVisionModel(eng).eval()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    xa = torch.rand(3, 3, cfg.image_size, cfg.image_size, generator=g, device=dev()).requires_grad_(True)
+    xb = torch.rand(3, 3, cfg.image_size, cfg.image_size, generator=g, device=dev())
+    out = model(xa, False)
+    with torch.no_grad():
+        model(xb, False)
+    with pytest.raises(RuntimeError, match="overwritten"):
+        out.sum().backward()
+    # and on the C ABI itself: backward after a non-saving forward is a state error, not garbage
+    eng.forward(xb, None, False, save=True)
+    eng.forward(xb, None, False, save=False)
+    with pytest.raises(L.RvlmError, match="no saved forward"):
+        eng.backward_input(torch.ones(3, cfg.out_dim, device=dev()))
+    # the regular order still works
+    out = model(xa, False)
+    out.sum().backward()
+    assert torch.isfinite(xa.grad).all()
+    eng.close()
+
+
+def test_fused_loops_reject_what_the_reference_rejects():
+    """the fused loops take raw pointers - shape / device / label errors must surface as Python errors
+    (l2 asserts out.shape == targets.shape, …clip.py:512; F.cross_entropy rejects labels >= C)."""
+    cfg = V.VIT_TINY2
+    w = V.init_weights(cfg, seed=9)
+    eng = make_engine(cfg, w, "fp32")
+    model = R.ClipVisionModel(eng).eval()
+    B, D, C = 4, cfg.out_dim, 7
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.rand(B, 3, cfg.image_size, cfg.image_size, generator=g, device=dev())
+    e0 = model(x, False)
+    T = torch.nn.functional.normalize(torch.randn(D, C, generator=g, device=dev()), dim=0)
+    y = torch.randint(0, C, (B,), generator=g, device=dev())
+    kw = dict(norm="linf", eps=4 / 255, iterations=2, stepsize=1 / 255, output_normalize=False, mode="max")
+    with pytest.raises(AssertionError):          # embedding_orig with fewer rows than the batch
+        R.pgd(model, R.ComputeLossWrapper(e0[:3], None, "mean", "l2", 100.), x, None, **kw)
+    with pytest.raises(L.RvlmError):             # reference embedding on the CPU
+        R.pgd(model, R.ComputeLossWrapper(e0.cpu(), None, "mean", "l2", 100.), x, None, **kw)
+    with pytest.raises(IndexError):              # label >= C
+        R.pgd(model, R.ComputeLossWrapper(e0, T, "mean", "ce", 100.), x, y + C, **kw)
+    with pytest.raises(AssertionError):          # text head with the wrong leading dimension
+        R.pgd(model, R.ComputeLossWrapper(e0, T[:-1], "mean", "ce", 100.), x, y, **kw)
+    with pytest.raises(AssertionError):          # label vector shorter than the batch
+        R.apgd_train(model, x, y[:3], "linf", 4 / 255, n_iter=2, loss_fn=R.ComputeLossWrapper(e0, T, "none", "ce", 100.))
+    out = R.pgd(model, R.ComputeLossWrapper(e0, T, "mean", "ce", 100.), x, y, **kw)       # the valid call still runs
+    assert out.shape == x.shape
+    eng.close()
+
+
+@pytest.mark.parametrize("loss_name", ["l2", "ce"])
+def test_fwd_inputgrad_single_call_equals_the_three_calls(loss_name):
+    """rvlm_vit_fwd_inputgrad = rvlm_vit_forward(save) + rvlm_loss_grad + rvlm_vit_backward_input,
+    bit for bit, and agrees with the oracle's forward / loss / autograd on the CPU."""
+    cfg = V.VIT_TINY2
+    w = V.init_weights(cfg, seed=9)
+    eng = make_engine(cfg, w, "fp32")
+    model = R.ClipVisionModel(eng).eval()
+    B, D, C = 4, cfg.out_dim, 9
+    g = torch.Generator().manual_seed(2)
+    x = torch.rand(B, 3, cfg.image_size, cfg.image_size, generator=g)
+    d = (torch.rand(x.shape, generator=g) * 2 - 1) * (4 / 255)
+    T = torch.nn.functional.normalize(torch.randn(D, C, generator=g), dim=0)
+    y = torch.randint(0, C, (B,), generator=g)
+    ref_model = V.ClipVisionModelRef(cfg, w).eval()
+    on = loss_name == "ce"
+    with torch.no_grad():
+        e0 = ref_model(x, on)
+    dr = d.clone().requires_grad_(True)
+    er = ref_model(x + dr, on)
+    lr = Lr.compute_loss_ref(loss_name, er, y, e0, 100., T)
+    (gr,) = torch.autograd.grad(lr, dr)
+    ref_t = (T if on else e0).to(dev())
+    emb, per, scalar, gx = eng.fwd_inputgrad(x.to(dev()), d.to(dev()), loss_name, "mean", ref_t, y.to(dev()), on)
+    assert rel_max(emb.cpu(), er.detach()) < 1e-4
+    assert abs(float(scalar) - float(lr)) <= 1e-4 * abs(float(lr)) + 1e-7
+    assert rel_max(gx.cpu(), gr) < 2e-3
+    # the three-call route through autograd
+    dd = d.to(dev()).requires_grad_(True)
+    e2 = model(x.to(dev()) + dd, on)
+    l2v = R.compute_loss(loss_name, e2, y.to(dev()), e0.to(dev()), 100., T.to(dev()))
+    (g2,) = torch.autograd.grad(l2v, dd)
+    assert torch.equal(e2.detach(), emb) and torch.equal(g2, gx)
+    assert float(l2v) == float(scalar)
+    eng.close()
+
+
+def test_ce_and_head_kernels_vs_torch():
+    """ce() (…clip.py:523-528) and ClassificationModel's head (clip_robustbench.py:66-68) run on librvlm kernels:
+    values and gradients against torch's own F.cross_entropy / matmul in fp64."""
+    g = torch.Generator(device="cuda").manual_seed(4)
+    B, D, C = 6, 48, 1000
+    logits = (torch.randn(B, C, generator=g, device=dev()) * 5).requires_grad_(True)
+    y = torch.randint(0, C, (B,), generator=g, device=dev())
+    for red in ("mean", "none", "sum"):
+        val = R.ce(logits, y, reduction=red)
+        (gl,) = torch.autograd.grad(val.sum(), logits)
+        ld = logits.detach().double().requires_grad_(True)
+        ref = torch.nn.functional.cross_entropy(ld, y, reduction=red)
+        (gref,) = torch.autograd.grad(ref.sum(), ld)
+        assert rel_max(val.detach(), ref.detach()) < 2e-6
+        assert rel_max(gl, gref) < 2e-5
+    with pytest.raises(IndexError):
+        R.ce(logits, y + C)
+    with pytest.raises(AssertionError):
+        R.ce(logits[:1], y[:1])
+    cfg = V.VIT_TINY2
+    w = V.init_weights(cfg, seed=9)
+    eng = make_engine(cfg, w, "fp32")
+    T = torch.nn.functional.normalize(torch.randn(cfg.out_dim, 11, generator=g, device=dev()), dim=0)
+    clf = R.ClassificationModel(eng, T).eval()
+    x = torch.rand(3, 3, cfg.image_size, cfg.image_size, generator=g, device=dev()).requires_grad_(True)
+    lg = clf(x)
+    emb = R.ClipVisionModel(eng)(x.detach(), True)
+    assert rel_max(lg.detach(), (emb.double() @ T.double()) * 100.) < 2e-6
+    (gx,) = torch.autograd.grad(R.ce(lg, torch.tensor([1, 5, 10], device=dev())), x)
+    refm = V.ClassificationModelRef(cfg, w, T.cpu())
+    xr = x.detach().cpu().requires_grad_(True)
+    (gr,) = torch.autograd.grad(torch.nn.functional.cross_entropy(refm(xr), torch.tensor([1, 5, 10])), xr)
+    assert rel_max(gx.cpu(), gr) < 2e-3
+    # evaluation batches larger than the engine's workspace are encoded in chunks
+    big = torch.rand(19, 3, cfg.image_size, cfg.image_size, generator=g, device=dev())
+    with torch.no_grad():
+        whole = clf(big)
+        parts = torch.cat([clf(big[:8]), clf(big[8:16]), clf(big[16:])])
+    assert torch.equal(whole, parts)
+    eng.close()

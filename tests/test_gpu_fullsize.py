@@ -1,0 +1,180 @@
+"""BASELINE.json configs 2, 3 and 5 at their FULL sizes on the GPU (ViT-L/14, bf16, B = 128 / 128 / 256), checked
+
+* through size-independent properties of the attack (eps-ball, image range, determinism, loss goes up, robust
+  accuracy can only go down, sharding invariance), and
+* against the CPU oracle (oracle/attacks_ref.py over oracle/vit_ref.py, fp32) on a 4-image slice of the SAME batch:
+  the attack is per-sample, so the slice's result inside the full batch must agree with the oracle's run of the slice
+  alone.  Two different encoders (bf16 MFMA vs fp32 CPU) flip the sign of near-zero gradient components (SURVEY
+  Appendix D.12), so the layered bar is: identical-pixel fraction, final per-sample loss within tolerance; the
+  fp32 mode of the engine, run on the same slice, has to agree with the oracle much more tightly.
+
+One ViT-L/14 engine pair (bf16 max_batch 256, fp32 max_batch 4) is shared by the module; the oracle runs with 32
+host threads and costs ~20 s per attack of 4 images.
+"""
+import numpy as np
+import pytest
+import torch
+
+import robustvlm_amd as R
+from oracle import vit_ref as V
+from oracle import attacks_ref as A
+from oracle import losses_ref as Lr
+from tests.gpu_helpers import dev, record
+
+pytestmark = pytest.mark.gpu
+
+EPS, STEP = 4 / 255, 1 / 255
+EPS_F = float(np.float32(EPS))
+NS = 4          # images of the oracle slice
+
+
+def to_cfg(c):
+    return R.VitConfig(c.image_size, c.patch, c.width, c.layers, c.heads, c.out_dim, c.act)
+
+
+@pytest.fixture(scope="module")
+def setup():
+    torch.set_num_threads(32)
+    cfg = V.VIT_L_14
+    w = V.init_weights(cfg, seed=3)
+    wd = {k: v.to(dev()) for k, v in w.items()}
+    eng = R.VitEngine(to_cfg(cfg), wd, precision="bf16", max_batch=256)
+    eng32 = R.VitEngine(to_cfg(cfg), wd, precision="fp32", max_batch=NS)
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(256, 3, 224, 224, generator=g)                       # BASELINE: torch.rand images, seed 0
+    d0 = (torch.rand(256, 3, 224, 224, generator=torch.Generator().manual_seed(1)) * 2 - 1) * EPS
+    y = torch.randint(0, 1000, (256,), generator=torch.Generator().manual_seed(2))
+    T = torch.nn.functional.normalize(torch.randn(cfg.out_dim, 1000, generator=torch.Generator().manual_seed(3)), dim=0)
+    ref = V.ClipVisionModelRef(cfg, w).eval()
+    yield dict(cfg=cfg, w=w, eng=eng, eng32=eng32, x=x, d0=d0, y=y, T=T, ref=ref)
+    eng.close(); eng32.close()
+    torch.set_num_threads(8)
+
+
+def ball_and_range(x_adv, x):
+    d = x_adv - x
+    # (x + delta) - x is evaluated in fp32: one ulp of the O(1) pixel values on top of float32(eps)
+    assert float(d.abs().max()) <= EPS_F + 1.2e-7, float(d.abs().max())
+    assert float(x_adv.min()) >= 0.0 and float(x_adv.max()) <= 1.0
+    return d
+
+
+def test_config2_fare_pgd_b128(setup):
+    """configs[1]: FARE PGD 10-step eps=4/255 on ViT-L/14 bf16, batch 128 - the shape bench.py times."""
+    s = setup
+    B = 128
+    x, d0 = s["x"][:B].to(dev()), s["d0"][:B].to(dev())
+    model = R.ClipVisionModel(s["eng"]).eval()
+    e0 = model(x, False)
+    wrap = R.ComputeLossWrapper(e0, None, "mean", "l2", 100.)
+    run = lambda: R.pgd(model, wrap, x, None, "linf", EPS, 10, STEP, False, perturbation=d0.clone(), mode="max")  # noqa: E731
+    xa = run()
+    assert torch.equal(xa, run()), "not deterministic"
+    d = ball_and_range(xa, x)
+    assert float((d.abs() >= EPS_F * 0.999).float().mean()) > 0.3          # the attack uses its budget
+    with torch.no_grad():
+        l_start = ((model(x + d0, False) - e0) ** 2).sum(1)
+        l_end = ((model(xa, False) - e0) ** 2).sum(1)
+    assert bool((l_end > l_start).all()) and float(l_end.mean()) > 2 * float(l_start.mean())
+    # sharding invariance (what the data-parallel path relies on): the first 16 images attacked alone
+    h = 16
+    xs = R.pgd(model, R.ComputeLossWrapper(e0[:h], None, "mean", "l2", 100.), x[:h], None, "linf", EPS, 10, STEP, False,
+               perturbation=d0[:h].clone(), mode="max")
+    same_shard = float((xs == xa[:h]).float().mean())
+    # oracle on the first NS images (fp32 CPU), and the engine's fp32 mode on the same slice
+    xc, dc = s["x"][:NS], s["d0"][:NS]
+    with torch.no_grad():
+        e0c = s["ref"](xc, False)
+    x_or = A.pgd_ref(s["ref"], Lr.ComputeLossWrapperRef(e0c, None, "mean", "l2", 100.), xc, None, "linf", EPS, 10, STEP,
+                     False, perturbation=dc.clone(), mode="max")
+    m32 = R.ClipVisionModel(s["eng32"]).eval()
+    e0_32 = m32(x[:NS], False)
+    x32 = R.pgd(m32, R.ComputeLossWrapper(e0_32, None, "mean", "l2", 100.), x[:NS], None, "linf", EPS, 10, STEP, False,
+                perturbation=d0[:NS].clone(), mode="max").cpu()
+    same_bf16 = float((xa[:NS].cpu() == x_or).float().mean())
+    same_fp32 = float((x32 == x_or).float().mean())
+    with torch.no_grad():
+        l_or = ((s["ref"](x_or, False) - e0c) ** 2).sum(1)
+        l_bf = ((s["ref"](xa[:NS].cpu(), False) - e0c) ** 2).sum(1)       # both judged by the oracle encoder
+    loss_ratio = float((l_bf / l_or).mean())
+    record("config2_fare_pgd_b128", same_pixels_bf16_vs_oracle=same_bf16, same_pixels_fp32_vs_oracle=same_fp32,
+           same_pixels_shard16_vs_b128=same_shard, loss_ratio_bf16_over_oracle=loss_ratio,
+           loss_end_over_start=float(l_end.mean()) / float(l_start.mean()))
+    assert same_shard > 0.9, same_shard
+    assert same_fp32 > 0.97, same_fp32
+    assert same_bf16 > 0.70, same_bf16
+    assert 0.9 < loss_ratio < 1.1, loss_ratio
+
+
+def test_config3_tecoa_apgd_b128(setup):
+    """configs[2]: TeCoA (supervised CE) apgd_train 10-step on ViT-L/14, batch 128."""
+    s = setup
+    B = 128
+    x, y, T = s["x"][:B].to(dev()), s["y"][:B].to(dev()), s["T"].to(dev())
+    model = R.ClipVisionModel(s["eng"]).eval()
+    wrap = R.ComputeLossWrapper(None, T, "none", "ce", 100.)
+    run = lambda: R.apgd_train(model, x, y, "linf", EPS, n_iter=10, loss_fn=wrap)      # noqa: E731
+    xa = run()
+    assert torch.equal(xa, run()), "not deterministic"
+    ball_and_range(xa, x)
+    with torch.no_grad():
+        l_clean = R.compute_loss("ce", model(x, True), y, None, 100., T, "none")
+        l_adv = R.compute_loss("ce", model(xa, True), y, None, 100., T, "none")
+    assert float(l_adv.mean()) > float(l_clean.mean())
+    xc, yc = s["x"][:NS], s["y"][:NS]
+    x_or = A.apgd_train_ref(s["ref"], xc, yc, "linf", EPS, n_iter=10, loss_fn=Lr.ComputeLossWrapperRef(None, s["T"], "none", "ce", 100.))
+    m32 = R.ClipVisionModel(s["eng32"]).eval()
+    x32 = R.apgd_train(m32, x[:NS], y[:NS], "linf", EPS, n_iter=10, loss_fn=wrap).cpu()
+    same_bf16 = float((xa[:NS].cpu() == x_or).float().mean())
+    same_fp32 = float((x32 == x_or).float().mean())
+    with torch.no_grad():
+        ce = lambda xx: Lr.compute_loss_ref("ce", s["ref"](xx, True), yc, None, 100., s["T"], "none")   # noqa: E731
+        loss_ratio = float((ce(xa[:NS].cpu()) / ce(x_or)).mean())
+    record("config3_tecoa_apgd_b128", same_pixels_bf16_vs_oracle=same_bf16, same_pixels_fp32_vs_oracle=same_fp32,
+           loss_ratio_bf16_over_oracle=loss_ratio, loss_adv_over_clean=float(l_adv.mean()) / float(l_clean.mean()))
+    assert same_fp32 > 0.97, same_fp32
+    assert same_bf16 > 0.70, same_bf16
+    assert 0.9 < loss_ratio < 1.1, loss_ratio
+
+
+def test_config5_apgd_ce_100_b256(setup):
+    """configs[4]: APGDAttack CE, 100 iterations, ViT-L/14 + zero-shot head with 1000 classes, batch 256; the oracle
+    slice runs 20 iterations (2 images; 100 CPU iterations would take minutes) through the same class."""
+    s = setup
+    B = 256
+    x, y, T = s["x"].to(dev()), s["y"].to(dev()), s["T"].to(dev())
+    clf = R.ClassificationModel(s["eng"], T).eval()
+    with torch.no_grad():
+        # labels = the model's own clean predictions (random-init weights know no ImageNet): every image starts
+        # "robust", so all 256 go through the 100 iterations, as in the timed configuration
+        y = clf(x).argmax(1)
+    att = R.APGDAttack(clf, n_iter=100, norm="Linf", n_restarts=1, eps=EPS, seed=0, loss="ce", device=dev())
+    xa = att.perturb(x, y)
+    ball_and_range(xa, x)
+    with torch.no_grad():
+        acc_clean = (clf(x).argmax(1) == y).float().mean().item()
+        acc_adv = (clf(xa).argmax(1) == y).float().mean().item()
+        l_clean = R.ce(clf(x), y, "none")
+        l_adv = R.ce(clf(xa), y, "none")
+    assert acc_clean == 1.0 and acc_adv <= acc_clean
+    # perturb() returns x for the points that stay robust and an adversarial point otherwise: the loss never drops
+    assert bool((l_adv >= l_clean - 1e-3).all())
+    att2 = R.APGDAttack(clf, n_iter=100, norm="Linf", n_restarts=1, eps=EPS, seed=0, loss="ce", device=dev())
+    assert torch.equal(att2.perturb(x[:32], y[:32]), R.APGDAttack(clf, n_iter=100, norm="Linf", n_restarts=1, eps=EPS, seed=0,
+                                                                  loss="ce", device=dev()).perturb(x[:32], y[:32]))
+    # oracle slice: 20 iterations, 2 images, start point fixed (no random start noise difference: same CPU generator)
+    n = 2
+    refclf = V.ClassificationModelRef(s["cfg"], s["w"], s["T"]).eval()
+    xc, yc = s["x"][:n], y[:n].cpu()
+    o = A.APGDAttackRef(refclf, n_iter=20, norm="Linf", n_restarts=1, eps=EPS, seed=0, loss="ce")
+    x_or = o.perturb(xc, yc, best_loss=True)
+    g = R.APGDAttack(clf, n_iter=20, norm="Linf", n_restarts=1, eps=EPS, seed=0, loss="ce", device=dev())
+    x_gpu = g.perturb(x[:n], y[:n], best_loss=True).cpu()
+    same = float((x_gpu == x_or).float().mean())
+    with torch.no_grad():
+        ce = lambda xx: torch.nn.functional.cross_entropy(refclf(xx), yc, reduction="none")   # noqa: E731
+        loss_ratio = float((ce(x_gpu) / ce(x_or)).mean())
+    record("config5_apgd_ce_100_b256", acc_clean=acc_clean, acc_adv=acc_adv, same_pixels_bf16_vs_oracle_20it=same,
+           loss_ratio_bf16_over_oracle_20it=loss_ratio, loss_adv_over_clean=float(l_adv.mean()) / float(l_clean.mean()))
+    assert same > 0.6, same
+    assert 0.85 < loss_ratio < 1.15, loss_ratio

@@ -4,7 +4,8 @@ import pytest
 import torch
 
 from robustvlm_amd import _lib as L
-from tests.gpu_helpers import (dev, st, lib, cos_sim, rel_max, gemm_bf16, act_ref, dact_ref, attn_ref)
+from tests.gpu_helpers import (dev, st, lib, cos_sim, rel_max, gemm_bf16, act_ref, dact_ref, attn_ref,
+                               persistent_expected, K_128, K_PERSISTENT, K_SPLITK, K_STRIP)
 
 pytestmark = pytest.mark.gpu
 
@@ -15,11 +16,19 @@ def test_library_is_the_in_tree_hip_build():
     assert L.LIB_PATH.endswith("robustvlm_amd/librvlm.so")
 
 
-@pytest.fixture(params=[0, 1], ids=["gemm128", "gemm256"])
+@pytest.fixture(params=[0, 3], ids=["gemm128", "persistent"])
 def gemm_variant(request):
+    """0: the 128x128 kernel only; 3: the persistent 256x256 kernel for every shape it can take (the production
+    fill / few-row rules are off), asserted through rvlm_k_gemm_last_kernels."""
     lib().rvlm_k_gemm_set_variant(request.param)
     yield request.param
     lib().rvlm_k_gemm_set_variant(-1)
+
+
+def family(variant, M, N, K):
+    if variant == 0:
+        return K_128
+    return persistent_expected(M, N, K)
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (257, 192, 128), (1028, 3072, 1024), (300, 640, 256),
@@ -30,9 +39,10 @@ def test_gemm_bf16_plain(M, N, K, gemm_variant):
     Bw = (torch.randn(N, K, generator=g, device=dev()) * K ** -0.5).bfloat16()
     bias = torch.randn(N, generator=g, device=dev())
     ref = A.double() @ Bw.double().t() + bias.double()
-    out, _ = gemm_bf16(A, Bw, epi=4, bias=bias)          # fp32 out: only accumulation-order error
+    fam = family(gemm_variant, M, N, K)
+    out, _ = gemm_bf16(A, Bw, epi=4, bias=bias, expect=fam)          # fp32 out: only accumulation-order error
     assert rel_max(out, ref) < 2e-5, "transpose / fragment-layout bug"
-    outb, _ = gemm_bf16(A, Bw, epi=0, bias=bias)
+    outb, _ = gemm_bf16(A, Bw, epi=0, bias=bias, expect=fam)
     assert rel_max(outb.float(), ref) < 1e-2
 
 
@@ -45,14 +55,15 @@ def test_gemm_bf16_epilogues(act, gemm_variant):
     bias = torch.randn(N, generator=g, device=dev())
     res = torch.randn(M, N, generator=g, device=dev())
     acc = A.double() @ Bw.double().t()
-    out, _ = gemm_bf16(A, Bw, epi=1, bias=bias, residual=res)
+    fam = family(gemm_variant, M, N, K)
+    out, _ = gemm_bf16(A, Bw, epi=1, bias=bias, residual=res, expect=fam)
     assert rel_max(out, acc + bias.double() + res.double()) < 2e-5
-    out, pre = gemm_bf16(A, Bw, epi=2, bias=bias, act=act)
+    out, pre = gemm_bf16(A, Bw, epi=2, bias=bias, act=act, expect=fam)
     h = acc + bias.double()
     assert rel_max(pre.float(), dact_ref(h, act)) < 1.5e-2          # out_pre = act'(h): all the backward needs of h
     assert rel_max(out.float(), act_ref(h, act)) < 1.5e-2
     hp = torch.randn(M, N, generator=g, device=dev()).bfloat16()     # stands for the stored act'(h)
-    out, _ = gemm_bf16(A, Bw, epi=3, h_pre=hp, act=act)
+    out, _ = gemm_bf16(A, Bw, epi=3, h_pre=hp, act=act, expect=fam)
     assert rel_max(out.float(), acc * hp.double()) < 1.5e-2
 
 
@@ -182,7 +193,7 @@ def test_layernorm_f32(M, W):
 def test_gemm_bf16_many_tiles_all_epilogues(K):
     """More 256x256 tiles than CUs (the persistent kernel walks >1 tile per workgroup) + a 128-row remainder,
     every epilogue, residual added IN PLACE (out aliases residual, as the weight-gradient accumulation does)."""
-    lib().rvlm_k_gemm_set_variant(1)
+    lib().rvlm_k_gemm_set_variant(3)
     try:
         M, N = 256 * 10 + 128, 256 * 30
         g = torch.Generator(device="cuda").manual_seed(K)
@@ -192,11 +203,12 @@ def test_gemm_bf16_many_tiles_all_epilogues(K):
         res = torch.randn(M, N, generator=g, device=dev())
         hp = torch.randn(M, N, generator=g, device=dev()).bfloat16()
         acc = (A.float() @ Bw.float().t()).double()
-        out, _ = gemm_bf16(A, Bw, epi=4, bias=bias)
+        fam = K_PERSISTENT | K_STRIP       # 300 tiles of 256x256 on <= 256 workgroups + the 128-row strip phase
+        out, _ = gemm_bf16(A, Bw, epi=4, bias=bias, expect=fam)
         assert rel_max(out, acc + bias.double()) < 3e-5
-        out, _ = gemm_bf16(A, Bw, epi=4)
+        out, _ = gemm_bf16(A, Bw, epi=4, expect=fam)
         assert rel_max(out, acc) < 3e-5
-        out, _ = gemm_bf16(A, Bw, epi=1, bias=bias, residual=res)
+        out, _ = gemm_bf16(A, Bw, epi=1, bias=bias, residual=res, expect=fam)
         assert rel_max(out, acc + bias.double() + res.double()) < 3e-5
         inplace = res.clone()
         Ap = torch.zeros((M + 255) // 256 * 256, K, dtype=torch.bfloat16, device=dev())
@@ -204,14 +216,15 @@ def test_gemm_bf16_many_tiles_all_epilogues(K):
         L.check(lib().rvlm_k_gemm_bf16_nt(Ap.data_ptr(), K, Bw.data_ptr(), K, M, N, K, Ap.shape[0], 1, bias.data_ptr(),
                                           inplace.data_ptr(), N, None, None, inplace.data_ptr(), 0, st()), "gemm")
         torch.cuda.synchronize()
+        assert lib().rvlm_k_gemm_last_kernels() == fam
         assert rel_max(inplace, acc + bias.double() + res.double()) < 3e-5
-        out, _ = gemm_bf16(A, Bw, epi=0, bias=bias)
+        out, _ = gemm_bf16(A, Bw, epi=0, bias=bias, expect=fam)
         assert rel_max(out.float(), acc + bias.double()) < 1e-2
         for act in (0, 1):
-            out, pre = gemm_bf16(A, Bw, epi=2, bias=bias, act=act)
+            out, pre = gemm_bf16(A, Bw, epi=2, bias=bias, act=act, expect=fam)
             assert rel_max(pre.float(), dact_ref(acc + bias.double(), act)) < 1.5e-2
             assert rel_max(out.float(), act_ref(acc + bias.double(), act)) < 1.5e-2
-            out, _ = gemm_bf16(A, Bw, epi=3, h_pre=hp, act=act)
+            out, _ = gemm_bf16(A, Bw, epi=3, h_pre=hp, act=act, expect=fam)
             assert rel_max(out.float(), acc * hp.double()) < 1.5e-2
     finally:
         lib().rvlm_k_gemm_set_variant(-1)
@@ -219,8 +232,9 @@ def test_gemm_bf16_many_tiles_all_epilogues(K):
 
 @pytest.mark.parametrize("K", [2048, 3072, 4096])
 def test_gemm_bf16_splitk_remainder(K):
-    """M = 256*q + r rows: the r remainder rows take the split-K path (K >= 2048) for every epilogue."""
-    lib().rvlm_k_gemm_set_variant(1)
+    """Few-row problems (M <= 512: the class-token rows of the last block) take split-K slabs on the 128x128 kernel +
+    the reduce/epilogue kernel under the production dispatch, for every epilogue."""
+    lib().rvlm_k_gemm_set_variant(2)
     try:
         M, N = 256 + 128, 512
         g = torch.Generator(device="cuda").manual_seed(K)
@@ -230,16 +244,17 @@ def test_gemm_bf16_splitk_remainder(K):
         res = torch.randn(M, N, generator=g, device=dev())
         hp = torch.randn(M, N, generator=g, device=dev()).bfloat16()
         acc = A.double() @ Bw.double().t()
-        out, _ = gemm_bf16(A, Bw, epi=4, bias=bias)
+        fam = K_SPLITK
+        out, _ = gemm_bf16(A, Bw, epi=4, bias=bias, expect=fam)
         assert rel_max(out, acc + bias.double()) < 2e-5
-        out, _ = gemm_bf16(A, Bw, epi=1, bias=bias, residual=res)
+        out, _ = gemm_bf16(A, Bw, epi=1, bias=bias, residual=res, expect=fam)
         assert rel_max(out, acc + bias.double() + res.double()) < 2e-5
-        out, _ = gemm_bf16(A, Bw, epi=0, bias=bias)
+        out, _ = gemm_bf16(A, Bw, epi=0, bias=bias, expect=fam)
         assert rel_max(out.float(), acc + bias.double()) < 1e-2
-        out, pre = gemm_bf16(A, Bw, epi=2, bias=bias, act=0)
+        out, pre = gemm_bf16(A, Bw, epi=2, bias=bias, act=0, expect=fam)
         assert rel_max(pre.float(), dact_ref(acc + bias.double(), 0)) < 1.5e-2
         assert rel_max(out.float(), act_ref(acc + bias.double(), 0)) < 1.5e-2
-        out, _ = gemm_bf16(A, Bw, epi=3, h_pre=hp, act=0)
+        out, _ = gemm_bf16(A, Bw, epi=3, h_pre=hp, act=0, expect=fam)
         assert rel_max(out.float(), acc * hp.double()) < 1.5e-2
     finally:
         lib().rvlm_k_gemm_set_variant(-1)
@@ -286,7 +301,7 @@ def test_wgrad_split_vs_fp32(M, N, K):
 def test_gemm_bf16_remainder_rows_in_launch(r, N, K):
     """M = 256 q + r: the r remainder rows are computed by the persistent kernel's strip phase (same launch); every
     epilogue, rows beyond M untouched."""
-    lib().rvlm_k_gemm_set_variant(1)
+    lib().rvlm_k_gemm_set_variant(3)
     try:
         M = 256 * 3 + r
         g = torch.Generator(device="cuda").manual_seed(r + N + K)
@@ -296,16 +311,17 @@ def test_gemm_bf16_remainder_rows_in_launch(r, N, K):
         res = torch.randn(M, N, generator=g, device=dev())
         hp = torch.randn(M, N, generator=g, device=dev()).bfloat16()
         acc = (A.float() @ Bw.float().t()).double()
-        out, _ = gemm_bf16(A, Bw, epi=4, bias=bias)
+        fam = K_PERSISTENT | K_STRIP
+        out, _ = gemm_bf16(A, Bw, epi=4, bias=bias, expect=fam)
         assert rel_max(out, acc + bias.double()) < 3e-5
-        out, _ = gemm_bf16(A, Bw, epi=1, bias=bias, residual=res)
+        out, _ = gemm_bf16(A, Bw, epi=1, bias=bias, residual=res, expect=fam)
         assert rel_max(out, acc + bias.double() + res.double()) < 3e-5
-        out, _ = gemm_bf16(A, Bw, epi=0)
+        out, _ = gemm_bf16(A, Bw, epi=0, expect=fam)
         assert rel_max(out.float(), acc) < 1e-2
-        out, pre = gemm_bf16(A, Bw, epi=2, bias=bias, act=0)
+        out, pre = gemm_bf16(A, Bw, epi=2, bias=bias, act=0, expect=fam)
         assert rel_max(pre.float(), dact_ref(acc + bias.double(), 0)) < 1.5e-2
         assert rel_max(out.float(), act_ref(acc + bias.double(), 0)) < 1.5e-2
-        out, _ = gemm_bf16(A, Bw, epi=3, h_pre=hp)
+        out, _ = gemm_bf16(A, Bw, epi=3, h_pre=hp, expect=fam)
         assert rel_max(out.float(), acc * hp.double()) < 1.5e-2
         # rows beyond M of a taller output buffer stay untouched
         tall = torch.full((M + 64, N), 7.0, device=dev())
@@ -314,16 +330,20 @@ def test_gemm_bf16_remainder_rows_in_launch(r, N, K):
         L.check(lib().rvlm_k_gemm_bf16_nt(Ap.data_ptr(), K, Bw.data_ptr(), K, M, N, K, Ap.shape[0], 4, None,
                                           tall.data_ptr(), N, None, None, None, 0, st()), "gemm")
         torch.cuda.synchronize()
+        assert lib().rvlm_k_gemm_last_kernels() == fam
         assert rel_max(tall[:M], acc) < 3e-5
         assert torch.all(tall[M:] == 7.0)
     finally:
         lib().rvlm_k_gemm_set_variant(-1)
 
 
-@pytest.mark.parametrize("M,N,K", [(256 * 3 + 100, 512, 256), (128, 256, 1024), (300, 192, 64)])
-def test_gemm_bf16_act_epilogue_without_derivative_output(M, N, K):
+@pytest.mark.parametrize("M,N,K,variant,fam", [(256 * 3 + 100, 512, 256, 3, K_PERSISTENT | K_STRIP),
+                                               (128, 256, 1024, 2, K_SPLITK), (300, 192, 64, 2, K_128)])
+def test_gemm_bf16_act_epilogue_without_derivative_output(M, N, K, variant, fam, request):
     """Forward-only callers pass out_pre = NULL to the activation epilogue: act(h) is written, act'(h) is not (every
     kernel family: persistent + strip phase, few-row split-K, 128x128 with edge tiles)."""
+    lib().rvlm_k_gemm_set_variant(variant)
+    request.addfinalizer(lambda: lib().rvlm_k_gemm_set_variant(-1))
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
     A = torch.randn(M, K, generator=g, device=dev()).bfloat16()
     Bw = (torch.randn(N, K, generator=g, device=dev()) * K ** -0.5).bfloat16()
@@ -335,4 +355,50 @@ def test_gemm_bf16_act_epilogue_without_derivative_output(M, N, K):
     L.check(lib().rvlm_k_gemm_bf16_nt(Ap.data_ptr(), K, Bw.data_ptr(), K, M, N, K, Ap.shape[0], 2, bias.data_ptr(),
                                       out.data_ptr(), N, None, None, None, 0, st()), "gemm")
     torch.cuda.synchronize()
+    assert lib().rvlm_k_gemm_last_kernels() == fam, hex(lib().rvlm_k_gemm_last_kernels())
     assert torch.equal(out, ref_out)
+
+
+# the eight GEMM launch types of one ViT-L/14 block at the headline batch (B = 128: M = 128 * 257 = 32 896 rows), as
+# (name, N, K, epilogue): forward QKV / out-proj / fc1 / fc2 and their dgrads (robustvlm_amd/csrc/engine.hip)
+HEADLINE_GEMMS = [("qkv_fwd", 3072, 1024, 0), ("out_fwd", 1024, 1024, 1), ("fc1_fwd", 4096, 1024, 2),
+                  ("fc2_fwd", 1024, 4096, 1), ("fc2_bwd", 4096, 1024, 3), ("fc1_bwd", 1024, 4096, 0),
+                  ("qkv_bwd", 1024, 3072, 0), ("out_bwd", 1024, 1024, 0)]
+
+
+@pytest.mark.parametrize("name,N,K,epi", HEADLINE_GEMMS, ids=[h[0] for h in HEADLINE_GEMMS])
+def test_gemm_bf16_headline_shapes_production_dispatch(name, N, K, epi):
+    """The exact shapes bench.py times (BASELINE config 2), under the PRODUCTION dispatch (no variant override): the
+    persistent 256x256 kernel + its in-launch strip phase must be what runs, and its result must match an fp32-
+    accumulated matmul of the same bf16 operands - the dominant kernel of the headline number is compared with
+    something other than itself."""
+    lib().rvlm_k_gemm_set_variant(-1)
+    M = 128 * 257
+    g = torch.Generator(device="cuda").manual_seed(N + K + epi)
+    A = torch.randn(M, K, generator=g, device=dev()).bfloat16()
+    Bw = (torch.randn(N, K, generator=g, device=dev()) * K ** -0.5).bfloat16()
+    bias = torch.randn(N, generator=g, device=dev()) if epi != 3 and "bwd" not in name else None
+    acc = (A.float() @ Bw.float().t()).double()
+    if bias is not None:
+        acc = acc + bias.double()
+    fam = K_PERSISTENT | K_STRIP
+    if epi == 0:
+        out, _ = gemm_bf16(A, Bw, epi=0, bias=bias, expect=fam)
+        assert rel_max(out.float(), acc) < 1e-2
+    elif epi == 1:
+        res = torch.randn(M, N, generator=g, device=dev())
+        out, _ = gemm_bf16(A, Bw, epi=1, bias=bias, residual=res, expect=fam)
+        assert rel_max(out, acc + res.double()) < 3e-5
+    elif epi == 2:
+        out, pre = gemm_bf16(A, Bw, epi=2, bias=bias, act=0, expect=fam)
+        assert rel_max(pre.float(), dact_ref(acc, 0)) < 1.5e-2
+        assert rel_max(out.float(), act_ref(acc, 0)) < 1.5e-2
+    else:
+        hp = torch.randn(M, N, generator=g, device=dev()).bfloat16()
+        out, _ = gemm_bf16(A, Bw, epi=3, h_pre=hp, expect=fam)
+        assert rel_max(out.float(), acc * hp.double()) < 1.5e-2
+    # the last rows (strip phase) separately: a bug there would be 0.4 % of the elements
+    tail = slice(M - 128, M)
+    if epi in (0, 2, 3):
+        ref_t = acc[tail] if epi == 0 else (act_ref(acc[tail], 0) if epi == 2 else acc[tail] * hp[tail].double())
+        assert rel_max(out[tail].float(), ref_t) < 1.5e-2

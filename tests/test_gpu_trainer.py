@@ -132,3 +132,160 @@ def test_train_step_bf16_runs_and_learns():
     losses = [float(tr.train_step(x, None, data_adv=xa)["loss"]) for _ in range(5)]   # fixed adversarial batch
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
     tr.engine.close(); tr.engine_orig.close()
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# round 2: loss_clean / trades / logging metrics / periodic eval / checkpoints on the device / data parallel
+# --------------------------------------------------------------------------------------------------------------------
+def _tiny_problem(B=4, C=7, seed=4):
+    cfg = V.VIT_TINY2
+    w = V.init_weights(cfg, seed=21)
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(B, 3, cfg.image_size, cfg.image_size, generator=g)
+    xa = (x + 0.03 * (torch.rand(x.shape, generator=g) * 2 - 1)).clamp(0, 1)
+    T = torch.nn.functional.normalize(torch.randn(cfg.out_dim, C, generator=g), dim=0)
+    y = torch.randint(0, C, (B,), generator=g)
+    return cfg, w, x, xa, T, y
+
+
+@pytest.mark.parametrize("trades", [False, True])
+def test_train_step_clean_weight_metrics_vs_oracle(trades):
+    """TeCoA with a clean term: loss = ce(adv), loss_clean = --loss_clean (l2 to e0, T=None, …clip.py:341-347),
+    loss_total, and the logging metrics cos-sim-clean / cos-sim / acc / racc (…clip.py:368-387) against the oracle's
+    restatement; parameters after two steps."""
+    cfg, w, x, xa, T, y = _tiny_problem()
+    kw = dict(lr=1e-3, wd=1e-2, warmup=2, steps=10, loss="ce", clean_weight=0.3, output_normalize=True)
+    tr = AdversarialTrainer(to_cfg(cfg), {k: v.to(dev()) for k, v in w.items()}, batch_size=4, precision="fp32",
+                            inner_loss="ce", attack="none", embedding_text_labels_norm=T.to(dev()), loss_clean="l2",
+                            trades=trades, **kw)
+    ref = TrainStepRef(cfg, w, T=T, loss_clean="l2", trades=trades, **kw)
+    with torch.no_grad():
+        e0 = torch.nn.functional.normalize(V.vit_forward(cfg, w, V.normalize_pixels(x)), dim=-1)
+    for it in range(2):
+        out = tr.train_step(x.to(dev()), y.to(dev()), data_adv=xa.to(dev()))
+        loss_ref, _ = ref.step(x, xa, y, e0)
+        m = ref.last_metrics
+        for key, want in (("loss", loss_ref), ("loss_clean", m["loss_clean"]), ("loss_total", m["loss_total"]),
+                          ("cos_sim_clean", m["cos_sim_clean"]), ("cos_sim", m["cos_sim"])):
+            got = float(out[key])
+            assert abs(got - want) <= 2e-3 * abs(want) + 2e-6, (it, key, got, want)
+        assert out["acc"] == m["acc"] and out["racc"] == m["racc"], (out["acc"], m["acc"], out["racc"], m["racc"])
+    sd = tr.state_dict()
+    W = cfg.width
+    for k, v in ref.w.items():
+        got, want = sd[k].cpu(), v.detach()
+        if k.endswith("attn.in_proj_bias"):
+            got = torch.cat([got[:W], got[2 * W:]]); want = torch.cat([want[:W], want[2 * W:]])
+        assert rel_max(got, want) < 1e-2, k
+    tr.close()
+
+
+def test_eval_step_vs_oracle():
+    """The periodic validation of …clip.py:389-424: 50-step supervised APGD with initial_stepsize 0.05 * eps when
+    clean_weight > 0, acc / racc / clean-vs-adversarial cosine similarity."""
+    from oracle import attacks_ref as A
+    from oracle import losses_ref as Lr
+    cfg, w, x, _, T, y = _tiny_problem(B=6)
+    eps = 4 / 255
+    tr = AdversarialTrainer(to_cfg(cfg), {k: v.to(dev()) for k, v in w.items()}, batch_size=6, precision="fp32",
+                            loss="ce", inner_loss="ce", attack="none", embedding_text_labels_norm=T.to(dev()),
+                            clean_weight=0.5, eps=eps)
+    logs = tr.eval_step(x.to(dev()), y.to(dev()))
+    assert set(logs) == {"eval/racc", "eval/acc", "eval/cos-sim"}
+    model = V.ClipVisionModelRef(cfg, w).eval()
+    adv = A.apgd_train_ref(model, x, y, "linf", eps, n_iter=50, initial_stepsize=0.05 * eps,
+                           loss_fn=Lr.ComputeLossWrapperRef(None, T, "none", "ce", 100.))
+    with torch.no_grad():
+        ea, ec = model(adv, True), model(x, True)
+        racc, acc = Lr.compute_acc_ref(ea @ T, y), Lr.compute_acc_ref(ec @ T, y)
+        cs = float(torch.nn.functional.cosine_similarity(ea, ec, dim=1).mean())
+    assert logs["eval/acc"] == acc
+    assert abs(logs["eval/racc"] - racc) <= 100 / 6 + 1e-6            # at most one borderline sample differs
+    assert abs(logs["eval/cos-sim"] - cs) < 0.02
+    assert tr.model.training                                          # back in train mode (…clip.py:424)
+    tr.close()
+
+
+def test_checkpoint_round_trip_on_the_device(tmp_path):
+    """SURVEY 8(f) rank 2 on the device: trainer -> CheckpointWriter files -> load_visual_state_dict -> a fresh engine
+    gives bit-identical embeddings (plain file and TeCoA container); the optimizer file is torch.optim.AdamW's own
+    layout (loads into a real AdamW over visual.parameters()-ordered tensors); resuming from the files reproduces
+    the uninterrupted run bit for bit."""
+    from robustvlm_amd.config import parameter_order
+    cfg, w, x, xa, T, y = _tiny_problem()
+    wd = {k: v.to(dev()) for k, v in w.items()}
+    kw = dict(batch_size=4, precision="bf16", lr=1e-3, wd=1e-2, warmup=2, steps=10, attack="none")
+    xd, xad = x.to(dev()), xa.to(dev())
+    tr = AdversarialTrainer(to_cfg(cfg), wd, **kw)
+    for _ in range(2):
+        tr.train_step(xd, None, data_adv=xad)
+    out_dir = str(tmp_path / "run_temp")
+    cw = R.CheckpointWriter(out_dir, steps=10)
+    final_dir = cw.final(tr.state_dict(), tr.optimizer_state_dict())
+    assert final_dir.endswith("run") and not final_dir.endswith("_temp")
+    model_file = f"{final_dir}/checkpoints/final.pt"
+    sd = R.load_visual_state_dict(model_file, to_cfg(cfg))
+    assert list(sd.keys()) == list(R.state_dict_shapes(to_cfg(cfg)).keys())     # visual.state_dict() key order
+    eng = R.VitEngine(to_cfg(cfg), sd, precision="bf16", max_batch=4)
+    e_file = eng.forward(xd, None, True)
+    e_live = tr.engine.forward(xd, None, True)
+    assert torch.equal(e_file, e_live)
+    torch.save({"vision_encoder_state_dict": sd}, str(tmp_path / "tecoa.pt"))    # CLIP_eval/eval_utils.py:45-48
+    sd2 = R.load_visual_state_dict(str(tmp_path / "tecoa.pt"), to_cfg(cfg))
+    eng.load_state_dict(sd2)
+    assert torch.equal(eng.forward(xd, None, True), e_live)
+    eng.close()
+    # the optimizer file is what torch.optim.AdamW would have written
+    opt_sd = torch.load(f"{final_dir}/checkpoints/final_opt.pt")
+    params = [torch.nn.Parameter(sd[k].clone()) for k in parameter_order(to_cfg(cfg))]
+    opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=1e-2)
+    opt.load_state_dict(opt_sd)
+    k5 = parameter_order(to_cfg(cfg))[5]
+    o, c = tr.params.offsets[k5]
+    assert torch.equal(opt.state[params[5]]["exp_avg"].reshape(-1), tr.exp_avg[o:o + c].cpu())
+    assert float(opt.state[params[5]]["step"]) == 2.0
+    # resume (…clip.py:98-102,207-208): model + optimizer files, start_step from the file name convention
+    torch.save(tr.state_dict(), str(tmp_path / "step_2.pt"))
+    torch.save(tr.optimizer_state_dict(), str(tmp_path / "step_2_opt.pt"))
+    mpath, opath = R.resume_paths(str(tmp_path / "step_2_opt.pt"), 2)
+    tr2 = AdversarialTrainer(to_cfg(cfg), wd, **kw)
+    tr2.load_state_dict(R.load_visual_state_dict(mpath, to_cfg(cfg)))
+    tr2.load_optimizer_state_dict(torch.load(opath), start_step=2)
+    a = tr.train_step(xd, None, data_adv=xad)
+    b = tr2.train_step(xd, None, data_adv=xad)
+    assert float(a["loss"]) == float(b["loss"]) and a["lr"] == b["lr"]
+    # model_orig of the resumed trainer was built from the ORIGINAL weights, like the reference's (:95-97)
+    assert torch.equal(tr.params.flat, tr2.params.flat)
+    tr.close(); tr2.close()
+
+
+def test_data_parallel_step_two_ranks_one_gpu(tmp_path):
+    """Two ranks (one process each, gloo rendezvous on 127.0.0.1) share the one GPU of the test box: the sharded FARE
+    PGD equals the unsharded one, and AdversarialTrainer's data-parallel step (bucketed gradient all-reduce between
+    the backward stages, uneven shards 3 + 2) equals the single-process step on the concatenated batch."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "dp")
+    os.makedirs(out)
+    env = dict(os.environ, PYTHONPATH=root, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(root, "tests", "dp_worker.py"), out]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    res = [torch.load(os.path.join(out, f"rank{i}.pt")) for i in range(2)]
+    single = torch.load(os.path.join(out, "single.pt"))
+    # attack: per-sample, no collective - the ranks' shards put together are the unsharded result
+    assert torch.equal(torch.cat([res[0]["x_adv"], res[1]["x_adv"]]), single["x_adv"])
+    # training step: same parameters on both ranks, equal to the single-process step (fp32: summation order only)
+    W = V.VIT_TINY2.width
+    for k, want in single["params"].items():
+        assert torch.equal(res[0]["params"][k], res[1]["params"][k]), k
+        got, p0 = res[0]["params"][k], single["params0"][k]
+        if k.endswith("attn.in_proj_bias"):     # key bias: true gradient 0, Adam turns rounding noise into +-lr steps
+            got, want, p0 = (torch.cat([t[:W], t[2 * W:]]) for t in (got, want, p0))
+        moved = float((want - p0).abs().max())
+        assert moved > 1e-4, k                  # two Adam steps at lr 1e-3 did move the parameter
+        assert float((got - want).abs().max()) < 1e-2 * moved, (k, float((got - want).abs().max()), moved)
+    assert abs(res[0]["loss_global"] - single["loss"]) <= 1e-5 * abs(single["loss"])
