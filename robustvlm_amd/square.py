@@ -14,9 +14,9 @@ import math
 import time
 
 import torch
+import torch.nn.functional as F
 
 from . import _lib as L
-from .clip_model import ce
 from .engine import _require_cuda, _f32c
 
 
@@ -53,7 +53,7 @@ class SquareAttack():
         """:param y: correct labels if untargeted else target labels  (square.py:68-86)"""
         with torch.no_grad():
             logits = self.predict(x).float().clone()
-        xent = ce(logits, y, reduction='none')
+        xent = F.cross_entropy(logits, y, reduction='none')   # bit-identical with the reference's bookkeeping
         z_y = logits.gather(1, y.view(-1, 1)).squeeze(1)
         z_other = logits.scatter(1, y.view(-1, 1), -float('inf')).max(dim=-1)[0]
         if self.targeted:

@@ -442,13 +442,13 @@ def test_vit_l14_engine_vs_oracle(l14, precision, norm):
     record(f"vit_l14_engine_vs_oracle[{precision},norm={norm}]", emb_rel=e_rel, grad_rel=g_rel, emb_cos=e_cos,
            grad_cos=g_cos, grad_sign_agree=sign)
     if precision == "fp32":
-        assert e_rel < 1e-4, e_rel
-        assert g_rel < 1e-3, g_rel
-        assert sign > 0.99, sign
+        assert e_rel < 2e-5, e_rel          # north_star bar: 1e-4 relative (measured 1.0e-6)
+        assert g_rel < 1e-4, g_rel          # measured 2.0e-6
+        assert sign > 0.9999, sign
     else:
-        assert e_cos > 0.999, e_cos
-        assert g_cos > 0.98, g_cos
-        assert sign > 0.85, sign
+        assert e_cos > 0.9999, e_cos        # measured 0.999998
+        assert g_cos > 0.999, g_cos         # measured 0.99997
+        assert sign > 0.99, sign            # measured 0.9974: the sign is all an L-inf attack uses of the gradient
     eng.close()
 
 
@@ -570,8 +570,8 @@ def test_ce_and_head_kernels_vs_torch():
     T = torch.nn.functional.normalize(torch.randn(cfg.out_dim, 11, generator=g, device=dev()), dim=0)
     clf = R.ClassificationModel(eng, T).eval()
     x = torch.rand(3, 3, cfg.image_size, cfg.image_size, generator=g, device=dev()).requires_grad_(True)
-    lg = clf(x)
     emb = R.ClipVisionModel(eng)(x.detach(), True)
+    lg = clf(x)
     assert rel_max(lg.detach(), (emb.double() @ T.double()) * 100.) < 2e-6
     (gx,) = torch.autograd.grad(R.ce(lg, torch.tensor([1, 5, 10], device=dev())), x)
     refm = V.ClassificationModelRef(cfg, w, T.cpu())

@@ -100,10 +100,12 @@ def test_config2_fare_pgd_b128(setup):
     record("config2_fare_pgd_b128", same_pixels_bf16_vs_oracle=same_bf16, same_pixels_fp32_vs_oracle=same_fp32,
            same_pixels_shard16_vs_b128=same_shard, loss_ratio_bf16_over_oracle=loss_ratio,
            loss_end_over_start=float(l_end.mean()) / float(l_start.mean()))
-    assert same_shard > 0.9, same_shard
-    assert same_fp32 > 0.97, same_fp32
+    # measured (profiles/r02_parity_metrics.jsonl): shard 0.986, fp32 0.9969, bf16 0.743 (ten iterations compound the
+    # sign flips of near-zero gradient components), loss ratio 0.998
+    assert same_shard > 0.97, same_shard
+    assert same_fp32 > 0.99, same_fp32
     assert same_bf16 > 0.70, same_bf16
-    assert 0.9 < loss_ratio < 1.1, loss_ratio
+    assert 0.97 < loss_ratio < 1.03, loss_ratio
 
 
 def test_config3_tecoa_apgd_b128(setup):
@@ -132,9 +134,10 @@ def test_config3_tecoa_apgd_b128(setup):
         loss_ratio = float((ce(xa[:NS].cpu()) / ce(x_or)).mean())
     record("config3_tecoa_apgd_b128", same_pixels_bf16_vs_oracle=same_bf16, same_pixels_fp32_vs_oracle=same_fp32,
            loss_ratio_bf16_over_oracle=loss_ratio, loss_adv_over_clean=float(l_adv.mean()) / float(l_clean.mean()))
-    assert same_fp32 > 0.97, same_fp32
-    assert same_bf16 > 0.70, same_bf16
-    assert 0.9 < loss_ratio < 1.1, loss_ratio
+    # measured: fp32 0.9999, bf16 0.9795, loss ratio 0.9999
+    assert same_fp32 > 0.999, same_fp32
+    assert same_bf16 > 0.95, same_bf16
+    assert 0.98 < loss_ratio < 1.02, loss_ratio
 
 
 def test_config5_apgd_ce_100_b256(setup):
@@ -162,19 +165,18 @@ def test_config5_apgd_ce_100_b256(setup):
     att2 = R.APGDAttack(clf, n_iter=100, norm="Linf", n_restarts=1, eps=EPS, seed=0, loss="ce", device=dev())
     assert torch.equal(att2.perturb(x[:32], y[:32]), R.APGDAttack(clf, n_iter=100, norm="Linf", n_restarts=1, eps=EPS, seed=0,
                                                                   loss="ce", device=dev()).perturb(x[:32], y[:32]))
-    # oracle slice: 20 iterations, 2 images, start point fixed (no random start noise difference: same CPU generator)
+    # oracle slice: attack_single_run, 20 iterations, 2 images, the SAME start point on both sides
     n = 2
     refclf = V.ClassificationModelRef(s["cfg"], s["w"], s["T"]).eval()
     xc, yc = s["x"][:n], y[:n].cpu()
+    start = (xc + EPS * (2 * torch.rand(xc.shape, generator=torch.Generator().manual_seed(9)) - 1)).clamp(0, 1)
     o = A.APGDAttackRef(refclf, n_iter=20, norm="Linf", n_restarts=1, eps=EPS, seed=0, loss="ce")
-    x_or = o.perturb(xc, yc, best_loss=True)
+    xb_or, _, lb_or, _ = o.attack_single_run(xc, yc, x_init=start)
     g = R.APGDAttack(clf, n_iter=20, norm="Linf", n_restarts=1, eps=EPS, seed=0, loss="ce", device=dev())
-    x_gpu = g.perturb(x[:n], y[:n], best_loss=True).cpu()
-    same = float((x_gpu == x_or).float().mean())
-    with torch.no_grad():
-        ce = lambda xx: torch.nn.functional.cross_entropy(refclf(xx), yc, reduction="none")   # noqa: E731
-        loss_ratio = float((ce(x_gpu) / ce(x_or)).mean())
+    xb, _, lb, _ = g.attack_single_run(x[:n], y[:n], x_init=start.to(dev()))
+    same = float((xb.cpu() == xb_or).float().mean())
+    loss_ratio = float((lb.cpu() / lb_or).mean())
     record("config5_apgd_ce_100_b256", acc_clean=acc_clean, acc_adv=acc_adv, same_pixels_bf16_vs_oracle_20it=same,
-           loss_ratio_bf16_over_oracle_20it=loss_ratio, loss_adv_over_clean=float(l_adv.mean()) / float(l_clean.mean()))
+           loss_best_ratio_bf16_over_oracle_20it=loss_ratio, loss_adv_over_clean=float(l_adv.mean()) / float(l_clean.mean()))
     assert same > 0.6, same
     assert 0.85 < loss_ratio < 1.15, loss_ratio
