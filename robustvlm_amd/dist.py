@@ -51,3 +51,21 @@ def allreduce_mean_(tensors, world: int | None = None):
         n = t.numel()
         t.copy_(flat[off:off + n].view_as(t))
         off += n
+
+
+def allreduce_sum_span(flat: torch.Tensor, lo: int, hi: int, group=None, device_collectives: bool = True):
+    """Sum all-reduce of the contiguous slice flat[lo:hi] (one gradient bucket of the trainer's flat fp32 buffer).
+    With device collectives (backend nccl = RCCL over xGMI) the call is asynchronous and returns a work handle whose
+    wait() makes the CURRENT STREAM wait - the bucket's reduction overlaps whatever the caller launches next.  A
+    backend without device collectives (gloo in the CPU / one-GPU tests) reduces through a host copy, synchronously."""
+    view = flat[lo:hi]
+    if device_collectives or not view.is_cuda:
+        work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        if not view.is_cuda:
+            work.wait()
+            return None
+        return work
+    host = view.cpu()
+    dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+    view.copy_(host)
+    return None

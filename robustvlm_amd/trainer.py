@@ -29,6 +29,7 @@ import torch.distributed as dist
 from . import _lib as L
 from .clip_model import ClipVisionModel, ComputeLossWrapper, compute_loss
 from .config import state_dict_shapes, backward_stage_keys, parameter_order
+from .dist import allreduce_sum_span
 from .engine import VitEngine
 from .pgd_train import pgd
 from .apgd_train import apgd_train
@@ -153,13 +154,7 @@ class AdversarialTrainer:
 
     def _allreduce_span(self, lo: int, hi: int):
         """Sum all-reduce of grads.flat[lo:hi] over the ranks; returns a waitable (or None when already done)."""
-        view = self.grads.flat[lo:hi]
-        if self._device_collectives:
-            return dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-        host = view.cpu()
-        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.pg)
-        view.copy_(host)
-        return None
+        return allreduce_sum_span(self.grads.flat, lo, hi, self.pg, self._device_collectives)
 
     def _loss_backward(self, x, targets, e_ref, loss_str, T, weight, accumulate, reduce_grads):
         """forward (activations kept for wgrad) + loss + weight gradients scaled by ``weight``; with ``reduce_grads``

@@ -98,6 +98,21 @@ assert max_over_ranks(1.0 + rank) == float(world)
 g = [torch.full((3,), float(rank)), torch.full((2, 2), 2.0 * rank)]
 allreduce_mean_(g)
 assert torch.allclose(g[0], torch.full((3,), (world - 1) / 2)) and torch.allclose(g[1], torch.full((2, 2), float(world - 1)))
+# the trainer's gradient path on CPU tensors: flat buffer in backward-stage order, bucket plan, per-bucket reduce
+from robustvlm_amd import VitConfig
+from robustvlm_amd.dist import allreduce_sum_span
+from robustvlm_amd.trainer import FlatParams, bucket_plan
+cfg = VitConfig(32, 8, 64, 3, 1, 16)
+gr = FlatParams(cfg, None, "cpu")
+for i, (k, v) in enumerate(sorted(gr.views.items())):
+    v.fill_(float(i + 1) * (rank + 1))
+plan = bucket_plan(cfg.layers + 2, 3)
+assert plan[0][0] == 0 and plan[-1][1] == cfg.layers + 2 and all(a[1] == b[0] for a, b in zip(plan, plan[1:]))
+for a, b in plan:
+    lo, hi = gr.stage_span(a, b)
+    assert allreduce_sum_span(gr.flat, lo, hi, None, False) is None
+for i, (k, v) in enumerate(sorted(gr.views.items())):
+    assert torch.all(v == float(i + 1) * sum(r + 1 for r in range(world))), k
 dist.barrier(); dist.destroy_process_group()
 print("ok", rank)
 """
@@ -116,6 +131,49 @@ def test_two_rank_gloo(tmp_path):
     for p in procs:
         out, _ = p.communicate(timeout=120)
         assert p.returncode == 0, out.decode()
+
+
+def test_flat_params_layout_and_parameter_order():
+    """The flat gradient buffer is laid out in backward-stage order (a bucket = a contiguous slice), every key has a
+    view, and parameter_order() (the index space of torch.optim.AdamW's state) covers the same keys with the
+    module's own Parameters first (class_embedding, positional_embedding, proj), ln_post last."""
+    import torch
+    from robustvlm_amd import VitConfig, state_dict_shapes
+    from robustvlm_amd.config import parameter_order, backward_stage_keys
+    from robustvlm_amd.trainer import FlatParams, bucket_plan
+    cfg = VitConfig(32, 8, 64, 4, 1, 16)
+    shapes = state_dict_shapes(cfg)
+    order = parameter_order(cfg)
+    assert sorted(order) == sorted(shapes) and len(set(order)) == len(order)
+    assert order[:4] == ["class_embedding", "positional_embedding", "proj", "conv1.weight"]
+    assert order[-2:] == ["ln_post.weight", "ln_post.bias"]
+    assert order[6].startswith("transformer.resblocks.0.") and order[-3].startswith("transformer.resblocks.3.")
+    stages = backward_stage_keys(cfg)
+    assert len(stages) == cfg.layers + 2 and stages[0][0] == "proj" and "conv1.weight" in stages[-1]
+    assert all(k.startswith("transformer.resblocks.3.") for k in stages[1])
+    fp = FlatParams(cfg, {k: torch.full(s, 2.0) for k, s in shapes.items()}, "cpu")
+    assert fp.stage_offsets[0] == 0 and fp.stage_offsets[-1] == fp.numel
+    for i, keys in enumerate(stages):
+        lo, hi = fp.stage_span(i, i + 1)
+        for k in keys:
+            o, c = fp.offsets[k]
+            assert lo <= o and o + c <= hi and o % 4 == 0
+    assert list(fp.state_dict().keys()) == list(shapes.keys())        # visual.state_dict() key order on the way out
+    assert float(fp.flat.sum()) == 2.0 * sum(torch.Size(s).numel() for s in shapes.values())
+    for n in (1, 3, 4, 6, 9):
+        plan = bucket_plan(6, n)
+        assert plan[0][0] == 0 and plan[-1][1] == 6 and len(plan) == min(n, 6)
+        assert all(a[1] == b[0] and a[0] < a[1] for a, b in zip(plan, plan[1:] + [(6, 7)]))
+
+
+def test_bench_host_helpers():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    model, physical, threads = b.host_cpu_info()
+    assert isinstance(model, str) and 1 <= physical <= threads
+    assert b.bind_rank_to_numa(0, 1) is None
 
 
 def test_checkpoint_layout_and_formats(tmp_path):
