@@ -868,6 +868,271 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
     stamp(4);
 }
 
+constexpr int FB2_TILE = 2048;   // one wave's dS tile [32 keys][32 q] bf16
+
+template <int NK>
+__global__ void __launch_bounds__(NK * 64)
+attn_bwd_fused2_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __restrict__ o, long ldo,
+                      const bf16_t* __restrict__ d_o, long lddo, const float* __restrict__ lse2,
+                      bf16_t* __restrict__ dqkv, long lddq, int H, int S, int W, float scale, float scale_log2,
+                      unsigned long long* __restrict__ trace, int desync) {
+    // optional phase timeline (RVLM_ATTN_TRACE=1: 5 s_memtime stamps per workgroup into the dsum scratch buffer)
+    auto stamp = [&](int k) {
+        if (trace && threadIdx.x == 0) trace[(long)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memtime();
+    };
+    // Phase offset: every CU would otherwise stage its head at the same moment (6 TB/s-bound, 22 % of the kernel spent
+    // waiting for HBM) and compute at the same moment (HBM idle).  The first workgroup of each CU starts up to 7 x desync
+    // kilo-cycles late; the stagger then persists, one CU's staging hides under the others' compute.
+    if (desync > 0 && blockIdx.x < 256) {
+        for (int i = 0; i < (int)((blockIdx.x >> 3) & 7) * desync; ++i) __builtin_amdgcn_s_sleep(16);   // 16 x 64 cycles
+    }
+    stamp(0);
+    constexpr int NT = NK + 1, Sp = NT * 32, SE = NK * 32;   // query tiles, padded rows, index of the odd key
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Qt = smem;
+    char* Dt = smem + Sp * 128;
+    char* area = smem + Sp * 256;                              // K | V tiles, later NK partial slots
+    char* Kt = area;
+    char* Vt = area + Sp * 128;
+    float* Ls = (float*)(area + Sp * 256);
+    float* Ds = Ls + Sp;
+    float* Pe = Ds + Sp;                                       // p[q][odd key]
+    float* De = Pe + Sp;                                       // dS[q][odd key]
+    float* Ke = De + Sp;                                       // k[odd key][0..63] as fp32
+    float* KVe = Ke + 64;                                      // [NK + 1][2][64] per-wave (+ odd query) dK / dV of the odd key
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const bf16_t* base = qkv + (long)b * S * ld + h * 64;
+    const bf16_t* dob = d_o + (long)b * S * lddo + h * 64;
+    const bf16_t* ob = o + (long)b * S * ldo + h * 64;
+
+    // ---- phase 0: stage Q, dO, K, V; lse -------------------------------------------------------------------
+    stage_tile(Qt, base, ld, S, Sp, w, NK, lane);
+    stage_tile(Dt, dob, lddo, S, Sp, w, NK, lane);
+    stage_tile(Kt, base + W, ld, S, Sp, w, NK, lane);
+    stage_tile(Vt, base + 2 * W, ld, S, Sp, w, NK, lane);
+    for (int i = tid; i < Sp; i += NK * 64) Ls[i] = (i < S) ? lse2[((long)b * H + h) * Sp + i] : INFINITY;
+    if (tid < 64) Ke[tid] = (float)base[(long)SE * ld + W + tid];
+    bf16x8 ofr[4];   // O rows of this wave's query tile (for D = rowsum(dO * O)): requested under the staging
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) ofr[kk] = frag_global(ob, ldo, w * 32 + (lane & 31), kk, lane);
+    __syncthreads();
+    stamp(1);
+
+    const FragOffs fo = make_offs(lane);
+    // ---- phase 1: this wave's key tile in registers; D for its query tile(s); the odd key -------------------
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) { kf[kk] = frag_rm(Kt, w * 32, fo.rm[kk]); vf[kk] = frag_rm(Vt, w * 32, fo.rm[kk]); }
+    // dQ ownership: wave w computes the 16 (d) x 16 (q) block (db, qb) of every query tile's dQ^T over ALL keys, so no
+    // partial sums cross waves.  Its A operands K^T[16 d][32 keys] of the NK key tiles stay in registers
+    // (v_mfma_f32_16x16x32_bf16: lane <-> d = 16 db + (lane & 15), k = 8 (lane >> 4) + 0..7 <-> key).
+    const int db = w >> 1, qb = w & 1, G = lane >> 4, i16 = lane & 15;
+    bf16x8 kq[NK];
+#pragma unroll
+    for (int j = 0; j < NK; ++j)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int row = j * 32 + 8 * G + 4 * r + (i16 >> 2);
+            const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                (__attribute__((address_space(3))) bf16x4*)((lds_char*)Kt + swz_off(row, 2 * db + ((i16 & 3) >> 1)) + (i16 & 1) * 8));
+            kq[j][4 * r + 0] = v[0]; kq[j][4 * r + 1] = v[1]; kq[j][4 * r + 2] = v[2]; kq[j][4 * r + 3] = v[3];
+        }
+    {
+        f32x16 dke[2] = {zero16(), zero16()}, dve[2] = {zero16(), zero16()};
+        {
+            const int qe = w;   // query tiles 0..NK-1: one per wave (the odd query, tile NK, takes the vector path below)
+            const int q = qe * 32 + l31;
+            bf16x8 qf[4], dof[4];
+            float dsum = 0.0f;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                qf[kk] = frag_rm(Qt, qe * 32, fo.rm[kk]);
+                dof[kk] = frag_rm(Dt, qe * 32, fo.rm[kk]);
+                const bf16x8 of = ofr[kk];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dsum = fmaf((float)dof[kk][e], (float)of[e], dsum);
+            }
+            dsum += __shfl_xor(dsum, 32, 64);
+            // S^T / dP^T against the last (padded) key tile: lane <-> query, register 0 of the hi = 0 lanes <-> odd key
+            f32x16 sT = zero16(), dpT = zero16();
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                sT = MFMA(frag_rm(Kt, SE, fo.rm[kk]), qf[kk], sT);
+                dpT = MFMA(frag_rm(Vt, SE, fo.rm[kk]), dof[kk], dpT);
+            }
+            const float pe = EXP2(fmaf(sT[0], scale_log2, -Ls[q]));
+            if (hi == 0) { Ds[q] = dsum; Pe[q] = pe; De[q] = pe * (dpT[0] - dsum); }
+            // dV, dK of the odd key: B operand with the single column n = 0 (lanes 0 and 32), k <-> the 32 queries
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 pb, db;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int qq = qe * 32 + ks * 16 + 4 * hi + (t & 3) + 8 * (t >> 2);
+                    pb[t] = (bf16_t)(l31 == 0 ? Pe[qq] : 0.0f);
+                    db[t] = (bf16_t)(l31 == 0 ? De[qq] : 0.0f);
+                }
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    dve[dt] = MFMA(frag_tr(Dt, qe * 32 + ks * 16, fo, dt), pb, dve[dt]);
+                    dke[dt] = MFMA(frag_tr(Qt, qe * 32 + ks * 16, fo, dt), db, dke[dt]);
+                }
+            }
+        }
+        if (l31 == 0) {   // column 0: rows d = dt*32 + (r&3) + 8*(r>>2) + 4*hi
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    KVe[(w * 2 + 0) * 64 + d] = dke[dt][r];
+                    KVe[(w * 2 + 1) * 64 + d] = dve[dt][r];
+                }
+        }
+    }
+    if (w == NK - 1) {
+        // the odd QUERY (row SE) against the odd key, as 64-wide vectors (lane <-> d): D, p, dS, and its dK / dV terms
+        const float dov = (float)dob[(long)SE * lddo + lane], ov = (float)ob[(long)SE * ldo + lane];
+        const float qv = (float)base[(long)SE * ld + lane], kv = Ke[lane], vv = (float)base[(long)SE * ld + 2 * W + lane];
+        const float dsum = wave_sum(dov * ov), sc = wave_sum(qv * kv), dpe = wave_sum(dov * vv);
+        const float pe = EXP2(fmaf(sc, scale_log2, -Ls[SE]));
+        const float de = pe * (dpe - dsum);
+        if (lane < 32) { Ds[SE + lane] = (lane == 0) ? dsum : 0.0f; Pe[SE + lane] = (lane == 0) ? pe : 0.0f; De[SE + lane] = (lane == 0) ? de : 0.0f; }
+        KVe[(NK * 2 + 0) * 64 + lane] = de * qv;
+        KVe[(NK * 2 + 1) * 64 + lane] = pe * dov;
+    }
+    __syncthreads();   // K / V tiles are dead: the area becomes the partial slots; Ds / Pe / De are complete
+    stamp(2);
+
+    // ---- phase 2: lockstep walk over the query tiles -------------------------------------------------------------
+    // Per tile: S, dP (8 MFMA) -> P, dS in registers -> dS tile to LDS -> ONE barrier -> dV, dK from the registers
+    // (8 MFMA) and this wave's dQ^T block from the NK waves' dS tiles (NK v_mfma_f32_16x16x32_bf16) -> dQ stored.
+    // The dS tiles are double-buffered by tile parity: a wave that writes tile qt + 1 has passed barrier qt, which
+    // every wave reaches only after its reads of tile qt - 1 - one barrier per tile is enough.
+    lds_char* dsb = (lds_char*)area;                          // [2][NK] tiles of FB2_TILE bytes: [32 keys][32 q] bf16
+    // write: this lane's key row (64-B rows), 8-B chunk (4 consecutive q) index XOR ((key >> 2) & 7)
+    const int st_w = w * FB2_TILE + l31 * 64;
+    const int st_sw = (l31 >> 2) & 7;
+    // read (B operand of the 16x16x32 MFMA, lane <-> q = 16 qb + (lane & 15), k <-> key = 8 G + 0..7): transposing read of
+    // the 4 (keys) x 16 (q) block; lane i of a 16-lane group addresses key row 8 G + 4 r + (i >> 2), 8-B chunk 4 qb + (i & 3)
+    int rd[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int row = 8 * G + 4 * r + (i16 >> 2);
+        rd[r] = row * 64 + (((4 * qb + (i16 & 3)) ^ ((row >> 2) & 7)) << 3);
+    }
+    const float4 ke4 = *(const float4*)(Ke + 16 * db + 4 * G);        // k[odd key][d], d = 16 db + 4 G + 0..3
+    bf16_t* dq_out = dqkv + (long)b * S * lddq + h * 64 + 16 * db + 4 * G;
+    f32x16 dk[2] = {zero16(), zero16()}, dv[2] = {zero16(), zero16()};
+    for (int qt = 0; qt < NT; ++qt) {
+        f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            s = MFMA(frag_rm(Qt, qt * 32, fo.rm[kk]), kf[kk], s);      // S[q][key]: lane <-> key, regs <-> q
+            dp = MFMA(frag_rm(Dt, qt * 32, fo.rm[kk]), vf[kk], dp);    // dP[q][key]
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 lq = *(const float4*)(Ls + qt * 32 + 8 * g + 4 * hi);
+            const float4 dq = *(const float4*)(Ds + qt * 32 + 8 * g + 4 * hi);
+            const float lqa[4] = {lq.x, lq.y, lq.z, lq.w};
+            const float dqa[4] = {dq.x, dq.y, dq.z, dq.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float pv = EXP2(fmaf(s[g * 4 + e], scale_log2, -lqa[e]));
+                s[g * 4 + e] = pv;                                  // P   (in place)
+                dp[g * 4 + e] = pv * (dp[g * 4 + e] - dqa[e]);      // dS  (in place)
+            }
+        }
+        lds_char* buf = dsb + (qt & 1) * (NK * FB2_TILE);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bf16x4 v4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v4[e] = (bf16_t)dp[g * 4 + e];
+            *(__attribute__((address_space(3))) bf16x4*)(buf + st_w + (((2 * g + hi) ^ st_sw) << 3)) = v4;
+        }
+        // operands of dV / dK: independent of the other waves, fetched before the barrier
+        bf16x8 dot[2][2], qtr[2][2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                dot[ks][dt] = frag_tr(Dt, qt * 32 + ks * 16, fo, dt);
+                qtr[ks][dt] = frag_tr(Qt, qt * 32 + ks * 16, fo, dt);
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the dS tile is in LDS
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        bf16x8 dsq[NK];
+#pragma unroll
+        for (int j = 0; j < NK; ++j)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (__attribute__((address_space(3))) bf16x4*)(buf + j * FB2_TILE + rd[r]));
+                dsq[j][4 * r + 0] = v[0]; dsq[j][4 * r + 1] = v[1]; dsq[j][4 * r + 2] = v[2]; dsq[j][4 * r + 3] = v[3];
+            }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 pb = pack_b(s, ks), dbv = pack_b(dp, ks);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                dv[dt] = MFMA(dot[ks][dt], pb, dv[dt]);
+                dk[dt] = MFMA(qtr[ks][dt], dbv, dk[dt]);
+            }
+        }
+        f32x4 dq0 = {0.0f, 0.0f, 0.0f, 0.0f}, dq1 = {0.0f, 0.0f, 0.0f, 0.0f};   // dQ^T block: lane <-> q, regs <-> d
+#pragma unroll
+        for (int j = 0; j < NK; j += 2) {
+            dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kq[j], dsq[j], dq0, 0, 0, 0);
+            dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kq[j + 1], dsq[j + 1], dq1, 0, 0, 0);
+        }
+        {
+            const int q = qt * 32 + 16 * qb + i16;
+            const float de = De[q];                                 // dS[q][odd key]: its rank-1 term dS * k joins here
+            if (q < S) {
+                bf16x4 ov;
+                ov[0] = (bf16_t)(fmaf(de, ke4.x, dq0[0] + dq1[0]) * scale); ov[1] = (bf16_t)(fmaf(de, ke4.y, dq0[1] + dq1[1]) * scale);
+                ov[2] = (bf16_t)(fmaf(de, ke4.z, dq0[2] + dq1[2]) * scale); ov[3] = (bf16_t)(fmaf(de, ke4.w, dq0[3] + dq1[3]) * scale);
+                *(bf16x4*)(dq_out + (long)q * lddq) = ov;
+            }
+        }
+    }
+
+    stamp(3);
+    // ---- phase 3: dK, dV of this wave's keys; the odd key ------------------------------------------------------
+    {
+        const int key = w * 32 + l31;
+        bf16_t* krow = dqkv + ((long)b * S + key) * lddq + W + h * 64;
+        bf16_t* vrow = krow + W;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 ok, ov;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    ok[e] = (bf16_t)(dk[dt][g * 4 + e] * scale);
+                    ov[e] = (bf16_t)dv[dt][g * 4 + e];
+                }
+                *(bf16x4*)(krow + dt * 32 + 8 * g + 4 * hi) = ok;
+                *(bf16x4*)(vrow + dt * 32 + 8 * g + 4 * hi) = ov;
+            }
+    }
+    if (w == 0) {
+        float ak = 0.0f, av = 0.0f;
+#pragma unroll
+        for (int ww = 0; ww <= NK; ++ww) { ak += KVe[(ww * 2 + 0) * 64 + lane]; av += KVe[(ww * 2 + 1) * 64 + lane]; }
+        bf16_t* krow = dqkv + ((long)b * S + SE) * lddq + W + h * 64;
+        krow[lane] = (bf16_t)(ak * scale);
+        krow[W + lane] = (bf16_t)av;
+    }
+    stamp(4);
+}
+
 // ---------------------------------------------------------------------------------------------
 static bool g_use_tr = true;
 void attn_set_use_tr(int on) { g_use_tr = on != 0; }
@@ -937,8 +1202,14 @@ int attn_bwd_bf16(const bf16_t* qkv, long ldqkv, const bf16_t* o, long ldo, cons
         static int trace = -1, desync = -1;
         if (trace < 0) { const char* e = getenv("RVLM_ATTN_TRACE"); trace = e ? atoi(e) : 0; }
         if (desync < 0) { const char* e = getenv("RVLM_ATTN_DESYNC"); desync = e ? atoi(e) : 5; }
-        hipLaunchKernelGGL((attn_bwd_fused_kernel<NK>), dim3(B * H), dim3(NK * 64), lds_f, s, qkv, ldqkv, o, ldo, d_o, lddo,
-                           lse, dqkv, lddqkv, H, S, W, scale, sl2, trace ? (unsigned long long*)dsum_scratch : nullptr, desync);
+        if (fused == 2) {
+            if ((rc = set_lds(attn_bwd_fused2_kernel<NK>, lds_f))) return rc;
+            hipLaunchKernelGGL((attn_bwd_fused2_kernel<NK>), dim3(B * H), dim3(NK * 64), lds_f, s, qkv, ldqkv, o, ldo, d_o, lddo,
+                               lse, dqkv, lddqkv, H, S, W, scale, sl2, trace ? (unsigned long long*)dsum_scratch : nullptr, desync);
+        } else {
+            hipLaunchKernelGGL((attn_bwd_fused_kernel<NK>), dim3(B * H), dim3(NK * 64), lds_f, s, qkv, ldqkv, o, ldo, d_o, lddo,
+                               lse, dqkv, lddqkv, H, S, W, scale, sl2, trace ? (unsigned long long*)dsum_scratch : nullptr, desync);
+        }
         RVLM_CHECK_LAUNCH();
         return RVLM_OK;
     }

@@ -157,6 +157,8 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w >> 2, wn = w & 3;
     const int l31 = lane & 31, hi = lane >> 5;
+    // experiment (MI355X_MICROARCH.md, two waves per SIMD, item 4): static priority for the second-dispatched half
+    if (p.wave_prio > 0 && w >= 4) __builtin_amdgcn_s_setprio(1);
     const int lda = (int)p.lda, ldb = (int)p.ldb, ldo = (int)p.ldo;   // byte offsets fit 31 bits (host check)
 
     // buffer descriptors (wave-uniform, built from kernel arguments only): every global access below is
@@ -177,9 +179,9 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
     auto tile_origin = [&](int tile, int& m0, int& n0) {
         const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = tile & 7, loc = tile >> 3;
         const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
-        const int group_size = 8 * tiles_n;
-        const int first_m = (t / group_size) * 8;
-        const int gm = min(tiles_m - first_m, 8);
+        const int group_size = p.group_m * tiles_n;
+        const int first_m = (t / group_size) * p.group_m;
+        const int gm = min(tiles_m - first_m, p.group_m);
         m0 = __builtin_amdgcn_readfirstlane((first_m + (t % group_size) % gm) * P_M);
         n0 = __builtin_amdgcn_readfirstlane(((t % group_size) / gm) * P_N);
     };
@@ -629,6 +631,10 @@ int gemm_bf16_nt_256p(const GemmBf16& p, int* rows_done, hipStream_t s) {
     static int stagger_ph = -1;     // phase mask: 3 = 4 phases
     if (stagger_ph < 0) { const char* e = getenv("RVLM_GEMM_STAGGER_PH"); stagger_ph = e ? atoi(e) : 3; }
     if (((stagger_mask >> q.epi) & 1) && stagger > 0) q.stagger = (stagger & 255) | (stagger_ph << 8);
+    static int group_m = -1, wave_prio = -1;
+    if (group_m < 0) { const char* e = getenv("RVLM_GEMM_GROUP_M"); group_m = e ? std::max(1, atoi(e)) : 8; }
+    if (wave_prio < 0) { const char* e = getenv("RVLM_GEMM_PRIO"); wave_prio = e ? atoi(e) : 0; }
+    q.group_m = group_m; q.wave_prio = wave_prio;
     const bool tail = tail_on && g_persist_ablate == 0 && p.batch_m_rows == 0 && p.M > q.M;
     const int m_total = tail ? p.M : q.M;
     int rc;
