@@ -598,21 +598,30 @@ attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __res
 // backward, FUSED (dQ, dK, dV in one kernel) for sequence lengths S = 32*NK + 1 (CLIP ViTs at 224 px: 257 = 8*32 + 1)
 //
 // The two-kernel backward above evaluates P and dS twice (once per kernel: exp2 + ~8 VALU per score, the bound of both
-// kernels) and runs 9 waves on 4 SIMDs (one SIMD carries 3).  Here NK = 8 waves (2 per SIMD, 256 VGPRs each) own one
+// kernels) and runs 9 waves on 4 SIMDs (one SIMD carries 3).  Here NK = 8 waves (2 per SIMD, <= 256 VGPRs each) own one
 // 32-key tile each - K, V fragments and the dK, dV accumulators stay in registers - and walk the 9 query tiles in
-// lockstep:  S, dP (8 MFMA) -> P, dS once -> dV, dK (8 MFMA) -> dS transposed through 2 KiB of LDS (ds_write_b64 +
-// ds_read_b64_tr_b16) -> dQ^T partial (4 MFMA) -> fp32 partial into the wave's 8 KiB slot -> barrier -> the 512 threads
-// sum the 8 slots in a fixed order (deterministic) and write dQ.  = 5 tile GEMMs per (query tile, key tile), P/dS once.
+// lockstep, ONE barrier per tile:
+//     S, dP (8 MFMA 32x32x16) -> P, dS once, in registers -> the wave's dS tile [32 keys][32 q] to LDS -> barrier ->
+//     dV, dK from the registers (8 MFMA) ; dQ: wave w OWNS the 16 (d) x 16 (q) block (w >> 1, w & 1) of the tile's dQ^T
+//     and contracts it over ALL 256 keys - K^T fragments of the NK key tiles held in registers against the NK waves'
+//     dS tiles read back through ds_read_b64_tr_b16 (NK v_mfma_f32_16x16x32_bf16) -> 8-byte stores of finished dQ.
+// = 5 tile GEMMs per (query tile, key tile), P / dS evaluated once, and NO partial sums cross waves: round 1 summed eight
+// fp32 32x64 partials per tile through 64 KiB of LDS with two barriers (3.8 k cycles per tile, now 2.7 k).  The dS tiles
+// are double-buffered by tile parity, which is what makes one barrier per tile enough.  The result is a deterministic
+// function of the inputs (fixed MFMA accumulation order).  dK / dV leave through a wave-private LDS transpose as 16-byte
+// full-line stores (the row-per-lane 8-byte store tail was 10 % of the kernel, now 4 %).
 //
-// The odd key (index S-1, the "+1") is handled up front (phase E) in the transposed orientation, where it is ONE
+// The odd key (index S-1, the "+1") is handled up front (phase 1) in the transposed orientation, where it is ONE
 // accumulator register instead of a 32-wide tile: S^T, dP^T by MFMA against the padded last key tile, p and dS for that
 // key on one register per lane, dK/dV of that key by MFMA against a one-column B operand; its rank-1 contribution to dQ
-// (dS[q] * k) is added by the reducer.  The odd QUERY rides in the ninth query tile (31 padded rows, lse = +inf -> P = 0).
+// (dS[q] * k) joins the owner's block before the store.  The odd QUERY rides in the ninth query tile (31 padded rows,
+// lse = +inf -> P = 0); its rows as 64-wide vectors are requested under the staging.
 //
-// LDS (S = 257): Q 36 KiB | dO 36 KiB | area 72 KiB (first the K and V tiles, then the partial slots; the dS staging
-// lives in the wave's own slot) | lse, D, p_odd, dS_odd [288] | k_odd [64] | per-wave dK/dV of the odd key.
+// LDS (S = 257): Q 36 KiB | dO 36 KiB | area 72 KiB (first the K and V tiles, then 2 x NK dS tiles of 2 KiB and NK
+// store-staging tiles of 4 KiB) | lse, D, p_odd, dS_odd [288] | k_odd [64] | per-wave dK/dV of the odd key.
+// Measured (MI355X, B = 128, 16 heads; profiles/r02_attn_bwd_*.log): 262 -> 206 us per launch.
 // =============================================================================================
-constexpr int FB_SLOT = 8192;
+constexpr int FB2_TILE = 2048;   // one wave's dS tile [32 keys][32 q] bf16
 
 template <int NK>
 __global__ void __launch_bounds__(NK * 64)
@@ -661,262 +670,13 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
     bf16x8 ofr[4];   // O rows of this wave's query tile (for D = rowsum(dO * O)): requested under the staging
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) ofr[kk] = frag_global(ob, ldo, w * 32 + (lane & 31), kk, lane);
-    __syncthreads();
-    stamp(1);
-
-    const FragOffs fo = make_offs(lane);
-    // ---- phase 1: this wave's key tile in registers; D for its query tile(s); the odd key -------------------
-    bf16x8 kf[4], vf[4], kT[2][2];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) { kf[kk] = frag_rm(Kt, w * 32, fo.rm[kk]); vf[kk] = frag_rm(Vt, w * 32, fo.rm[kk]); }
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) kT[dt][ks] = frag_tr(Kt, w * 32 + ks * 16, fo, dt);
-    {
-        f32x16 dke[2] = {zero16(), zero16()}, dve[2] = {zero16(), zero16()};
-        {
-            const int qe = w;   // query tiles 0..NK-1: one per wave (the odd query, tile NK, takes the vector path below)
-            const int q = qe * 32 + l31;
-            bf16x8 qf[4], dof[4];
-            float dsum = 0.0f;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                qf[kk] = frag_rm(Qt, qe * 32, fo.rm[kk]);
-                dof[kk] = frag_rm(Dt, qe * 32, fo.rm[kk]);
-                const bf16x8 of = ofr[kk];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) dsum = fmaf((float)dof[kk][e], (float)of[e], dsum);
-            }
-            dsum += __shfl_xor(dsum, 32, 64);
-            // S^T / dP^T against the last (padded) key tile: lane <-> query, register 0 of the hi = 0 lanes <-> odd key
-            f32x16 sT = zero16(), dpT = zero16();
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                sT = MFMA(frag_rm(Kt, SE, fo.rm[kk]), qf[kk], sT);
-                dpT = MFMA(frag_rm(Vt, SE, fo.rm[kk]), dof[kk], dpT);
-            }
-            const float pe = EXP2(fmaf(sT[0], scale_log2, -Ls[q]));
-            if (hi == 0) { Ds[q] = dsum; Pe[q] = pe; De[q] = pe * (dpT[0] - dsum); }
-            // dV, dK of the odd key: B operand with the single column n = 0 (lanes 0 and 32), k <-> the 32 queries
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 pb, db;
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const int qq = qe * 32 + ks * 16 + 4 * hi + (t & 3) + 8 * (t >> 2);
-                    pb[t] = (bf16_t)(l31 == 0 ? Pe[qq] : 0.0f);
-                    db[t] = (bf16_t)(l31 == 0 ? De[qq] : 0.0f);
-                }
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    dve[dt] = MFMA(frag_tr(Dt, qe * 32 + ks * 16, fo, dt), pb, dve[dt]);
-                    dke[dt] = MFMA(frag_tr(Qt, qe * 32 + ks * 16, fo, dt), db, dke[dt]);
-                }
-            }
-        }
-        if (l31 == 0) {   // column 0: rows d = dt*32 + (r&3) + 8*(r>>2) + 4*hi
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    KVe[(w * 2 + 0) * 64 + d] = dke[dt][r];
-                    KVe[(w * 2 + 1) * 64 + d] = dve[dt][r];
-                }
-        }
-    }
+    // the odd query's rows as 64-wide vectors (last wave only), requested under the staging as well: fetched in phase 1
+    // they put an HBM round trip on the path to the phase's barrier
+    float odd_do = 0.0f, odd_o = 0.0f, odd_q = 0.0f, odd_v = 0.0f;
     if (w == NK - 1) {
-        // the odd QUERY (row SE) against the odd key, as 64-wide vectors (lane <-> d): D, p, dS, and its dK / dV terms
-        const float dov = (float)dob[(long)SE * lddo + lane], ov = (float)ob[(long)SE * ldo + lane];
-        const float qv = (float)base[(long)SE * ld + lane], kv = Ke[lane], vv = (float)base[(long)SE * ld + 2 * W + lane];
-        const float dsum = wave_sum(dov * ov), sc = wave_sum(qv * kv), dpe = wave_sum(dov * vv);
-        const float pe = EXP2(fmaf(sc, scale_log2, -Ls[SE]));
-        const float de = pe * (dpe - dsum);
-        if (lane < 32) { Ds[SE + lane] = (lane == 0) ? dsum : 0.0f; Pe[SE + lane] = (lane == 0) ? pe : 0.0f; De[SE + lane] = (lane == 0) ? de : 0.0f; }
-        KVe[(NK * 2 + 0) * 64 + lane] = de * qv;
-        KVe[(NK * 2 + 1) * 64 + lane] = pe * dov;
+        odd_do = (float)dob[(long)SE * lddo + lane]; odd_o = (float)ob[(long)SE * ldo + lane];
+        odd_q = (float)base[(long)SE * ld + lane]; odd_v = (float)base[(long)SE * ld + 2 * W + lane];
     }
-    __syncthreads();   // K / V tiles are dead: the area becomes the partial slots; Ds / Pe / De are complete
-    stamp(2);
-
-    // ---- phase 2: lockstep walk over the query tiles -------------------------------------------------------------
-    char* slot = area + w * FB_SLOT;
-    lds_char* slot3 = (lds_char*)slot;
-    // dS staging [32 keys][32 q] bf16 (64-B rows), 8-B chunk index XOR ((key >> 2) & 7)
-    const int st_w = l31 * 64;
-    const int st_sw = (l31 >> 2) & 7;
-    const int i16 = lane & 15, qhalf = (lane >> 4) & 1;
-    int st_r[2][2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int row = ks * 16 + r * 8 + 4 * hi + (i16 >> 2);
-            st_r[ks][r] = row * 64 + (((qhalf * 4 + (i16 & 3)) ^ ((row >> 2) & 7)) << 3);
-        }
-    f32x16 dk[2] = {zero16(), zero16()}, dv[2] = {zero16(), zero16()};
-    for (int qt = 0; qt < NT; ++qt) {
-        f32x16 s = zero16(), dp = zero16();
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            s = MFMA(frag_rm(Qt, qt * 32, fo.rm[kk]), kf[kk], s);      // S[q][key]: lane <-> key, regs <-> q
-            dp = MFMA(frag_rm(Dt, qt * 32, fo.rm[kk]), vf[kk], dp);    // dP[q][key]
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 lq = *(const float4*)(Ls + qt * 32 + 8 * g + 4 * hi);
-            const float4 dq = *(const float4*)(Ds + qt * 32 + 8 * g + 4 * hi);
-            const float lqa[4] = {lq.x, lq.y, lq.z, lq.w};
-            const float dqa[4] = {dq.x, dq.y, dq.z, dq.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float pv = EXP2(fmaf(s[g * 4 + e], scale_log2, -lqa[e]));
-                s[g * 4 + e] = pv;                                  // P   (in place)
-                dp[g * 4 + e] = pv * (dp[g * 4 + e] - dqa[e]);      // dS  (in place)
-            }
-        }
-        // dS -> LDS as [key][q] (this lane: its key, 4 x 4 consecutive q), read back with lane <-> q, k <-> key
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            bf16x4 v4;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v4[e] = (bf16_t)dp[g * 4 + e];
-            *(__attribute__((address_space(3))) bf16x4*)(slot3 + st_w + (((2 * g + hi) ^ st_sw) << 3)) = v4;
-        }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const bf16x8 pb = pack_b(s, ks), db = pack_b(dp, ks);
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                dv[dt] = MFMA(frag_tr(Dt, qt * 32 + ks * 16, fo, dt), pb, dv[dt]);
-                dk[dt] = MFMA(frag_tr(Qt, qt * 32 + ks * 16, fo, dt), db, dk[dt]);
-            }
-        }
-        bf16x8 dsq[2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (__attribute__((address_space(3))) bf16x4*)(slot3 + st_r[ks][r]));
-                dsq[ks][4 * r + 0] = v[0]; dsq[ks][4 * r + 1] = v[1]; dsq[ks][4 * r + 2] = v[2]; dsq[ks][4 * r + 3] = v[3];
-            }
-        f32x16 dqp[2] = {zero16(), zero16()};   // dQ^T partial: lane <-> q, regs <-> d
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) dqp[dt] = MFMA(kT[dt][ks], dsq[ks], dqp[dt]);
-        // partial -> own slot, [32 q][64 d] fp32 (256-B rows), 16-B chunk index XOR (q & 15)
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                *(float4*)(slot + l31 * 256 + (((dt * 8 + 2 * g + hi) ^ (l31 & 15)) << 4)) =
-                    make_float4(dqp[dt][g * 4 + 0], dqp[dt][g * 4 + 1], dqp[dt][g * 4 + 2], dqp[dt][g * 4 + 3]);
-        __syncthreads();
-        {   // reduce: thread -> (row q = tid / 16, 16-B chunk c = tid % 16); fixed summation order over the waves
-            const int q = tid >> 4, c = tid & 15;
-            const int off = q * 256 + ((c ^ (q & 15)) << 4);
-            float4 acc4 = *(const float4*)(area + off);
-#pragma unroll
-            for (int ww = 1; ww < NK; ++ww) {
-                const float4 t = *(const float4*)(area + ww * FB_SLOT + off);
-                acc4.x += t.x; acc4.y += t.y; acc4.z += t.z; acc4.w += t.w;
-            }
-            const float de = De[qt * 32 + q];
-            const float4 ke = *(const float4*)(Ke + 4 * c);
-            const int row = qt * 32 + q;
-            if (row < S) {
-                bf16x4 ov;
-                ov[0] = (bf16_t)(fmaf(de, ke.x, acc4.x) * scale); ov[1] = (bf16_t)(fmaf(de, ke.y, acc4.y) * scale);
-                ov[2] = (bf16_t)(fmaf(de, ke.z, acc4.z) * scale); ov[3] = (bf16_t)(fmaf(de, ke.w, acc4.w) * scale);
-                *(bf16x4*)(dqkv + ((long)b * S + row) * lddq + h * 64 + 4 * c) = ov;
-            }
-        }
-        __syncthreads();
-    }
-
-    stamp(3);
-    // ---- phase 3: dK, dV of this wave's keys; the odd key ------------------------------------------------------
-    {
-        const int key = w * 32 + l31;
-        bf16_t* krow = dqkv + ((long)b * S + key) * lddq + W + h * 64;
-        bf16_t* vrow = krow + W;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                bf16x4 ok, ov;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    ok[e] = (bf16_t)(dk[dt][g * 4 + e] * scale);
-                    ov[e] = (bf16_t)dv[dt][g * 4 + e];
-                }
-                *(bf16x4*)(krow + dt * 32 + 8 * g + 4 * hi) = ok;
-                *(bf16x4*)(vrow + dt * 32 + 8 * g + 4 * hi) = ov;
-            }
-    }
-    if (w == 0) {
-        float ak = 0.0f, av = 0.0f;
-#pragma unroll
-        for (int ww = 0; ww <= NK; ++ww) { ak += KVe[(ww * 2 + 0) * 64 + lane]; av += KVe[(ww * 2 + 1) * 64 + lane]; }
-        bf16_t* krow = dqkv + ((long)b * S + SE) * lddq + W + h * 64;
-        krow[lane] = (bf16_t)(ak * scale);
-        krow[W + lane] = (bf16_t)av;
-    }
-    stamp(4);
-}
-
-constexpr int FB2_TILE = 2048;   // one wave's dS tile [32 keys][32 q] bf16
-
-template <int NK>
-__global__ void __launch_bounds__(NK * 64)
-attn_bwd_fused2_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __restrict__ o, long ldo,
-                      const bf16_t* __restrict__ d_o, long lddo, const float* __restrict__ lse2,
-                      bf16_t* __restrict__ dqkv, long lddq, int H, int S, int W, float scale, float scale_log2,
-                      unsigned long long* __restrict__ trace, int desync) {
-    // optional phase timeline (RVLM_ATTN_TRACE=1: 5 s_memtime stamps per workgroup into the dsum scratch buffer)
-    auto stamp = [&](int k) {
-        if (trace && threadIdx.x == 0) trace[(long)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memtime();
-    };
-    // Phase offset: every CU would otherwise stage its head at the same moment (6 TB/s-bound, 22 % of the kernel spent
-    // waiting for HBM) and compute at the same moment (HBM idle).  The first workgroup of each CU starts up to 7 x desync
-    // kilo-cycles late; the stagger then persists, one CU's staging hides under the others' compute.
-    if (desync > 0 && blockIdx.x < 256) {
-        for (int i = 0; i < (int)((blockIdx.x >> 3) & 7) * desync; ++i) __builtin_amdgcn_s_sleep(16);   // 16 x 64 cycles
-    }
-    stamp(0);
-    constexpr int NT = NK + 1, Sp = NT * 32, SE = NK * 32;   // query tiles, padded rows, index of the odd key
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Qt = smem;
-    char* Dt = smem + Sp * 128;
-    char* area = smem + Sp * 256;                              // K | V tiles, later NK partial slots
-    char* Kt = area;
-    char* Vt = area + Sp * 128;
-    float* Ls = (float*)(area + Sp * 256);
-    float* Ds = Ls + Sp;
-    float* Pe = Ds + Sp;                                       // p[q][odd key]
-    float* De = Pe + Sp;                                       // dS[q][odd key]
-    float* Ke = De + Sp;                                       // k[odd key][0..63] as fp32
-    float* KVe = Ke + 64;                                      // [NK + 1][2][64] per-wave (+ odd query) dK / dV of the odd key
-    const int b = blockIdx.x / H, h = blockIdx.x % H;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int l31 = lane & 31, hi = lane >> 5;
-    const bf16_t* base = qkv + (long)b * S * ld + h * 64;
-    const bf16_t* dob = d_o + (long)b * S * lddo + h * 64;
-    const bf16_t* ob = o + (long)b * S * ldo + h * 64;
-
-    // ---- phase 0: stage Q, dO, K, V; lse -------------------------------------------------------------------
-    stage_tile(Qt, base, ld, S, Sp, w, NK, lane);
-    stage_tile(Dt, dob, lddo, S, Sp, w, NK, lane);
-    stage_tile(Kt, base + W, ld, S, Sp, w, NK, lane);
-    stage_tile(Vt, base + 2 * W, ld, S, Sp, w, NK, lane);
-    for (int i = tid; i < Sp; i += NK * 64) Ls[i] = (i < S) ? lse2[((long)b * H + h) * Sp + i] : INFINITY;
-    if (tid < 64) Ke[tid] = (float)base[(long)SE * ld + W + tid];
-    bf16x8 ofr[4];   // O rows of this wave's query tile (for D = rowsum(dO * O)): requested under the staging
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) ofr[kk] = frag_global(ob, ldo, w * 32 + (lane & 31), kk, lane);
     __syncthreads();
     stamp(1);
 
@@ -969,10 +729,15 @@ attn_bwd_fused2_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __
             for (int ks = 0; ks < 2; ++ks) {
                 bf16x8 pb, db;
 #pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const int qq = qe * 32 + ks * 16 + 4 * hi + (t & 3) + 8 * (t >> 2);
-                    pb[t] = (bf16_t)(l31 == 0 ? Pe[qq] : 0.0f);
-                    db[t] = (bf16_t)(l31 == 0 ? De[qq] : 0.0f);
+                for (int half = 0; half < 2; ++half) {     // k index t = 4 half + e <-> query qe*32 + ks*16 + 4 hi + 8 half + e
+                    const int q0 = qe * 32 + ks * 16 + 4 * hi + 8 * half;
+                    const float4 p4 = *(const float4*)(Pe + q0), d4 = *(const float4*)(De + q0);
+                    const float pa[4] = {p4.x, p4.y, p4.z, p4.w}, da[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        pb[4 * half + e] = (bf16_t)(l31 == 0 ? pa[e] : 0.0f);
+                        db[4 * half + e] = (bf16_t)(l31 == 0 ? da[e] : 0.0f);
+                    }
                 }
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
@@ -981,21 +746,20 @@ attn_bwd_fused2_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __
                 }
             }
         }
-        if (l31 == 0) {   // column 0: rows d = dt*32 + (r&3) + 8*(r>>2) + 4*hi
+        if (l31 == 0) {   // column 0: rows d = dt*32 + 8*g + 4*hi + 0..3 in registers 4 g .. 4 g + 3
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    KVe[(w * 2 + 0) * 64 + d] = dke[dt][r];
-                    KVe[(w * 2 + 1) * 64 + d] = dve[dt][r];
+                for (int g = 0; g < 4; ++g) {
+                    const int d = dt * 32 + 8 * g + 4 * hi;
+                    *(float4*)(KVe + (w * 2 + 0) * 64 + d) = make_float4(dke[dt][4 * g], dke[dt][4 * g + 1], dke[dt][4 * g + 2], dke[dt][4 * g + 3]);
+                    *(float4*)(KVe + (w * 2 + 1) * 64 + d) = make_float4(dve[dt][4 * g], dve[dt][4 * g + 1], dve[dt][4 * g + 2], dve[dt][4 * g + 3]);
                 }
         }
     }
     if (w == NK - 1) {
         // the odd QUERY (row SE) against the odd key, as 64-wide vectors (lane <-> d): D, p, dS, and its dK / dV terms
-        const float dov = (float)dob[(long)SE * lddo + lane], ov = (float)ob[(long)SE * ldo + lane];
-        const float qv = (float)base[(long)SE * ld + lane], kv = Ke[lane], vv = (float)base[(long)SE * ld + 2 * W + lane];
+        const float dov = odd_do, ov = odd_o, qv = odd_q, kv = Ke[lane], vv = odd_v;
         const float dsum = wave_sum(dov * ov), sc = wave_sum(qv * kv), dpe = wave_sum(dov * vv);
         const float pe = EXP2(fmaf(sc, scale_log2, -Ls[SE]));
         const float de = pe * (dpe - dsum);
@@ -1054,7 +818,8 @@ attn_bwd_fused2_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __
             for (int e = 0; e < 4; ++e) v4[e] = (bf16_t)dp[g * 4 + e];
             *(__attribute__((address_space(3))) bf16x4*)(buf + st_w + (((2 * g + hi) ^ st_sw) << 3)) = v4;
         }
-        // operands of dV / dK: independent of the other waves, fetched before the barrier
+        // operands of dV / dK (dO^T, Q^T of this query tile): independent of the other waves.  (Requesting them ahead of
+        // the softmax arithmetic measured 1 % slower: 256 VGPRs and a spill.)
         bf16x8 dot[2][2], qtr[2][2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -1104,23 +869,36 @@ attn_bwd_fused2_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __
 
     stamp(3);
     // ---- phase 3: dK, dV of this wave's keys; the odd key ------------------------------------------------------
+    // Through a wave-private 4 KiB LDS tile ([32 keys][64 d] bf16, 16-B chunk index XOR (key & 7)), so that the global
+    // stores are 16 B per lane and 8 whole 128-B rows per instruction instead of row-per-lane 8-byte stores (4 + 4
+    // dwordx4 stores instead of 16 + 16 dwordx2; the store tail was 10 % of the kernel, issue-bound).  The tile lives
+    // behind the dS buffers, which slower waves may still be reading.
     {
-        const int key = w * 32 + l31;
-        bf16_t* krow = dqkv + ((long)b * S + key) * lddq + W + h * 64;
-        bf16_t* vrow = krow + W;
+        lds_char* tile = (lds_char*)area + 2 * NK * FB2_TILE + w * 4096;
+        const int r8 = lane >> 3, c8 = lane & 7;
+        bf16_t* kbase = dqkv + ((long)b * S + w * 32) * lddq + W + h * 64 + c8 * 8;
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
+        for (int which = 0; which < 2; ++which) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                bf16x4 ok, ov;
+            for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    ok[e] = (bf16_t)(dk[dt][g * 4 + e] * scale);
-                    ov[e] = (bf16_t)dv[dt][g * 4 + e];
+                for (int g = 0; g < 4; ++g) {
+                    bf16x4 ov;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        ov[e] = which == 0 ? (bf16_t)(dk[dt][g * 4 + e] * scale) : (bf16_t)dv[dt][g * 4 + e];
+                    *(__attribute__((address_space(3))) bf16x4*)(tile + l31 * 128 + (((dt * 4 + g) ^ (l31 & 7)) << 4) + hi * 8) = ov;
                 }
-                *(bf16x4*)(krow + dt * 32 + 8 * g + 4 * hi) = ok;
-                *(bf16x4*)(vrow + dt * 32 + 8 * g + 4 * hi) = ov;
+            bf16x8 t[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = it * 8 + r8;
+                t[it] = *(const __attribute__((address_space(3))) bf16x8*)(tile + row * 128 + ((c8 ^ (row & 7)) << 4));
             }
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+                *(bf16x8*)(kbase + (long)(it * 8 + r8) * lddq + which * W) = t[it];
+        }
     }
     if (w == 0) {
         float ak = 0.0f, av = 0.0f;
@@ -1202,14 +980,8 @@ int attn_bwd_bf16(const bf16_t* qkv, long ldqkv, const bf16_t* o, long ldo, cons
         static int trace = -1, desync = -1;
         if (trace < 0) { const char* e = getenv("RVLM_ATTN_TRACE"); trace = e ? atoi(e) : 0; }
         if (desync < 0) { const char* e = getenv("RVLM_ATTN_DESYNC"); desync = e ? atoi(e) : 5; }
-        if (fused == 2) {
-            if ((rc = set_lds(attn_bwd_fused2_kernel<NK>, lds_f))) return rc;
-            hipLaunchKernelGGL((attn_bwd_fused2_kernel<NK>), dim3(B * H), dim3(NK * 64), lds_f, s, qkv, ldqkv, o, ldo, d_o, lddo,
-                               lse, dqkv, lddqkv, H, S, W, scale, sl2, trace ? (unsigned long long*)dsum_scratch : nullptr, desync);
-        } else {
-            hipLaunchKernelGGL((attn_bwd_fused_kernel<NK>), dim3(B * H), dim3(NK * 64), lds_f, s, qkv, ldqkv, o, ldo, d_o, lddo,
-                               lse, dqkv, lddqkv, H, S, W, scale, sl2, trace ? (unsigned long long*)dsum_scratch : nullptr, desync);
-        }
+        hipLaunchKernelGGL((attn_bwd_fused_kernel<NK>), dim3(B * H), dim3(NK * 64), lds_f, s, qkv, ldqkv, o, ldo, d_o, lddo,
+                           lse, dqkv, lddqkv, H, S, W, scale, sl2, trace ? (unsigned long long*)dsum_scratch : nullptr, desync);
         RVLM_CHECK_LAUNCH();
         return RVLM_OK;
     }

@@ -595,6 +595,9 @@ static int launch_256p_act(const GemmBf16& p, int tiles_m, int tiles_n, int m_to
             default: break;
         }
     }
+    if constexpr (EPI == EPI_F32_RESID) {   // evidence for DESIGN.md: the fp32 + residual epilogue with the MFMAs removed
+        if (g_persist_ablate == 2) return launch_256p_abl<EPI, ACT, 2>(p, tiles_m, tiles_n, m_total, s);
+    }
     return launch_256p_abl<EPI, ACT, 0>(p, tiles_m, tiles_n, m_total, s);
 }
 template <int EPI>
