@@ -326,14 +326,28 @@ attn_fwd_odd_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict_
         const float ltot = l + __shfl_xor(l, 32, 64);
         const float inv = 1.0f / ltot;
         bf16_t* orow = o + ((long)b * S + q) * ldo + h * 64;
+        // A lane holds 4 consecutive d per (dt, g) and its partner lane ^ 32 the next 4: v_permlane32_swap pairs the two
+        // 8-byte halves of the even chunk on the lower lanes and of the odd chunk on the upper lanes, so that the row leaves
+        // as four 16-byte stores per lane instead of eight 8-byte ones (the store tail of this kernel is issue-bound).
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                bf16x4 ov;
+            for (int pr = 0; pr < 2; ++pr) {
+                bf16x4 ev, od;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) ov[e] = (bf16_t)(oacc[dt][g * 4 + e] * inv);
-                *(bf16x4*)(orow + dt * 32 + 8 * g + 4 * hi) = ov;
+                for (int e = 0; e < 4; ++e) {
+                    ev[e] = (bf16_t)(oacc[dt][(2 * pr) * 4 + e] * inv);
+                    od[e] = (bf16_t)(oacc[dt][(2 * pr + 1) * 4 + e] * inv);
+                }
+                typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+                typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+                const u32x2v e2 = __builtin_bit_cast(u32x2v, ev), o2 = __builtin_bit_cast(u32x2v, od);
+                // (vdst, src) -> vdst keeps its lower lanes and takes src's lower lanes into its upper half; src takes
+                // vdst's upper lanes into its lower half
+                const auto r0 = __builtin_amdgcn_permlane32_swap(e2[0], o2[0], false, false);
+                const auto r1 = __builtin_amdgcn_permlane32_swap(e2[1], o2[1], false, false);
+                const u32x4v out = {r0[0], r1[0], r0[1], r1[1]};
+                *(u32x4v*)(orow + dt * 32 + 16 * pr + 8 * hi) = out;
             }
         if (hi == 0 && lse2) lse2[((long)b * H + h) * Sp + q] = m + log2f(ltot);
     }
