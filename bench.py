@@ -351,11 +351,11 @@ def main():
         # HBM-side traffic comes from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE cannot be
         # read from inside this process); the committed measurement of this same command is reported.
         traffic, traffic_src = None, None
-        tj = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+        tj = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")
         if os.path.exists(tj) and args.model == "ViT-L-14" and args.batch == 128 and args.precision == "bf16":
             try:
                 traffic = json.load(open(tj))["gemm_bytes_per_logical_launch"]
-                traffic_src = "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+                traffic_src = "profiles/r02_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
             except Exception:
                 traffic = None
         res["roofline"] = {
