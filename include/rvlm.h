@@ -189,6 +189,13 @@ int rvlm_check_image_range(const float* x, size_t n, int32_t* flags, rvlm_stream
 int rvlm_pgd_linf_update(const float* x, const float* grad, float* delta, float* velocity,
                          size_t n, float eps, float stepsize, float momentum, int mode_max,
                          float* x_adv_out, int32_t* flags, rvlm_stream_t stream);
+/* The L2 branch of the same block (norm in [2, 'l2', ...]; vlm_eval/attacks/utils.py:12-14,22-26), per sample b over
+ * its n_per_sample pixels:  g = NaN->0; g /= max(|g|_2, 1e-12); v = mom*v + g; v /= max(|v|_2, 1e-12);
+ * delta +/-= step*v; delta *= eps/(|delta|_2 + 1e-7) where |delta|_2 > eps (torch.renorm); delta = clamp(x+delta,0,1)-x.
+ * The norms are deterministic fp32 sums in an order of their own: equal to the reference to fp32 rounding. */
+int rvlm_pgd_l2_update(const float* x, const float* grad, float* delta, float* velocity, size_t n_per_sample, int B,
+                       float eps, float stepsize, float momentum, int mode_max, float* x_adv_out, int32_t* flags,
+                       rvlm_stream_t stream);
 /* One APGD step (apgd_train.py:205-229 == autopgd_base.py:328-341); step is per-sample [B]. */
 int rvlm_apgd_linf_step(const float* x, float* x_adv, float* x_adv_old, const float* grad,
                         const float* step, float a, float eps, size_t n_per_sample, int B,
@@ -243,6 +250,11 @@ int rvlm_pgd_run(rvlm_vit* h, const float* x, const float* delta0, int B,
                  float momentum, int mode_max, float* x_adv_out, float* loss_trace,
                  int32_t* flags, rvlm_stream_t stream);
 
+/* pgd() with the norm as a parameter: norm_kind 0 = L-inf (rvlm_pgd_run), 2 = L2 (rvlm_pgd_l2_update per iteration). */
+int rvlm_pgd_run_norm(rvlm_vit* h, const float* x, const float* delta0, int B, const rvlm_loss_spec* loss, int norm_kind,
+                      float eps, int iterations, float stepsize, float momentum, int mode_max, float* x_adv_out,
+                      float* loss_trace, int32_t* flags, rvlm_stream_t stream);
+
 /* APGD L-inf.  x_init: NULL -> start from clamp(x,0,1) (apgd_train) or the caller-provided random
  * start (APGDAttack).  logits_from_head: 0 -> the `argmax(model output)==y` test runs on the
  * embedding (apgd_train quirk); 1 -> on emb @ (logit_scale*T) logits
@@ -292,7 +304,8 @@ int rvlm_vit_reset_profile(rvlm_vit* h);
 const char* rvlm_last_error(void);
 int rvlm_version(void);   /* = RVLM_VERSION.  101: rvlm_loss_spec.y_target, rvlm_loss_grad(y_target), DLR losses;
                            * 102: square-attack kernels; 103: rvlm_vit_fwd_inputgrad, rvlm_vit_backward_params_stages,
-                           * rvlm_ce_logits, rvlm_head_logits(_bwd), double hyper-parameters in rvlm_adamw_step */
+                           * rvlm_ce_logits, rvlm_head_logits(_bwd), double hyper-parameters in rvlm_adamw_step,
+                           * rvlm_pgd_l2_update, rvlm_pgd_run_norm */
 
 #ifdef __cplusplus
 }

@@ -80,6 +80,85 @@ pgd_linf_update_kernel(const float* __restrict__ x, const float* __restrict__ g,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// L2 branch of pgd() (train/pgd_train.py:38-63 with vlm_eval/attacks/utils.py:12-14,22-26): the per-sample norms make
+// it three dependent reductions, so ONE workgroup owns one sample and walks its pixels four times (the sample's four
+// tensors are 2.4 MB: the later passes are L2-cache reads):
+//   g = NaN -> 0;  g /= max(|g|_2, 1e-12)                         F.normalize(grad.view(bs, -1), p=2, dim=1)
+//   v = mom * v + g;  v /= max(|v|_2, 1e-12)                      momentum, normalize again
+//   d = d +- step * v;  d *= eps / (|d|_2 + 1e-7) if |d|_2 > eps  torch.renorm(d, p=2, dim=0, maxnorm=eps)
+//   d = clamp(x + d, 0, 1) - x
+// Sums of squares are fp32 in a fixed order (lane-strided partial sums, wave shuffles, 16 wave partials in LDS):
+// deterministic, but not torch's reduction order - parity with the reference is to fp32 rounding of the norms, not
+// bit-exact like the L-inf branch.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum_1024(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();                                   // red may still be read from the previous reduction
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += red[i];
+    return t;
+}
+
+__global__ void __launch_bounds__(1024)
+pgd_l2_update_kernel(const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ delta,
+                     float* __restrict__ vel, size_t n_per, float eps, float step, float mom, int mode_max,
+                     float* __restrict__ x_adv_out, int32_t* flags) {
+    __shared__ float red[16];
+    const size_t base = (size_t)blockIdx.x * n_per;
+    const float* xs = x + base;
+    const float* gs = g + base;
+    float* ds = delta + base;
+    float* vs = vel + base;
+    int f = 0;
+    float acc = 0.0f;
+    for (size_t i = threadIdx.x; i < n_per; i += 1024) {
+        float gi = gs[i];
+        if (gi != gi) { gi = 0.0f; f |= RVLM_FLAG_NAN_GRAD; }
+        acc = fmaf(gi, gi, acc);
+    }
+    const float gn = fmaxf(sqrtf(block_sum_1024(acc, red)), 1e-12f);
+    acc = 0.0f;
+    for (size_t i = threadIdx.x; i < n_per; i += 1024) {
+        float gi = gs[i];
+        if (gi != gi) gi = 0.0f;
+        const float v = mom * vs[i] + gi / gn;
+        vs[i] = v;                                      // un-normalised for now (same thread re-reads it below)
+        acc = fmaf(v, v, acc);
+    }
+    const float vn = fmaxf(sqrtf(block_sum_1024(acc, red)), 1e-12f);
+    acc = 0.0f;
+    for (size_t i = threadIdx.x; i < n_per; i += 1024) {
+        const float v = vs[i] / vn;
+        vs[i] = v;
+        const float sv = step * v;
+        const float d = mode_max ? (ds[i] + sv) : (ds[i] - sv);
+        ds[i] = d;
+        acc = fmaf(d, d, acc);
+    }
+    const float dn = sqrtf(block_sum_1024(acc, red));
+    const float sc = dn > eps ? eps / (dn + 1e-7f) : 1.0f;
+    for (size_t i = threadIdx.x; i < n_per; i += 1024) {
+        const float xv = xs[i];
+        float d = ds[i] * sc;
+        d = clamp01(xv + d) - xv;
+        if (d != d) f |= RVLM_FLAG_NAN_DELTA;
+        const float s2 = xv + d;
+        if (!(s2 < 1.000001f && s2 > -1e-6f)) f |= RVLM_FLAG_ADV_RANGE;
+        ds[i] = d;
+        if (x_adv_out) x_adv_out[base + i] = s2;
+    }
+    if (flags) {
+        int wf = f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) wf |= __shfl_xor(wf, o, 64);
+        if (wf && (threadIdx.x & 63) == 0) atomicOr(flags, wf);
+    }
+}
+
 // one block row per sample chunk: blockIdx.y = sample
 __global__ void __launch_bounds__(256)
 apgd_linf_step_kernel(const float* __restrict__ x, float* __restrict__ x_adv,
@@ -256,6 +335,16 @@ extern "C" int rvlm_pgd_linf_update(const float* x, const float* grad, float* de
         hipLaunchKernelGGL(pgd_linf_update_kernel<false>, dim3(ew_grid(n, 1)), dim3(256), 0,
                            (hipStream_t)stream, x, grad, delta, velocity, n, eps, stepsize,
                            momentum, mode_max, x_adv_out, flags);
+    RVLM_CHECK_LAUNCH();
+    return RVLM_OK;
+}
+
+extern "C" int rvlm_pgd_l2_update(const float* x, const float* grad, float* delta, float* velocity, size_t n_per_sample,
+                                  int B, float eps, float stepsize, float momentum, int mode_max, float* x_adv_out,
+                                  int32_t* flags, rvlm_stream_t stream) {
+    RVLM_REQUIRE(x && grad && delta && velocity && n_per_sample > 0 && B > 0, "rvlm_pgd_l2_update: bad arguments");
+    hipLaunchKernelGGL(pgd_l2_update_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, x, grad, delta, velocity,
+                       n_per_sample, eps, stepsize, momentum, mode_max, x_adv_out, flags);
     RVLM_CHECK_LAUNCH();
     return RVLM_OK;
 }

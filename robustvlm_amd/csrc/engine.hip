@@ -1014,11 +1014,12 @@ extern "C" int rvlm_vit_fwd_inputgrad(rvlm_vit* h, const float* x, const float* 
     return RVLM_OK;
 }
 
-extern "C" int rvlm_pgd_run(rvlm_vit* h, const float* x, const float* delta0, int B,
-                            const rvlm_loss_spec* loss, float eps, int iterations, float stepsize,
-                            float momentum, int mode_max, float* x_adv_out, float* loss_trace,
-                            int32_t* flags, rvlm_stream_t stream) {
+extern "C" int rvlm_pgd_run_norm(rvlm_vit* h, const float* x, const float* delta0, int B,
+                                 const rvlm_loss_spec* loss, int norm_kind, float eps, int iterations, float stepsize,
+                                 float momentum, int mode_max, float* x_adv_out, float* loss_trace,
+                                 int32_t* flags, rvlm_stream_t stream) {
     RVLM_REQUIRE(h && x && loss && x_adv_out && loss->ref, "rvlm_pgd_run: null argument");
+    if (norm_kind != 0 && norm_kind != 2) return fail(RVLM_ERR_UNSUPPORTED, "rvlm_pgd_run: norm must be L-inf (0) or L2 (2)");
     RVLM_REQUIRE(B > 1 && B <= h->maxB, "rvlm_pgd_run: need 1 < B <= max_batch");
     RVLM_REQUIRE(iterations >= 0 && iterations <= 4096, "rvlm_pgd_run: iterations");
     hipStream_t s = (hipStream_t)stream;
@@ -1040,11 +1041,21 @@ extern "C" int rvlm_pgd_run(rvlm_vit* h, const float* x, const float* delta0, in
         if ((rc = vit_backward(h, h->d_emb, B, grad, s))) return rc;
         {
             PROF("linf_update", 0, (double)n * 28);
-            if ((rc = rvlm_pgd_linf_update(x, grad, delta, vel, n, eps, stepsize, momentum, mode_max,
-                                           it == iterations - 1 ? x_adv_out : nullptr, flags, s))) return rc;
+            float* xo = it == iterations - 1 ? x_adv_out : nullptr;
+            if (norm_kind == 2) rc = rvlm_pgd_l2_update(x, grad, delta, vel, n / B, B, eps, stepsize, momentum, mode_max, xo, flags, s);
+            else rc = rvlm_pgd_linf_update(x, grad, delta, vel, n, eps, stepsize, momentum, mode_max, xo, flags, s);
+            if (rc) return rc;
         }
     }
     return RVLM_OK;
+}
+
+extern "C" int rvlm_pgd_run(rvlm_vit* h, const float* x, const float* delta0, int B,
+                            const rvlm_loss_spec* loss, float eps, int iterations, float stepsize,
+                            float momentum, int mode_max, float* x_adv_out, float* loss_trace,
+                            int32_t* flags, rvlm_stream_t stream) {
+    return rvlm_pgd_run_norm(h, x, delta0, B, loss, 0, eps, iterations, stepsize, momentum, mode_max, x_adv_out,
+                             loss_trace, flags, stream);
 }
 
 extern "C" int rvlm_apgd_run(rvlm_vit* h, const float* x, const float* x_init, int B,

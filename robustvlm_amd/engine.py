@@ -218,8 +218,9 @@ class VitEngine:
         return ls
 
     def pgd_run(self, x, delta0, loss_kind, reduction, ref, targets, output_normalize, eps, iterations,
-                stepsize, momentum, mode, logit_scale=100.0, want_trace=False):
-        """Whole pgd() loop on the device (rvlm_pgd_run).  Returns (x_adv, flags:int, loss_trace|None)."""
+                stepsize, momentum, mode, logit_scale=100.0, want_trace=False, norm_kind=0):
+        """Whole pgd() loop on the device (rvlm_pgd_run_norm; norm_kind 0 = L-inf, 2 = L2).
+        Returns (x_adv, flags:int, loss_trace|None)."""
         self._check_images(x)
         x = _f32c(x)
         d0 = _f32c(delta0) if delta0 is not None else None
@@ -230,10 +231,10 @@ class VitEngine:
         flags = torch.zeros(1, dtype=torch.int32, device=x.device)
         trace = torch.zeros(max(iterations, 1), dtype=torch.float32, device=x.device) if want_trace else None
         with torch.cuda.device(x.device):
-            L.check(self.lib.rvlm_pgd_run(self._h, x.data_ptr(), L.ptr(d0), x.shape[0], C.byref(ls), float(eps),
-                                          int(iterations), float(stepsize), float(momentum),
-                                          1 if mode == "max" else 0, out.data_ptr(), L.ptr(trace),
-                                          flags.data_ptr(), L.stream_ptr()), "rvlm_pgd_run")
+            L.check(self.lib.rvlm_pgd_run_norm(self._h, x.data_ptr(), L.ptr(d0), x.shape[0], C.byref(ls),
+                                               int(norm_kind), float(eps), int(iterations), float(stepsize),
+                                               float(momentum), 1 if mode == "max" else 0, out.data_ptr(),
+                                               L.ptr(trace), flags.data_ptr(), L.stream_ptr()), "rvlm_pgd_run")
         self.generation += 1
         return out, flags, trace
 

@@ -38,14 +38,14 @@ def pgd(forward, loss_fn, data_clean, targets, norm, eps, iterations, stepsize, 
         raise NotImplementedError(f"Norm {norm} not supported")                          # utils.py:16
     lib = L.load()
 
-    fused = (norm in LINF and isinstance(forward, ClipVisionModel)
+    fused = (isinstance(forward, ClipVisionModel)
              and isinstance(loss_fn, ComputeLossWrapper) and not verbose
              and loss_fn.reduction in ("mean", "none") and data_clean.shape[0] > 1)
     if fused:
         kind, ref = loss_fn.fused_spec()
         x_adv, flags, _ = forward.model.pgd_run(
             data_clean, perturbation, kind, loss_fn.reduction, ref, targets, output_normalize, eps,
-            iterations, stepsize, momentum, mode, loss_fn.logit_scale)
+            iterations, stepsize, momentum, mode, loss_fn.logit_scale, norm_kind=0 if norm in LINF else 2)
         _raise_from_flags(int(flags.item()))          # the loop's only host sync
         return x_adv
 
@@ -72,13 +72,11 @@ def pgd(forward, loss_fn, data_clean, targets, norm, eps, iterations, stepsize, 
                         x.data_ptr(), gradient.data_ptr(), delta.data_ptr(), velocity.data_ptr(), n,
                         float(eps), float(stepsize), float(momentum), 1 if mode == "max" else 0, None,
                         flags.data_ptr(), L.stream_ptr()), "rvlm_pgd_linf_update")
-            else:   # L2 branch of the reference (secondary; tensor ops)
-                gradient = torch.nan_to_num(gradient, nan=0.0, posinf=float("inf"), neginf=float("-inf"))
-                gradient = normalize_grad(gradient, p=norm)
-                velocity = normalize_grad(momentum * velocity + gradient, p=norm)
-                delta = delta - stepsize * velocity if mode == "min" else delta + stepsize * velocity
-                delta = project_perturbation(delta, eps, norm)
-                delta = torch.clamp(x + delta, 0, 1) - x
-                assert not delta.isnan().any()
+            else:   # L2 branch (utils.py:12-14,22-26): per-sample normalise / momentum / renorm / clamp in one kernel
+                with torch.cuda.device(x.device):
+                    L.check(lib.rvlm_pgd_l2_update(
+                        x.data_ptr(), gradient.data_ptr(), delta.data_ptr(), velocity.data_ptr(), x[0].numel(),
+                        x.shape[0], float(eps), float(stepsize), float(momentum), 1 if mode == "max" else 0, None,
+                        flags.data_ptr(), L.stream_ptr()), "rvlm_pgd_l2_update")
     _raise_from_flags(int(flags.item()))
     return data_clean + delta.detach()

@@ -247,3 +247,65 @@ def test_preprocess_kernel_bit_exact_vs_pillow_golden():
     small = R.ResizeCenterCropToTensor(32, max_input_dim=64)
     with pytest.raises(NotImplementedError):
         small(torch.zeros(1000, 1000, 3, dtype=torch.uint8).cuda())   # 31x down-scaling needs more taps than provisioned
+
+
+# ---- L2-norm branch of pgd as a device kernel (rvlm_pgd_l2_update), against the reference's own outputs
+@pytest.mark.parametrize("mode", ["max", "min"])
+def test_pgd_l2_update_kernel_vs_golden(mode):
+    """Per-sample normalise / momentum / renorm / clamp (train/pgd_train.py:38-63 with utils.py:12-14,22-26).  The norms
+    are fp32 sums in the kernel's own order: equal to the reference to fp32 rounding of three norms per step (tolerance
+    2e-6 absolute on pixel values in [0,1]; the all-zero-gradient sample and the NaN entries must behave identically)."""
+    l = lib()
+    z = load_golden("pgd_l2norm.npz")
+    x = _cu(z["ew_x"]); delta = _cu(z["ew_delta0"]); vel = torch.zeros_like(x)
+    B, npix = x.shape[0], x[0].numel()
+    flags = torch.zeros(1, dtype=torch.int32, device=dev())
+    xadv = torch.zeros_like(x)
+    eps, step = float(z["ew_eps"]), float(z["ew_stepsize"])
+    for i in range(4):
+        g = _cu(z["ew_grads"][i])
+        L.check(l.rvlm_pgd_l2_update(x.data_ptr(), g.data_ptr(), delta.data_ptr(), vel.data_ptr(), npix, B, eps, step,
+                                     0.9, int(mode == "max"), xadv.data_ptr(), flags.data_ptr(), st()))
+        torch.cuda.synchronize()
+        got, want = xadv.cpu().numpy(), z[f"ew_xadv_{mode}"][i]
+        assert np.abs(got - want).max() < 2e-6, (i, np.abs(got - want).max())
+        assert np.array_equal(got[2], want[2])                   # zero gradient, zero velocity: the start point, clamped
+    assert int(flags.item()) == L.FLAG_NAN_GRAD
+    dn = (xadv - x).flatten(1).norm(dim=1)
+    assert float(dn.max()) <= eps * (1 + 1e-5)
+    # deterministic
+    d2 = _cu(z["ew_delta0"]); v2 = torch.zeros_like(x); x2 = torch.zeros_like(x)
+    for i in range(4):
+        L.check(l.rvlm_pgd_l2_update(x.data_ptr(), _cu(z["ew_grads"][i]).data_ptr(), d2.data_ptr(), v2.data_ptr(), npix, B,
+                                     eps, step, 0.9, int(mode == "max"), x2.data_ptr(), None, st()))
+    torch.cuda.synchronize()
+    assert torch.equal(x2, xadv)
+
+
+def test_pgd_l2norm_fused_and_generic_vs_reference_golden():
+    """pgd(norm='l2') through the fused route (rvlm_pgd_run_norm) and the generic route (autograd + rvlm_pgd_l2_update)
+    on the fp32 engine against the reference's x_adv on the same tiny ViT."""
+    from oracle import vit_ref as V
+    from tests.helpers import cfg_from_array, weights_from_golden
+    zt = load_golden("tiny_vit_attacks.npz")
+    g = load_golden("pgd_l2norm.npz")
+    cfg = cfg_from_array(zt["cfg"])
+    w = weights_from_golden(zt)
+    eng = R.VitEngine(R.VitConfig(cfg.image_size, cfg.patch, cfg.width, cfg.layers, cfg.heads, cfg.out_dim, cfg.act),
+                      {k: v.to(dev()) for k, v in w.items()}, precision="fp32", max_batch=8)
+    model = R.ClipVisionModel(eng).eval()
+    x, d0 = _cu(zt["x"]), _cu(zt["delta0"])
+    e0 = model(x, False)
+    wrap = R.ComputeLossWrapper(e0, None, "mean", "l2", 100.)
+    eps, step = float(g["vit_eps"]), float(g["vit_stepsize"])
+    fused = R.pgd(model, wrap, x, None, "l2", eps, 10, step, False, perturbation=d0.clone(), mode="max")
+    generic = R.pgd(lambda v, output_normalize: model(v, output_normalize), wrap, x, None, "l2", eps, 10, step, False,
+                    perturbation=d0.clone().requires_grad_(True), mode="max")
+    want = g["vit_xadv"]
+    for name, got in (("fused", fused), ("generic", generic)):
+        diff = np.abs(got.cpu().numpy() - want).max()
+        assert diff < 1e-4, (name, diff)                          # fp32 encoders differ at 1e-6 relative; 10 steps
+        assert float((got - x).flatten(1).norm(dim=1).max()) <= eps * (1 + 1e-5)
+    lf = float(wrap(model(fused, False), None))
+    assert abs(lf - float(g["vit_loss_final"])) <= 1e-3 * abs(float(g["vit_loss_final"]))
+    eng.close()

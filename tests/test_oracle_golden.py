@@ -260,3 +260,33 @@ def test_preprocess_oracle_bit_exact_vs_pillow_golden():
         assert got.dtype == np.float32 and np.array_equal(got, want), f"case {i}"
     assert P.resize_size(375, 500, 224) == (224, 298) and P.resize_size(500, 333, 224) == (336, 224)
     assert P.center_crop_box(224, 298, 224, 224) == (0, 37) and P.center_crop_box(336, 224, 224, 224) == (56, 0)
+
+
+# ---- L2-norm branch of pgd (vlm_eval/attacks/utils.py:12-14,22-26), tests/golden/pgd_l2norm.npz (make_golden_l2norm.py)
+@pytest.mark.parametrize("mode", ["max", "min"])
+def test_pgd_l2norm_elementwise_bit_exact(mode):
+    from tests.helpers import InjectGrad
+    z = load_golden("pgd_l2norm.npz")
+    x, d0 = torch.from_numpy(z["ew_x"]), torch.from_numpy(z["ew_delta0"])
+    grads = [torch.from_numpy(g) for g in z["ew_grads"]]
+    for n_it in range(1, 5):
+        it = iter(range(n_it))
+        out = A.pgd_ref(lambda v, output_normalize=False: v, lambda o, t: InjectGrad.apply(o, grads[next(it)]), x, None,
+                        "l2", float(z["ew_eps"]), n_it, float(z["ew_stepsize"]), False, perturbation=d0.clone(), mode=mode)
+        assert np.array_equal(out.numpy(), z[f"ew_xadv_{mode}"][n_it - 1]), n_it
+    # the eps ball is the L2 ball, per sample
+    dn = (torch.from_numpy(z[f"ew_xadv_{mode}"][3]) - x).flatten(1).norm(dim=1)
+    assert float(dn.max()) <= float(z["ew_eps"]) * (1 + 1e-6)
+
+
+def test_pgd_l2norm_tiny_vit_bit_exact():
+    z, cfg, w = _tiny()
+    g = load_golden("pgd_l2norm.npz")
+    model = V.ClipVisionModelRef(cfg, w).eval()
+    x = torch.from_numpy(z["x"])
+    with torch.no_grad():
+        e0 = model(x, False)
+    wrap = Lr.ComputeLossWrapperRef(e0, None, "mean", "l2", 100.)
+    out = A.pgd_ref(model, wrap, x, None, "l2", float(g["vit_eps"]), 10, float(g["vit_stepsize"]), False,
+                    perturbation=torch.from_numpy(z["delta0"].copy()), mode="max")
+    assert np.array_equal(out.numpy(), g["vit_xadv"])
