@@ -104,7 +104,8 @@ class AdversarialTrainer:
                  steps=20000, loss="l2", inner_loss="l2", attack="pgd", norm="linf", eps=4 / 255,
                  iterations_adv=10, stepsize_adv=1 / 255, output_normalize=False, clean_weight=0.0,
                  embedding_text_labels_norm=None, betas=(0.9, 0.999), adam_eps=1e-8, device=None,
-                 loss_clean="l2", trades=False, n_buckets=4, metrics=True, process_group=None):
+                 loss_clean="l2", trades=False, n_buckets=4, metrics=True, process_group=None,
+                 always_reduce=False):
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.cfg = cfg
         self.lib = L.load()
@@ -131,9 +132,12 @@ class AdversarialTrainer:
         self.cur_lr = cosine_lr_value(0, lr, warmup, steps)      # scheduler(start_step), …clip.py:219
         self.pg = process_group
         self.world = dist.get_world_size(self.pg) if (dist.is_available() and dist.is_initialized()) else 1
-        self.buckets = bucket_plan(self.engine.n_stages, n_buckets if self.world > 1 else 1)
+        # always_reduce: run the bucketed all-reduce path even in a one-rank group (exercises the RCCL calls, the work
+        # handles and the stream ordering on a single GPU; the reduction itself is then the identity)
+        self._reduce = self.world > 1 or (bool(always_reduce) and dist.is_available() and dist.is_initialized())
+        self.buckets = bucket_plan(self.engine.n_stages, n_buckets if self._reduce else 1)
         # a backend without device collectives (gloo in the CPU/1-GPU tests) reduces through a pinned host copy
-        self._device_collectives = self.world > 1 and dist.get_backend(self.pg) == "nccl"
+        self._device_collectives = self._reduce and dist.get_backend(self.pg) == "nccl"
 
     # -- pieces of the step ----------------------------------------------------------------------
     def _attack(self, data, targets, e0):
@@ -228,7 +232,7 @@ class AdversarialTrainer:
             data_adv = self._attack(data, targets, e0)
         cw = self.clean_weight
         wshard = self._shard_weight(data.shape[0])
-        dp = self.world > 1
+        dp = self._reduce
         loss_clean = torch.zeros((), device=self.device)
         emb_clean = None
         accumulate = False

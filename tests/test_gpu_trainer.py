@@ -289,3 +289,19 @@ def test_data_parallel_step_two_ranks_one_gpu(tmp_path):
         assert moved > 1e-4, k                  # two Adam steps at lr 1e-3 did move the parameter
         assert float((got - want).abs().max()) < 5e-2 * moved, (k, float((got - want).abs().max()), moved)
     assert abs(res[0]["loss_global"] - single["loss"]) <= 1e-5 * abs(single["loss"])
+
+
+def test_bucketed_allreduce_on_rccl_single_rank(tmp_path):
+    """The trainer's bucketed asynchronous all-reduce on the REAL collective backend (RCCL, one-rank group on the one GPU
+    of the test box): async work handles, RCCL's internal stream and the wait before AdamW - identity reduction, so the
+    parameters after three steps equal the non-reducing trainer's bit for bit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "rccl.pt")
+    env = dict(os.environ, PYTHONPATH=root, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "rccl_worker.py"), out], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert torch.load(out)["same"]
