@@ -137,6 +137,13 @@ def test_train_step_bf16_runs_and_learns():
 # --------------------------------------------------------------------------------------------------------------------
 # round 2: loss_clean / trades / logging metrics / periodic eval / checkpoints on the device / data parallel
 # --------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return str(sk.getsockname()[1])
+
+
 def _tiny_problem(B=4, C=7, seed=4):
     cfg = V.VIT_TINY2
     w = V.init_weights(cfg, seed=21)
@@ -271,7 +278,7 @@ def test_data_parallel_step_two_ranks_one_gpu(tmp_path):
     os.makedirs(out)
     env = dict(os.environ, PYTHONPATH=root, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", os.path.join(root, "tests", "dp_worker.py"), out]
+           "--master-port", _free_port(), os.path.join(root, "tests", "dp_worker.py"), out]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     res = [torch.load(os.path.join(out, f"rank{i}.pt")) for i in range(2)]
@@ -300,7 +307,7 @@ def test_bucketed_allreduce_on_rccl_single_rank(tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = str(tmp_path / "rccl.pt")
-    env = dict(os.environ, PYTHONPATH=root, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    env = dict(os.environ, PYTHONPATH=root, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port())
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "rccl_worker.py"), out], env=env, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
