@@ -200,6 +200,11 @@ int rvlm_pgd_l2_update(const float* x, const float* grad, float* delta, float* v
 int rvlm_apgd_linf_step(const float* x, float* x_adv, float* x_adv_old, const float* grad,
                         const float* step, float a, float eps, size_t n_per_sample, int B,
                         rvlm_stream_t stream);
+/* The L2 branch of the same step (apgd_train.py:231-254): gradient step of length `step` along grad / |grad|_2, projection
+ * onto the eps ball (L2) around x and the image range, momentum mix (a, 1 - a), projection again; per-sample norms are
+ * deterministic fp32 sums in an order of their own (equal to the reference to fp32 rounding). */
+int rvlm_apgd_l2_step(const float* x, float* x_adv, float* x_adv_old, const float* grad, const float* step, float a,
+                      float eps, size_t n_per_sample, int B, rvlm_stream_t stream);
 /* Per-sample APGD bookkeeping for iteration i (apgd_train.py:301-305,320-355): k and do_check
  * follow the data-independent checkpoint schedule kept by the host. */
 int rvlm_apgd_controller(int i, int B, int n_iter, int k, int do_check, const float* loss_i,
@@ -274,6 +279,11 @@ int rvlm_vit_fwd_inputgrad(rvlm_vit* h, const float* x, const float* delta, int 
                            float* out_emb, float* out_loss_per_sample, float* out_loss_scalar, float* out_grad_x,
                            rvlm_stream_t stream);
 
+/* rvlm_apgd_run with the norm as a parameter: norm_kind 0 = L-inf, 2 = L2 (apgd_train(norm='l2'); train_variant only). */
+int rvlm_apgd_run_norm(rvlm_vit* h, const float* x, const float* x_init, int B, const rvlm_loss_spec* loss, int norm_kind,
+                       float eps, int n_iter, float alpha, int train_variant, int logits_from_head, float* x_best_adv,
+                       float* x_best, float* loss_best, uint8_t* acc, rvlm_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Input front end: replaces Compose([Resize(size, bicubic), CenterCrop(size),
  * ToTensor()]) over a decoded RGB image (train/adversarial_training_clip.py:105-116; torchvision 0.15.2 over Pillow).
@@ -305,7 +315,7 @@ const char* rvlm_last_error(void);
 int rvlm_version(void);   /* = RVLM_VERSION.  101: rvlm_loss_spec.y_target, rvlm_loss_grad(y_target), DLR losses;
                            * 102: square-attack kernels; 103: rvlm_vit_fwd_inputgrad, rvlm_vit_backward_params_stages,
                            * rvlm_ce_logits, rvlm_head_logits(_bwd), double hyper-parameters in rvlm_adamw_step,
-                           * rvlm_pgd_l2_update, rvlm_pgd_run_norm */
+                           * rvlm_pgd_l2_update, rvlm_pgd_run_norm, rvlm_apgd_l2_step, rvlm_apgd_run_norm */
 
 #ifdef __cplusplus
 }

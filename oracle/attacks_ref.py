@@ -90,6 +90,24 @@ def apgd_linf_step_ref(x, x_adv, x_adv_old, grad, step, a, eps):
     return new.astype(F32), x_adv.copy()
 
 
+def apgd_l2_step_ref(x, x_adv, x_adv_old, grad, step, a, eps):
+    """One APGD L2 step (train/apgd_train.py:231-254), with the reference's own tensor expressions (the per-sample
+    norms are torch sums: ``(t ** 2).view(B, -1).sum(-1).sqrt()``, :16-20), so that the restatement is bit-equal to the
+    reference on the CPU.  ``step`` is [B,1,1,1] fp32.  Returns (x_adv_new, x_adv_old_new)."""
+    xt, xa, xo, g = (torch.from_numpy(np.ascontiguousarray(t)) for t in (x, x_adv, x_adv_old, grad))
+    st = torch.from_numpy(np.ascontiguousarray(step))
+
+    def l2n(t):
+        return (t ** 2).view(t.shape[0], -1).sum(-1).sqrt().view(-1, *[1] * (t.dim() - 1))
+
+    grad2 = xa - xo
+    x1 = xa + st * g / (l2n(g) + 1e-12)
+    x1 = torch.clamp(xt + (x1 - xt) / (l2n(x1 - xt) + 1e-12) * torch.min(eps * torch.ones_like(xt), l2n(x1 - xt)), 0.0, 1.0)
+    x1 = xa + (x1 - xa) * a + grad2 * (1 - a)
+    x1 = torch.clamp(xt + (x1 - xt) / (l2n(x1 - xt) + 1e-12) * torch.min(eps * torch.ones_like(xt), l2n(x1 - xt)), 0.0, 1.0)
+    return x1.numpy().astype(F32), x_adv.copy()
+
+
 def check_oscillation_ref(loss_steps: np.ndarray, j: int, k: int, k3: float = 0.75) -> np.ndarray:
     """train/apgd_train.py:117-122; negative row indices wrap like Python/torch indexing."""
     t = np.zeros(loss_steps.shape[1], dtype=F32)
@@ -201,8 +219,9 @@ def apgd_train_ref(model, x, y, norm, eps, n_iter=10, use_rs=False, loss_fn=None
                    is_train=True, initial_stepsize=None, trace=None):
     assert not model.training                                                     # :127
     norm = norm.replace("linf", "Linf").replace("l2", "L2")
-    if norm != "Linf":
-        raise NotImplementedError("oracle restates the Linf branch only (SURVEY.md 8(a4))")
+    if norm not in ("Linf", "L2"):
+        raise NotImplementedError("oracle restates the Linf and L2 branches (SURVEY.md 8(a4))")
+    step_fn = apgd_linf_step_ref if norm == "Linf" else apgd_l2_step_ref
     if use_rs:
         raise NotImplementedError  # reference raises too (:132-135)
     xn = x.detach().cpu().numpy().astype(F32)
@@ -222,8 +241,7 @@ def apgd_train_ref(model, x, y, norm, eps, n_iter=10, use_rs=False, loss_fn=None
     x_adv_old = x_adv.copy()
     for i in range(n_iter):
         a = 0.75 if i > 0 else 1.0
-        x_adv, x_adv_old = apgd_linf_step_ref(xn, x_adv, x_adv_old, grad,
-                                              ctl.step.reshape(B, 1, 1, 1), a, eps)
+        x_adv, x_adv_old = step_fn(xn, x_adv, x_adv_old, grad, ctl.step.reshape(B, 1, 1, 1), a, eps)
         last = (i == n_iter - 1)
         logits, loss_indiv, g_new = _fwd_bwd(call, loss_fn, x_adv, y, need_grad=not last)
         if not last:

@@ -114,6 +114,10 @@ _SIGS = {
                                     C.c_int, C.c_float, C.c_float, C.c_int, c_f32p, c_f32p, C.c_void_p, c_stream]),
     "rvlm_apgd_linf_step": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_float, C.c_float,
                                       C.c_size_t, C.c_int, c_stream]),
+    "rvlm_apgd_l2_step": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_float, C.c_float, C.c_size_t, C.c_int,
+                                    c_stream]),
+    "rvlm_apgd_run_norm": (C.c_int, [C.c_void_p, c_f32p, c_f32p, C.c_int, C.POINTER(LossSpecC), C.c_int, C.c_float,
+                                     C.c_int, C.c_float, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, C.c_void_p, c_stream]),
     "rvlm_apgd_controller": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p,
                                        C.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, c_stream]),

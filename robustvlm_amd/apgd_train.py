@@ -21,7 +21,7 @@ def apgd_schedule(n_iter: int):
     return max(int(0.22 * n_iter), 1), max(int(0.06 * n_iter), 1), max(int(0.03 * n_iter), 1)
 
 
-def _apgd_linf_generic(model_call, loss_call, x, y, eps, n_iter, step0, train_variant, x_init=None):
+def _apgd_linf_generic(model_call, loss_call, x, y, eps, n_iter, step0, train_variant, x_init=None, norm_kind=0):
     """Shared host loop of apgd_train / APGDAttack.attack_single_run for arbitrary callables.
     Returns (x_best, acc(bool), loss_best, x_best_adv)."""
     lib = L.load()
@@ -65,8 +65,9 @@ def _apgd_linf_generic(model_call, loss_call, x, y, eps, n_iter, step0, train_va
     for i in range(n_iter):
         a = 0.75 if i > 0 else 1.0
         with torch.cuda.device(dev):
-            L.check(lib.rvlm_apgd_linf_step(x.data_ptr(), x_adv.data_ptr(), x_adv_old.data_ptr(),
-                                            grad.data_ptr(), step.data_ptr(), a, float(eps), npix, B, st()))
+            step_fn = lib.rvlm_apgd_l2_step if norm_kind == 2 else lib.rvlm_apgd_linf_step
+            L.check(step_fn(x.data_ptr(), x_adv.data_ptr(), x_adv_old.data_ptr(),
+                            grad.data_ptr(), step.data_ptr(), a, float(eps), npix, B, st()))
         need_grad = not (train_variant and i == n_iter - 1)
         loss_indiv, g = evaluate(need_grad)
         if need_grad:
@@ -95,9 +96,10 @@ def apgd_train(model, x, y, norm, eps, n_iter=10, use_rs=False, loss_fn=None, ve
     norm = norm.replace('linf', 'Linf').replace('l2', 'L2')
     if use_rs:
         raise NotImplementedError                                          # reference raises (:132-135)
-    if norm != 'Linf':
-        raise NotImplementedError(f"apgd_train on the native path covers norm='Linf' (got {norm}); "
+    if norm not in ('Linf', 'L2'):
+        raise NotImplementedError(f"apgd_train on the native path covers norm='Linf' and 'L2' (got {norm}); "
                                   f"SURVEY.md 8(a4)")
+    norm_kind = 0 if norm == 'Linf' else 2
     alpha = 2.
     if initial_stepsize:
         alpha = initial_stepsize / eps                                     # :168-169
@@ -109,7 +111,7 @@ def apgd_train(model, x, y, norm, eps, n_iter=10, use_rs=False, loss_fn=None, ve
         # output itself, i.e. the embedding
         x_best_adv, _, _, _ = model.model.apgd_run(x, None, kind, ref, y, True, eps, n_iter, step0,
                                                    train_variant=True, logits_from_head=False,
-                                                   logit_scale=loss_fn.logit_scale)
+                                                   logit_scale=loss_fn.logit_scale, norm_kind=norm_kind)
         return x_best_adv
     call = lambda t: model(t, output_normalize=True)   # noqa: E731
-    return _apgd_linf_generic(call, loss_fn, x, y, eps, n_iter, step0, True)[3]
+    return _apgd_linf_generic(call, loss_fn, x, y, eps, n_iter, step0, True, norm_kind=norm_kind)[3]

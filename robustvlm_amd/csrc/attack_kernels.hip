@@ -159,6 +159,56 @@ pgd_l2_update_kernel(const float* __restrict__ x, const float* __restrict__ g, f
     }
 }
 
+// L2 branch of the APGD step (train/apgd_train.py:231-254), one workgroup per sample, three per-sample norms:
+//   grad2 = x_adv - x_adv_old;  x_adv_old = x_adv
+//   z = x_adv + (step * grad) / (|grad|_2 + 1e-12)
+//   z = clamp(x + (z - x) / (|z - x|_2 + 1e-12) * min(eps, |z - x|_2), 0, 1)
+//   u = x_adv + (z - x_adv) * a + grad2 * (1 - a)
+//   x_adv = clamp(x + (u - x) / (|u - x|_2 + 1e-12) * min(eps, |u - x|_2), 0, 1)
+// z is recomputed instead of stored (x_adv and x_adv_old are rewritten only in the third pass).  fp32 sums in this
+// kernel's own fixed order: equal to the reference to fp32 rounding of the norms.
+__global__ void __launch_bounds__(1024)
+apgd_l2_step_kernel(const float* __restrict__ x, float* __restrict__ x_adv, float* __restrict__ x_adv_old,
+                    const float* __restrict__ grad, const float* __restrict__ step, float a, float one_minus_a,
+                    float eps, size_t n_per) {
+    __shared__ float red[16];
+    const size_t base = (size_t)blockIdx.x * n_per;
+    const float* xs = x + base;
+    const float* gs = grad + base;
+    float* xa = x_adv + base;
+    float* xo = x_adv_old + base;
+    const float st = step[blockIdx.x];
+    float acc = 0.0f;
+    for (size_t i = threadIdx.x; i < n_per; i += 1024) acc = fmaf(gs[i], gs[i], acc);
+    const float gd = sqrtf(block_sum_1024(acc, red)) + 1e-12f;
+    acc = 0.0f;
+    for (size_t i = threadIdx.x; i < n_per; i += 1024) {
+        const float z = xa[i] + (st * gs[i]) / gd;
+        const float d = z - xs[i];
+        acc = fmaf(d, d, acc);
+    }
+    const float n1 = sqrtf(block_sum_1024(acc, red));
+    const float d1 = n1 + 1e-12f, m1 = fminf(eps, n1);
+    acc = 0.0f;
+    for (size_t i = threadIdx.x; i < n_per; i += 1024) {
+        const float xv = xs[i], av = xa[i];
+        float z = av + (st * gs[i]) / gd;
+        z = clamp01(xv + (z - xv) / d1 * m1);
+        const float g2 = av - xo[i];
+        const float u = (av + (z - av) * a) + g2 * one_minus_a;
+        xo[i] = av;
+        xa[i] = u;                                        // finished in the last pass
+        const float d = u - xv;
+        acc = fmaf(d, d, acc);
+    }
+    const float n2 = sqrtf(block_sum_1024(acc, red));
+    const float d2 = n2 + 1e-12f, m2 = fminf(eps, n2);
+    for (size_t i = threadIdx.x; i < n_per; i += 1024) {
+        const float xv = xs[i];
+        xa[i] = clamp01(xv + (xa[i] - xv) / d2 * m2);
+    }
+}
+
 // one block row per sample chunk: blockIdx.y = sample
 __global__ void __launch_bounds__(256)
 apgd_linf_step_kernel(const float* __restrict__ x, float* __restrict__ x_adv,
@@ -358,6 +408,16 @@ extern "C" int rvlm_apgd_linf_step(const float* x, float* x_adv, float* x_adv_ol
     float oma = (float)(1.0 - (double)a);
     hipLaunchKernelGGL(apgd_linf_step_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, x,
                        x_adv, x_adv_old, grad, step, a, oma, eps, n_per_sample);
+    RVLM_CHECK_LAUNCH();
+    return RVLM_OK;
+}
+
+extern "C" int rvlm_apgd_l2_step(const float* x, float* x_adv, float* x_adv_old, const float* grad, const float* step,
+                                 float a, float eps, size_t n_per_sample, int B, rvlm_stream_t stream) {
+    RVLM_REQUIRE(x && x_adv && x_adv_old && grad && step && B > 0 && n_per_sample > 0, "rvlm_apgd_l2_step: bad args");
+    const float oma = (float)(1.0 - (double)a);
+    hipLaunchKernelGGL(apgd_l2_step_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, x, x_adv, x_adv_old, grad, step,
+                       a, oma, eps, n_per_sample);
     RVLM_CHECK_LAUNCH();
     return RVLM_OK;
 }

@@ -1058,11 +1058,12 @@ extern "C" int rvlm_pgd_run(rvlm_vit* h, const float* x, const float* delta0, in
                              loss_trace, flags, stream);
 }
 
-extern "C" int rvlm_apgd_run(rvlm_vit* h, const float* x, const float* x_init, int B,
-                             const rvlm_loss_spec* loss, float eps, int n_iter, float step0,
-                             int train_variant, int logits_from_head, float* x_best_adv, float* x_best_out,
-                             float* loss_best_out, uint8_t* acc_out, rvlm_stream_t stream) {
+extern "C" int rvlm_apgd_run_norm(rvlm_vit* h, const float* x, const float* x_init, int B,
+                                  const rvlm_loss_spec* loss, int norm_kind, float eps, int n_iter, float step0,
+                                  int train_variant, int logits_from_head, float* x_best_adv, float* x_best_out,
+                                  float* loss_best_out, uint8_t* acc_out, rvlm_stream_t stream) {
     RVLM_REQUIRE(h && x && loss && loss->ref && loss->targets, "rvlm_apgd_run: null argument");
+    if (norm_kind != 0 && norm_kind != 2) return fail(RVLM_ERR_UNSUPPORTED, "rvlm_apgd_run: norm must be L-inf (0) or L2 (2)");
     RVLM_REQUIRE(x_best_adv, "rvlm_apgd_run: x_best_adv output required");
     RVLM_REQUIRE(B > 1 && B <= h->maxB, "rvlm_apgd_run: need 1 < B <= max_batch");
     RVLM_REQUIRE(n_iter >= 1 && n_iter <= 1024, "rvlm_apgd_run: n_iter must be in 1..1024");
@@ -1104,7 +1105,9 @@ extern "C" int rvlm_apgd_run(rvlm_vit* h, const float* x, const float* x_init, i
         const float a = i > 0 ? 0.75f : 1.0f;
         {
             PROF("linf_update", 0, (double)n * 24);
-            if ((rc = rvlm_apgd_linf_step(x, x_adv, x_adv_old, grad, h->ap_step, a, eps, npix, B, s))) return rc;
+            rc = norm_kind == 2 ? rvlm_apgd_l2_step(x, x_adv, x_adv_old, grad, h->ap_step, a, eps, npix, B, s)
+                                : rvlm_apgd_linf_step(x, x_adv, x_adv_old, grad, h->ap_step, a, eps, npix, B, s);
+            if (rc) return rc;
         }
         const bool need_grad = !(train_variant && i == n_iter - 1);   // apgd_train.py:293-295
         if ((rc = eval(need_grad))) return rc;
@@ -1124,6 +1127,14 @@ extern "C" int rvlm_apgd_run(rvlm_vit* h, const float* x, const float* x_init, i
     if (loss_best_out) RVLM_HIP(hipMemcpyAsync(loss_best_out, h->ap_loss_best, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
     if (acc_out) RVLM_HIP(hipMemcpyAsync(acc_out, h->ap_acc, (size_t)B, hipMemcpyDeviceToDevice, s));
     return RVLM_OK;
+}
+
+extern "C" int rvlm_apgd_run(rvlm_vit* h, const float* x, const float* x_init, int B,
+                             const rvlm_loss_spec* loss, float eps, int n_iter, float step0,
+                             int train_variant, int logits_from_head, float* x_best_adv, float* x_best_out,
+                             float* loss_best_out, uint8_t* acc_out, rvlm_stream_t stream) {
+    return rvlm_apgd_run_norm(h, x, x_init, B, loss, 0, eps, n_iter, step0, train_variant, logits_from_head, x_best_adv,
+                              x_best_out, loss_best_out, acc_out, stream);
 }
 
 extern "C" int rvlm_vit_set_profiling(rvlm_vit* h, int enabled) {

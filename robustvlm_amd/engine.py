@@ -239,7 +239,7 @@ class VitEngine:
         return out, flags, trace
 
     def apgd_run(self, x, x_init, loss_kind, ref, targets, output_normalize, eps, n_iter, step0,
-                 train_variant, logits_from_head, logit_scale=100.0, want_extra=False, y_target=None):
+                 train_variant, logits_from_head, logit_scale=100.0, want_extra=False, y_target=None, norm_kind=0):
         """Whole APGD Linf loop on the device (rvlm_apgd_run).  loss_kind: 'l2' | 'ce' | 'dlr' | 'dlr-targeted'
         (the DLR losses of AutoAttack need logits_from_head; 'dlr-targeted' needs y_target [B] int64)."""
         self._check_images(x)
@@ -257,10 +257,10 @@ class VitEngine:
         loss_best = torch.empty(B, dtype=torch.float32, device=x.device) if want_extra else None
         acc = torch.empty(B, dtype=torch.uint8, device=x.device) if want_extra else None
         with torch.cuda.device(x.device):
-            L.check(self.lib.rvlm_apgd_run(self._h, x.data_ptr(), L.ptr(xi), B, C.byref(ls), float(eps),
-                                           int(n_iter), float(step0), int(bool(train_variant)),
-                                           int(bool(logits_from_head)), x_best_adv.data_ptr(), L.ptr(x_best),
-                                           L.ptr(loss_best), L.ptr(acc), L.stream_ptr()), "rvlm_apgd_run")
+            L.check(self.lib.rvlm_apgd_run_norm(self._h, x.data_ptr(), L.ptr(xi), B, C.byref(ls), int(norm_kind),
+                                                float(eps), int(n_iter), float(step0), int(bool(train_variant)),
+                                                int(bool(logits_from_head)), x_best_adv.data_ptr(), L.ptr(x_best),
+                                                L.ptr(loss_best), L.ptr(acc), L.stream_ptr()), "rvlm_apgd_run")
         self.generation += 1
         return x_best_adv, x_best, loss_best, acc
 

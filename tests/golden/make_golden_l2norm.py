@@ -82,6 +82,22 @@ def main():
     with torch.no_grad():
         arrs["vit_loss_final"] = np.float32(wrap(model(xadv, False), None).item())
     arrs["vit_eps"], arrs["vit_stepsize"] = np.float64(1.0), np.float64(0.25)
+    # apgd_train(norm='l2') on the same model: FARE (l2 loss, reduction none) and TeCoA (ce), 10 iterations, plus a
+    # 25-iteration run whose checkpoints halve step sizes
+    yt, T = torch.from_numpy(z["y"]), torch.from_numpy(z["T"])
+    with torch.no_grad():
+        # the frozen model_orig differs from the model under attack once training has started (a FARE attack from the
+        # clean image against the model's own embedding has zero loss and zero gradient): emulate with a shifted target
+        noise = torch.randn(xt.shape, generator=torch.Generator().manual_seed(77)) * 0.05
+        e0n = model((xt + noise).clamp(0, 1), True)
+    arrs["apgd_e0"] = e0n.numpy()
+    for loss_name in ("l2", "ce"):
+        wrapn = REFL["ComputeLossWrapper"](e0n, T, "none", loss_name, 100.)
+        for n_iter in (10, 25):
+            xa = MG.ref_apgd_train(model, xt, yt, "l2", 1.0, n_iter=n_iter, loss_fn=wrapn)
+            arrs[f"apgd_{loss_name}_{n_iter}_xadv"] = xa.numpy()
+            with torch.no_grad():
+                arrs[f"apgd_{loss_name}_{n_iter}_loss_final"] = wrapn(model(xa, True), yt).numpy()
     MG.save("pgd_l2norm.npz", **arrs)
 
 

@@ -309,3 +309,59 @@ def test_pgd_l2norm_fused_and_generic_vs_reference_golden():
     lf = float(wrap(model(fused, False), None))
     assert abs(lf - float(g["vit_loss_final"])) <= 1e-3 * abs(float(g["vit_loss_final"]))
     eng.close()
+
+
+def test_apgd_l2_step_kernel_vs_oracle():
+    """One APGD L2 step (apgd_train.py:231-254) on random data with mixed per-sample step sizes, first step (a = 1) and a
+    later one (a = 0.75), against the oracle's torch restatement; tolerance = fp32 rounding of the three norms."""
+    from oracle import attacks_ref as A
+    l = lib()
+    rng = np.random.default_rng(5)
+    B, shape = 6, (6, 3, 16, 16)
+    x = rng.random(shape, dtype=F32)
+    x_adv = np.clip(x + rng.normal(0, 0.02, shape).astype(F32), 0, 1).astype(F32)
+    x_old = np.clip(x + rng.normal(0, 0.02, shape).astype(F32), 0, 1).astype(F32)
+    grad = rng.standard_normal(shape).astype(F32)
+    grad[3] = 0.0                                               # zero gradient: the 1e-12 guards
+    step = np.array([1.0, 0.5, 0.25, 2.0, 0.125, 1.0], dtype=F32)
+    eps = 0.5
+    for a in (1.0, 0.75):
+        want, want_old = A.apgd_l2_step_ref(x, x_adv, x_old, grad, step.reshape(B, 1, 1, 1), a, eps)
+        dx, da, do, dg, ds = _cu(x), _cu(x_adv), _cu(x_old), _cu(grad), _cu(step)
+        L.check(l.rvlm_apgd_l2_step(dx.data_ptr(), da.data_ptr(), do.data_ptr(), dg.data_ptr(), ds.data_ptr(), a, eps,
+                                    x[0].size, B, st()))
+        torch.cuda.synchronize()
+        assert np.abs(da.cpu().numpy() - want).max() < 2e-6
+        assert np.array_equal(do.cpu().numpy(), want_old)
+        assert float((da - dx).flatten(1).norm(dim=1).max()) <= eps * (1 + 1e-5)
+
+
+@pytest.mark.parametrize("loss_name", ["l2", "ce"])
+def test_apgd_train_l2norm_fused_and_generic_vs_reference_golden(loss_name):
+    """apgd_train(norm='l2') through rvlm_apgd_run_norm (fused) and through autograd + rvlm_apgd_l2_step (generic) on the
+    fp32 engine against the reference's x_best_adv on the same tiny ViT."""
+    from tests.helpers import cfg_from_array, weights_from_golden
+    zt = load_golden("tiny_vit_attacks.npz")
+    g = load_golden("pgd_l2norm.npz")
+    cfg = cfg_from_array(zt["cfg"])
+    w = weights_from_golden(zt)
+    eng = R.VitEngine(R.VitConfig(cfg.image_size, cfg.patch, cfg.width, cfg.layers, cfg.heads, cfg.out_dim, cfg.act),
+                      {k: v.to(dev()) for k, v in w.items()}, precision="fp32", max_batch=8)
+    model = R.ClipVisionModel(eng).eval()
+    x, y, T, e0 = _cu(zt["x"]), _cu(zt["y"]), _cu(zt["T"]), _cu(g["apgd_e0"])
+    wrap = R.ComputeLossWrapper(e0, T, "none", loss_name, 100.)
+    fused = R.apgd_train(model, x, y, "l2", 1.0, n_iter=10, loss_fn=wrap)
+
+    class Plain(torch.nn.Module):          # not a ClipVisionModel: takes the generic route
+        def forward(self, v, output_normalize=True):
+            return model(v, output_normalize)
+    generic = R.apgd_train(Plain().eval(), x, y, "l2", 1.0, n_iter=10, loss_fn=wrap)
+    want = g[f"apgd_{loss_name}_10_xadv"]
+    for name, got in (("fused", fused), ("generic", generic)):
+        diff = np.abs(got.cpu().numpy() - want).max()
+        assert diff < 2e-4, (name, diff)
+        assert float((got - x).flatten(1).norm(dim=1).max()) <= 1.0 + 1e-5
+    with torch.no_grad():
+        lf = wrap(model(fused, True), y).cpu().numpy()
+    np.testing.assert_allclose(lf, g[f"apgd_{loss_name}_10_loss_final"], rtol=2e-3, atol=1e-6)
+    eng.close()

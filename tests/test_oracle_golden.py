@@ -290,3 +290,17 @@ def test_pgd_l2norm_tiny_vit_bit_exact():
     out = A.pgd_ref(model, wrap, x, None, "l2", float(g["vit_eps"]), 10, float(g["vit_stepsize"]), False,
                     perturbation=torch.from_numpy(z["delta0"].copy()), mode="max")
     assert np.array_equal(out.numpy(), g["vit_xadv"])
+
+
+@pytest.mark.parametrize("loss_name,n_iter", [("l2", 10), ("l2", 25), ("ce", 10), ("ce", 25)])
+def test_apgd_train_l2norm_tiny_vit_bit_exact(loss_name, n_iter):
+    """apgd_train(norm='l2') (train/apgd_train.py:231-254) with FARE / TeCoA losses: the oracle's L2 step + the shared
+    controller against the reference's x_best_adv, 10 iterations and 25 (several step-size checkpoints)."""
+    z, cfg, w = _tiny()
+    g = load_golden("pgd_l2norm.npz")
+    model = V.ClipVisionModelRef(cfg, w).eval()
+    x, y, T = (torch.from_numpy(z[k]) for k in ("x", "y", "T"))
+    wrap = Lr.ComputeLossWrapperRef(torch.from_numpy(g["apgd_e0"]), T, "none", loss_name, 100.)
+    out = A.apgd_train_ref(model, x, y, "l2", 1.0, n_iter=n_iter, loss_fn=wrap)
+    assert np.array_equal(out.numpy(), g[f"apgd_{loss_name}_{n_iter}_xadv"])
+    assert float((out - x).flatten(1).norm(dim=1).max()) <= 1.0 + 1e-5
