@@ -186,6 +186,12 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
         n0 = __builtin_amdgcn_readfirstlane(((t % group_size) / gm) * P_N);
     };
     const int nk = p.K / P_K;
+    // experiment (RVLM_GEMM_KROT): the workgroups of an XCD walk K from different start offsets, so that at any moment
+    // their operand requests fall on different k-columns of the panels they share (the sum order of a tile rotates with it)
+    int k0 = 0;
+    if (p.krot > 0) k0 = (((int)blockIdx.x >> 3) % p.krot) * (nk >= p.krot ? nk / p.krot : 1) % nk;
+    else if (p.krot < 0) k0 = (((int)blockIdx.x >> 3) % (-p.krot)) % nk;
+    k0 = __builtin_amdgcn_readfirstlane(k0);
     const int ntw = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // tiles of this workgroup
 
     // ---- operand streams.  Stage g (global K-step counter over all tiles of this workgroup) has its A half in A
@@ -223,7 +229,7 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
             for (int j = 0; j < 4; ++j) {
                 sink ^= pendA[j];
                 pendA[j] = __builtin_amdgcn_raw_buffer_load_b128(
-                    a_rs, a_loff[j & 1], __builtin_amdgcn_readfirstlane(a_soff + a_kt * (P_K * 2) + j * 16 * lda), 0);
+                    a_rs, a_loff[j & 1], __builtin_amdgcn_readfirstlane(a_soff + (a_kt + k0 >= nk ? a_kt + k0 - nk : a_kt + k0) * (P_K * 2) + j * 16 * lda), 0);
             }
         } else if (!(ABL & 1)) {
             __attribute__((address_space(3))) char* dst =
@@ -232,7 +238,7 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
             for (int j = 0; j < 4; ++j)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(
                     a_rs, (lds_ptr_t)(dst + j * 1024), 16, a_loff[j & 1],
-                    __builtin_amdgcn_readfirstlane(a_soff + a_kt * (P_K * 2) + j * 16 * lda), 0, 0);
+                    __builtin_amdgcn_readfirstlane(a_soff + (a_kt + k0 >= nk ? a_kt + k0 - nk : a_kt + k0) * (P_K * 2) + j * 16 * lda), 0, 0);
         }
         a_slot = (a_slot == 2) ? 0 : a_slot + 1;
         if (++a_kt == nk) {
@@ -252,7 +258,7 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
             for (int j = 0; j < 4; ++j) {
                 sink ^= pendB[j];
                 pendB[j] = __builtin_amdgcn_raw_buffer_load_b128(
-                    b_rs, b_loff[j & 1], __builtin_amdgcn_readfirstlane(b_soff + b_kt * (P_K * 2) + j * 16 * ldb), 0);
+                    b_rs, b_loff[j & 1], __builtin_amdgcn_readfirstlane(b_soff + (b_kt + k0 >= nk ? b_kt + k0 - nk : b_kt + k0) * (P_K * 2) + j * 16 * ldb), 0);
             }
         } else if (!(ABL & 1)) {
             __attribute__((address_space(3))) char* dst =
@@ -261,7 +267,7 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
             for (int j = 0; j < 4; ++j)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(
                     b_rs, (lds_ptr_t)(dst + j * 1024), 16, b_loff[j & 1],
-                    __builtin_amdgcn_readfirstlane(b_soff + b_kt * (P_K * 2) + j * 16 * ldb), 0, 0);
+                    __builtin_amdgcn_readfirstlane(b_soff + (b_kt + k0 >= nk ? b_kt + k0 - nk : b_kt + k0) * (P_K * 2) + j * 16 * ldb), 0, 0);
         }
         b_slot ^= 1;
         if (++b_kt == nk) {
@@ -637,7 +643,9 @@ int gemm_bf16_nt_256p(const GemmBf16& p, int* rows_done, hipStream_t s) {
     static int group_m = -1, wave_prio = -1;
     if (group_m < 0) { const char* e = getenv("RVLM_GEMM_GROUP_M"); group_m = e ? std::max(1, atoi(e)) : 8; }
     if (wave_prio < 0) { const char* e = getenv("RVLM_GEMM_PRIO"); wave_prio = e ? atoi(e) : 0; }
-    q.group_m = group_m; q.wave_prio = wave_prio;
+    static int krot = -999;
+    if (krot == -999) { const char* e = getenv("RVLM_GEMM_KROT"); krot = e ? atoi(e) : 0; }
+    q.group_m = group_m; q.wave_prio = wave_prio; q.krot = krot;
     const bool tail = tail_on && g_persist_ablate == 0 && p.batch_m_rows == 0 && p.M > q.M;
     const int m_total = tail ? p.M : q.M;
     int rc;

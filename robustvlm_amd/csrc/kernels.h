@@ -55,6 +55,7 @@ struct GemmBf16 {
     int stagger = 0;                    // persistent kernel only: odd workgroup groups start stagger x ~4 us late
     int group_m = 8;                    // persistent kernel only: m-tiles per tile-order group (RVLM_GEMM_GROUP_M experiment)
     int wave_prio = 0;                  // persistent kernel only: s_setprio for waves 4-7 (RVLM_GEMM_PRIO experiment)
+    int krot = 0;                       // persistent kernel only: K-step rotation per workgroup (RVLM_GEMM_KROT experiment)
     int batch_m_rows = 0;               // persistent kernel only, > 0: batched form - rows [b*batch_m_rows, ...) of A meet
                                         // rows [b*N, (b+1)*N) of Bw (the split-K weight-gradient GEMM, gemm_bf16_wgrad)
 };
