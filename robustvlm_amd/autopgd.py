@@ -96,10 +96,20 @@ class APGDAttack():
         step0 = alpha * self.eps
         m = self.model
         if isinstance(m, ClassificationModel) and x.shape[0] > 1 and m.logit_scale and m._identity_resizer:
-            x_best_adv, x_best, loss_best, acc = m.model.apgd_run(
-                x, start, self.loss, m.text_embedding, y, True, self.eps, self.n_iter, step0,
-                train_variant=False, logits_from_head=True, logit_scale=m.logit_scale_value, want_extra=True,
-                y_target=self.y_target if self.loss == 'dlr-targeted' else None)
+            # every quantity of the attack is per sample: batches beyond the engine's workspace (AutoAttack's bs = 250 on
+            # a max_batch = 128 engine) run as chunks of the device loop (chunks of >= 2 images: the losses need batch > 1)
+            B, mb = x.shape[0], m.model.max_batch
+            bounds = list(range(0, B, mb)) + [B]
+            if len(bounds) > 2 and bounds[-1] - bounds[-2] < 2:
+                bounds[-2] -= 1
+            yt = self.y_target if self.loss == 'dlr-targeted' else None
+            parts = []
+            for lo, hi in zip(bounds[:-1], bounds[1:]):
+                parts.append(m.model.apgd_run(
+                    x[lo:hi], None if start is None else start[lo:hi], self.loss, m.text_embedding, y[lo:hi], True,
+                    self.eps, self.n_iter, step0, train_variant=False, logits_from_head=True,
+                    logit_scale=m.logit_scale_value, want_extra=True, y_target=None if yt is None else yt[lo:hi]))
+            x_best_adv, x_best, loss_best, acc = (torch.cat([p[i] for p in parts]) for i in range(4))
             return x_best, acc.bool(), loss_best, x_best_adv
         if self.loss == 'ce':
             crit = lambda lg, yy: ce(lg, yy, reduction='none')   # noqa: E731  (rvlm_ce_logits)

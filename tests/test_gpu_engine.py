@@ -585,3 +585,24 @@ def test_ce_and_head_kernels_vs_torch():
         parts = torch.cat([clf(big[:8]), clf(big[8:16]), clf(big[16:])])
     assert torch.equal(whole, parts)
     eng.close()
+
+
+def test_apgdattack_batches_beyond_the_engine_workspace():
+    """AutoAttack's default bs (250) exceeds a max_batch = 128 engine - the fused APGD route chunks the batch
+    (per-sample attack: chunked == unchunked, bit for bit in the fp32 mode whose GEMMs sum k in order for every row)."""
+    cfg = V.VIT_TINY2
+    w = V.init_weights(cfg, seed=9)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    T = torch.nn.functional.normalize(torch.randn(cfg.out_dim, 10, generator=g, device=dev()), dim=0)
+    x = torch.rand(11, 3, cfg.image_size, cfg.image_size, generator=g, device=dev())
+    big = make_engine(cfg, w, "fp32", max_batch=16)
+    small = make_engine(cfg, w, "fp32", max_batch=5)             # 11 images -> chunks 5, 4, 2 (never a chunk of 1)
+    outs = []
+    for eng in (big, small):
+        clf = R.ClassificationModel(eng, T).eval()
+        with torch.no_grad():
+            y = clf(x).argmax(1)
+        atk = R.APGDAttack(clf, n_iter=8, norm="Linf", n_restarts=1, eps=4 / 255, seed=0, loss="ce", device=dev())
+        outs.append(atk.perturb(x, y))
+    assert torch.equal(outs[0], outs[1])
+    big.close(); small.close()
