@@ -108,6 +108,8 @@ _SIGS = {
     "rvlm_check_image_range": (C.c_int, [c_f32p, C.c_size_t, C.c_void_p, c_stream]),
     "rvlm_pgd_linf_update": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_size_t, C.c_float,
                                        C.c_float, C.c_float, C.c_int, c_f32p, C.c_void_p, c_stream]),
+    "rvlm_project_perturbation": (C.c_int, [c_f32p, C.c_size_t, C.c_int, C.c_int, C.c_float, c_f32p, c_stream]),
+    "rvlm_normalize_grad": (C.c_int, [c_f32p, C.c_size_t, C.c_int, C.c_int, c_f32p, c_stream]),
     "rvlm_pgd_l2_update": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_size_t, C.c_int, C.c_float, C.c_float,
                                      C.c_float, C.c_int, c_f32p, C.c_void_p, c_stream]),
     "rvlm_pgd_run_norm": (C.c_int, [C.c_void_p, c_f32p, c_f32p, C.c_int, C.POINTER(LossSpecC), C.c_int, C.c_float,

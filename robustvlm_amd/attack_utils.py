@@ -1,28 +1,42 @@
-"""project_perturbation / normalize_grad (vlm_eval/attacks/utils.py:8-26) on device tensors.
-
-The Linf branches are what the fused HIP kernels implement (rvlm_pgd_linf_update); these
-tensor-level helpers keep the reference's standalone API (and its L2 branch) available."""
+"""project_perturbation / normalize_grad (vlm_eval/attacks/utils.py:8-26) on device tensors, as kernels of librvlm
+(rvlm_project_perturbation, rvlm_normalize_grad).  Inside pgd() the same arithmetic is fused into the per-iteration update
+kernels (rvlm_pgd_linf_update / rvlm_pgd_l2_update); these keep the reference's standalone API."""
 from __future__ import annotations
 
 import torch
-import torch.nn.functional as F
+
+from . import _lib as L
+from .engine import _require_cuda, _f32c
 
 LINF = ("inf", "linf", "Linf")
 L2 = (2, 2.0, "l2", "L2", "2")
 
 
-def project_perturbation(perturbation, eps, norm):
+def _norm_kind(norm):
     if norm in LINF:
-        return torch.clamp(perturbation, -eps, eps)
+        return 0
     if norm in L2:
-        return torch.renorm(perturbation, p=2, dim=0, maxnorm=eps)
-    raise NotImplementedError(f"Norm {norm} not supported")
+        return 2
+    raise NotImplementedError(f"Norm {norm} not supported")               # utils.py:16
+
+
+def project_perturbation(perturbation, eps, norm):
+    kind = _norm_kind(norm)
+    _require_cuda(perturbation, "perturbation")
+    p = _f32c(perturbation)
+    out = torch.empty_like(p)
+    with torch.cuda.device(p.device):
+        L.check(L.load().rvlm_project_perturbation(p.data_ptr(), p[0].numel(), p.shape[0], kind, float(eps), out.data_ptr(),
+                                                   L.stream_ptr()), "rvlm_project_perturbation")
+    return out
 
 
 def normalize_grad(grad, p):
-    if p in LINF:
-        return grad.sign()
-    if p in L2:
-        bs = grad.shape[0]
-        return F.normalize(grad.view(bs, -1), p=2, dim=1).view_as(grad)
-    raise NotImplementedError(f"Norm {p} not supported")
+    kind = _norm_kind(p)
+    _require_cuda(grad, "grad")
+    g = _f32c(grad)
+    out = torch.empty_like(g)
+    with torch.cuda.device(g.device):
+        L.check(L.load().rvlm_normalize_grad(g.data_ptr(), g[0].numel(), g.shape[0], kind, out.data_ptr(), L.stream_ptr()),
+                "rvlm_normalize_grad")
+    return out

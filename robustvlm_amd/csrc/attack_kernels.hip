@@ -209,6 +209,37 @@ apgd_l2_step_kernel(const float* __restrict__ x, float* __restrict__ x_adv, floa
     }
 }
 
+// ---- the standalone helpers of vlm_eval/attacks/utils.py:8-26 as device kernels (robustvlm_amd/attack_utils.py) ----
+__global__ void __launch_bounds__(256)
+ew_clamp_kernel(const float* __restrict__ x, float lo, float hi, size_t n, float* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        out[i] = (v != v) ? v : fminf(fmaxf(v, lo), hi);         // torch.clamp propagates NaN
+    }
+}
+__global__ void __launch_bounds__(256)
+ew_sign_kernel(const float* __restrict__ x, size_t n, float* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = sgnf(x[i]);                                      // sign(+-0) = 0, sign(NaN) = 0 like torch.sign
+}
+// mode 0: F.normalize(x.view(B, -1), p=2, dim=1): x / max(|x|_2, 1e-12);  mode 1: torch.renorm(x, 2, 0, maxnorm):
+// rows with |x|_2 > maxnorm scaled by maxnorm / (|x|_2 + 1e-7)
+__global__ void __launch_bounds__(1024)
+row_l2_scale_kernel(const float* __restrict__ x, size_t n_per, int mode, float maxnorm, float* __restrict__ out) {
+    __shared__ float red[16];
+    const size_t base = (size_t)blockIdx.x * n_per;
+    float acc = 0.0f;
+    for (size_t i = threadIdx.x; i < n_per; i += 1024) acc = fmaf(x[base + i], x[base + i], acc);
+    const float nrm = sqrtf(block_sum_1024(acc, red));
+    if (mode == 0) {
+        const float d = fmaxf(nrm, 1e-12f);
+        for (size_t i = threadIdx.x; i < n_per; i += 1024) out[base + i] = x[base + i] / d;
+    } else {
+        const float sc = nrm > maxnorm ? maxnorm / (nrm + 1e-7f) : 1.0f;
+        for (size_t i = threadIdx.x; i < n_per; i += 1024) out[base + i] = x[base + i] * sc;
+    }
+}
+
 // one block row per sample chunk: blockIdx.y = sample
 __global__ void __launch_bounds__(256)
 apgd_linf_step_kernel(const float* __restrict__ x, float* __restrict__ x_adv,
@@ -408,6 +439,33 @@ extern "C" int rvlm_apgd_linf_step(const float* x, float* x_adv, float* x_adv_ol
     float oma = (float)(1.0 - (double)a);
     hipLaunchKernelGGL(apgd_linf_step_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, x,
                        x_adv, x_adv_old, grad, step, a, oma, eps, n_per_sample);
+    RVLM_CHECK_LAUNCH();
+    return RVLM_OK;
+}
+
+extern "C" int rvlm_project_perturbation(const float* pert, size_t n_per_sample, int B, int norm_kind, float eps, float* out,
+                                         rvlm_stream_t stream) {
+    RVLM_REQUIRE(pert && out && B > 0 && n_per_sample > 0, "rvlm_project_perturbation: bad arguments");
+    const size_t n = n_per_sample * (size_t)B;
+    if (norm_kind == 0)
+        hipLaunchKernelGGL(ew_clamp_kernel, dim3(ew_grid(n, 1)), dim3(256), 0, (hipStream_t)stream, pert, -eps, eps, n, out);
+    else if (norm_kind == 2)
+        hipLaunchKernelGGL(row_l2_scale_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, pert, n_per_sample, 1, eps, out);
+    else
+        return fail(RVLM_ERR_UNSUPPORTED, "rvlm_project_perturbation: norm must be L-inf (0) or L2 (2)");
+    RVLM_CHECK_LAUNCH();
+    return RVLM_OK;
+}
+extern "C" int rvlm_normalize_grad(const float* grad, size_t n_per_sample, int B, int norm_kind, float* out,
+                                   rvlm_stream_t stream) {
+    RVLM_REQUIRE(grad && out && B > 0 && n_per_sample > 0, "rvlm_normalize_grad: bad arguments");
+    const size_t n = n_per_sample * (size_t)B;
+    if (norm_kind == 0)
+        hipLaunchKernelGGL(ew_sign_kernel, dim3(ew_grid(n, 1)), dim3(256), 0, (hipStream_t)stream, grad, n, out);
+    else if (norm_kind == 2)
+        hipLaunchKernelGGL(row_l2_scale_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, grad, n_per_sample, 0, 0.0f, out);
+    else
+        return fail(RVLM_ERR_UNSUPPORTED, "rvlm_normalize_grad: norm must be L-inf (0) or L2 (2)");
     RVLM_CHECK_LAUNCH();
     return RVLM_OK;
 }

@@ -365,3 +365,30 @@ def test_apgd_train_l2norm_fused_and_generic_vs_reference_golden(loss_name):
         lf = wrap(model(fused, True), y).cpu().numpy()
     np.testing.assert_allclose(lf, g[f"apgd_{loss_name}_10_loss_final"], rtol=2e-3, atol=1e-6)
     eng.close()
+
+
+def test_standalone_attack_utils_vs_torch():
+    """robustvlm_amd.project_perturbation / normalize_grad (vlm_eval/attacks/utils.py:8-26) are device kernels of librvlm:
+    L-inf branches bit-equal to torch.clamp / torch.sign (NaN, signed zeros), L2 branches equal to torch.renorm /
+    F.normalize to fp32 rounding of the per-sample norm."""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    t = torch.randn(5, 3, 16, 16, generator=g, device=dev())
+    t.view(-1)[::17] = 0.0
+    t.view(-1)[5::29] = -0.0
+    t.view(-1)[7::31] = float("nan")
+    eps = 0.3
+    assert torch.equal(R.normalize_grad(t, "linf"), t.sign())
+    got, want = R.project_perturbation(t, eps, "linf"), torch.clamp(t, -eps, eps)
+    assert torch.equal(torch.nan_to_num(got, nan=7.0), torch.nan_to_num(want, nan=7.0))
+    u = torch.randn(5, 3, 16, 16, generator=g, device=dev())
+    u[1] *= 0.001                                          # inside the ball: untouched by renorm
+    u[2] = 0.0                                             # zero row: F.normalize's eps path
+    for name, got, want in (("normalize", R.normalize_grad(u, "l2"),
+                             torch.nn.functional.normalize(u.view(5, -1), p=2, dim=1).view_as(u)),
+                            ("renorm", R.project_perturbation(u, eps, 2), torch.renorm(u, p=2, dim=0, maxnorm=eps))):
+        assert float((got - want).abs().max()) <= 2e-6 * float(want.abs().max() + 1e-30) + 1e-9, name
+    assert torch.equal(R.project_perturbation(u, eps, "l2")[1], u[1])
+    with pytest.raises(NotImplementedError):
+        R.normalize_grad(u, "l1")
+    with pytest.raises(L.RvlmError):
+        R.project_perturbation(u.cpu(), eps, "linf")
