@@ -533,7 +533,7 @@ def test_fwd_inputgrad_single_call_equals_the_three_calls(loss_name):
     ref_t = (T if on else e0).to(dev())
     emb, per, scalar, gx = eng.fwd_inputgrad(x.to(dev()), d.to(dev()), loss_name, "mean", ref_t, y.to(dev()), on)
     assert rel_max(emb.cpu(), er.detach()) < 1e-4
-    assert abs(float(scalar) - float(lr)) <= 1e-4 * abs(float(lr)) + 1e-7
+    assert abs(float(scalar) - float(lr.detach())) <= 1e-4 * abs(float(lr.detach())) + 1e-7
     assert rel_max(gx.cpu(), gr) < 2e-3
     # the three-call route through autograd
     dd = d.to(dev()).requires_grad_(True)
