@@ -21,8 +21,88 @@ __global__ void probe_tr16_kernel(const bf16_t* __restrict__ src, const int32_t*
         (__attribute__((address_space(3))) bf16x4*)((__attribute__((address_space(3))) char*)tile + offs[lane]));
     for (int j = 0; j < 4; ++j) out[lane * 4 + j] = v[j];
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Operand-stream probe (measurement only, no product path uses it): the persistent GEMM's global-memory request
+// stream - 256 workgroups x 8 waves, tile -> workgroup order of gemm_bf16_nt_256p_kernel, per K-step every wave
+// fetches 4 + 4 pieces of 8 rows x 128 B of its A and B tiles - with NO MFMA and NO LDS, loaded straight into
+// registers, DEPTH K-steps (DEPTH x 64 KiB per CU) in flight.  Answers one question: does L2 -> CU delivery per
+// clock grow with more bytes in flight than the GEMM's 160 KiB LDS ring can hold (<= 96 KiB)?
+// ---------------------------------------------------------------------------------------------------------------
+typedef unsigned u32x4p __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4p gload16(const char* sbase, unsigned voff) {
+    u32x4p r;
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
+    return r;
+}
+template <int DEPTH>
+__global__ void __launch_bounds__(512)
+probe_stream_kernel(const char* __restrict__ A, const char* __restrict__ Bw, long ld_bytes, int tiles_m, int tiles_n,
+                    int nk, unsigned* __restrict__ out) {
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ntiles = tiles_m * tiles_n;
+    unsigned voff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) voff[j] = (unsigned)((w * 32 + j * 8 + (lane >> 3)) * ld_bytes + (lane & 7) * 16);
+    u32x4p P[DEPTH][8], sink = {0u, 0u, 0u, 0u};
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = tile & 7, loc = tile >> 3;
+        const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+        const int group_size = 8 * tiles_n, first_m = (t / group_size) * 8, gm = min(tiles_m - first_m, 8);
+        const long m0 = (long)(first_m + (t % group_size) % gm) * 256, n0 = (long)((t % group_size) / gm) * 256;
+        const char* a = A + m0 * ld_bytes;
+        const char* b = Bw + n0 * ld_bytes;
+        // prologue: DEPTH K-steps in flight
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                P[d][j] = gload16(a + (long)d * 128, voff[j]);
+                P[d][4 + j] = gload16(b + (long)d * 128, voff[j]);
+            }
+        for (int kt = DEPTH; kt < nk + DEPTH; kt += DEPTH) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                // the oldest generation has landed when at most 8 * (DEPTH - 1) younger loads are outstanding
+                if (DEPTH == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (DEPTH == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (DEPTH == 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sink ^= P[d][j];
+                const int k = kt + d;
+                if (k < nk) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        P[d][j] = gload16(a + (long)k * 128, voff[j]);
+                        P[d][4 + j] = gload16(b + (long)k * 128, voff[j]);
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (sink.x == 0x12345678u && sink.y == 0x9abcdef0u) out[threadIdx.x] = sink.z ^ sink.w;
+}
 }  // namespace rvlm
 using namespace rvlm;
+
+extern "C" int rvlm_k_probe_operand_stream(const uint16_t* A, const uint16_t* Bw, int M, int N, int K, int depth,
+                                           uint32_t* out, rvlm_stream_t stream) {
+    if (M % 256 || N % 256 || K % 64 || depth < 1 || depth > 4 || (K / 64) % depth)
+        return fail(RVLM_ERR_ARG, "rvlm_k_probe_operand_stream: M, N % 256, K % (64 * depth), depth 1..4");
+    const int tm = M / 256, tn = N / 256, nk = K / 64, grid = std::min(tm * tn, 256);
+    const long ldb = (long)K * 2;
+    hipStream_t s = (hipStream_t)stream;
+    switch (depth) {
+        case 1: hipLaunchKernelGGL((probe_stream_kernel<1>), dim3(grid), dim3(512), 0, s, (const char*)A, (const char*)Bw, ldb, tm, tn, nk, out); break;
+        case 2: hipLaunchKernelGGL((probe_stream_kernel<2>), dim3(grid), dim3(512), 0, s, (const char*)A, (const char*)Bw, ldb, tm, tn, nk, out); break;
+        case 3: hipLaunchKernelGGL((probe_stream_kernel<3>), dim3(grid), dim3(512), 0, s, (const char*)A, (const char*)Bw, ldb, tm, tn, nk, out); break;
+        default: hipLaunchKernelGGL((probe_stream_kernel<4>), dim3(grid), dim3(512), 0, s, (const char*)A, (const char*)Bw, ldb, tm, tn, nk, out); break;
+    }
+    RVLM_CHECK_LAUNCH();
+    return RVLM_OK;
+}
 
 extern "C" int rvlm_k_gemm_bf16_nt(const uint16_t* A, long lda, const uint16_t* Bw, long ldb, int M, int N,
                                    int K, int a_rows, int epi, const float* bias, void* out, long ldo,
