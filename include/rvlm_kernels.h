@@ -49,10 +49,11 @@ int rvlm_k_gemm_set_trace(void* ptr);
 int rvlm_k_gemm_set_ablate(int v);
 /* measurement only: the persistent GEMM's operand request stream (same tile order, 8 waves x (4 + 4) pieces of 8 rows x
  * 128 B per K-step) with no MFMA and no LDS, `depth` K-steps (depth x 64 KiB per CU) in flight in registers.
- * A [M, K], Bw [N, K] bf16 row-major; M, N % 256 == 0, K % (64 * depth) == 0; `out` >= 512 words (never written in
- * practice). */
-int rvlm_k_probe_operand_stream(const uint16_t* A, const uint16_t* Bw, int M, int N, int K, int depth, uint32_t* out,
-                                rvlm_stream_t stream);
+ * mode bit 0: one s_barrier per K-step (a wave waits for the slowest wave's pieces, like a GEMM K-step); bit 1: pieces by
+ * LDS-DMA into LDS instead of into registers (depth <= 2).  A [M, K], Bw [N, K] bf16 row-major; M, N % 256 == 0,
+ * K % 64 == 0; `out` >= 512 words (never written in practice). */
+int rvlm_k_probe_operand_stream(const uint16_t* A, const uint16_t* Bw, int M, int N, int K, int depth, int mode,
+                                uint32_t* out, rvlm_stream_t stream);
 /* workgroups per CU reported by the runtime for attn fwd (96-VGPR build), attn fwd (default), attn dq */
 int rvlm_k_attn_occupancy(int S, int* out3);
 int rvlm_k_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y,

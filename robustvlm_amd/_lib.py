@@ -158,8 +158,8 @@ _SIGS = {
     "rvlm_k_gemm_last_kernels": (C.c_int, []),
     "rvlm_k_gemm_set_trace": (C.c_int, [C.c_void_p]),
     "rvlm_k_gemm_set_ablate": (C.c_int, [C.c_int]),
-    "rvlm_k_probe_operand_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
-                                              c_stream]),
+    "rvlm_k_probe_operand_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                              C.c_void_p, c_stream]),
     "rvlm_k_attn_occupancy": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
     "rvlm_k_layernorm_fwd_f32": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int,
                                            C.c_int, c_stream]),

@@ -35,16 +35,35 @@ __device__ __forceinline__ u32x4p gload16(const char* sbase, unsigned voff) {
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
     return r;
 }
-template <int DEPTH>
+// MODE bit 0: one s_barrier per K-step (every wave then waits for the slowest wave's pieces, as a GEMM K-step does);
+// MODE bit 1: the pieces go to LDS by LDS-DMA (global_load_lds_dwordx4) instead of to registers (DEPTH <= 2: 64 KiB each)
+template <int DEPTH, int MODE>
 __global__ void __launch_bounds__(512)
 probe_stream_kernel(const char* __restrict__ A, const char* __restrict__ Bw, long ld_bytes, int tiles_m, int tiles_n,
                     int nk, unsigned* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(1024))) char plds[];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ntiles = tiles_m * tiles_n;
+    constexpr bool DMA = (MODE & 2) != 0;
     unsigned voff[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) voff[j] = (unsigned)((w * 32 + j * 8 + (lane >> 3)) * ld_bytes + (lane & 7) * 16);
-    u32x4p P[DEPTH][8], sink = {0u, 0u, 0u, 0u};
+    u32x4p P[DMA ? 1 : DEPTH][8], sink = {0u, 0u, 0u, 0u};
+    auto fetch = [&](int d, const char* a, const char* b, int k) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (DMA) {
+                char* dst = plds + d * 65536 + w * 8192 + j * 1024;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a + (long)k * 128 + voff[j]),
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b + (long)k * 128 + voff[j]),
+                                                 (__attribute__((address_space(3))) void*)(dst + 4096), 16, 0, 0);
+            } else {
+                P[d][j] = gload16(a + (long)k * 128, voff[j]);
+                P[d][4 + j] = gload16(b + (long)k * 128, voff[j]);
+            }
+        }
+    };
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = tile & 7, loc = tile >> 3;
         const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
@@ -52,32 +71,23 @@ probe_stream_kernel(const char* __restrict__ A, const char* __restrict__ Bw, lon
         const long m0 = (long)(first_m + (t % group_size) % gm) * 256, n0 = (long)((t % group_size) / gm) * 256;
         const char* a = A + m0 * ld_bytes;
         const char* b = Bw + n0 * ld_bytes;
-        // prologue: DEPTH K-steps in flight
 #pragma unroll
-        for (int d = 0; d < DEPTH; ++d)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                P[d][j] = gload16(a + (long)d * 128, voff[j]);
-                P[d][4 + j] = gload16(b + (long)d * 128, voff[j]);
-            }
+        for (int d = 0; d < DEPTH; ++d) fetch(d, a, b, d);            // prologue: DEPTH K-steps in flight
         for (int kt = DEPTH; kt < nk + DEPTH; kt += DEPTH) {
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d) {
-                // the oldest generation has landed when at most 8 * (DEPTH - 1) younger loads are outstanding
+                // the oldest generation has landed when at most 8 * (DEPTH - 1) younger pieces are outstanding
                 if (DEPTH == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 else if (DEPTH == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                 else if (DEPTH == 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+                if (MODE & 1) __builtin_amdgcn_s_barrier();
+                if (!DMA) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) sink ^= P[d][j];
-                const int k = kt + d;
-                if (k < nk) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        P[d][j] = gload16(a + (long)k * 128, voff[j]);
-                        P[d][4 + j] = gload16(b + (long)k * 128, voff[j]);
-                    }
+                    for (int j = 0; j < 8; ++j) sink ^= P[d][j];
                 }
+                const int k = kt + d;
+                if (k < nk) fetch(d, a, b, k);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -87,19 +97,28 @@ probe_stream_kernel(const char* __restrict__ A, const char* __restrict__ Bw, lon
 }  // namespace rvlm
 using namespace rvlm;
 
-extern "C" int rvlm_k_probe_operand_stream(const uint16_t* A, const uint16_t* Bw, int M, int N, int K, int depth,
+extern "C" int rvlm_k_probe_operand_stream(const uint16_t* A, const uint16_t* Bw, int M, int N, int K, int depth, int mode,
                                            uint32_t* out, rvlm_stream_t stream) {
-    if (M % 256 || N % 256 || K % 64 || depth < 1 || depth > 4 || (K / 64) % depth)
-        return fail(RVLM_ERR_ARG, "rvlm_k_probe_operand_stream: M, N % 256, K % (64 * depth), depth 1..4");
+    if (M % 256 || N % 256 || K % 64 || depth < 1 || depth > 4 || K / 64 < depth || mode < 0 || mode > 3 ||
+        ((mode & 2) && depth > 2))
+        return fail(RVLM_ERR_ARG, "rvlm_k_probe_operand_stream: M, N % 256, K % 64, depth 1..4 (<= 2 with LDS-DMA), mode 0..3");
     const int tm = M / 256, tn = N / 256, nk = K / 64, grid = std::min(tm * tn, 256);
     const long ldb = (long)K * 2;
     hipStream_t s = (hipStream_t)stream;
-    switch (depth) {
-        case 1: hipLaunchKernelGGL((probe_stream_kernel<1>), dim3(grid), dim3(512), 0, s, (const char*)A, (const char*)Bw, ldb, tm, tn, nk, out); break;
-        case 2: hipLaunchKernelGGL((probe_stream_kernel<2>), dim3(grid), dim3(512), 0, s, (const char*)A, (const char*)Bw, ldb, tm, tn, nk, out); break;
-        case 3: hipLaunchKernelGGL((probe_stream_kernel<3>), dim3(grid), dim3(512), 0, s, (const char*)A, (const char*)Bw, ldb, tm, tn, nk, out); break;
-        default: hipLaunchKernelGGL((probe_stream_kernel<4>), dim3(grid), dim3(512), 0, s, (const char*)A, (const char*)Bw, ldb, tm, tn, nk, out); break;
+    const size_t lds = (mode & 2) ? (size_t)depth * 65536 : 0;
+#define PROBE(D, MD)                                                                                                  \
+    do {                                                                                                               \
+        if (lds) (void)hipFuncSetAttribute((const void*)probe_stream_kernel<D, MD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((probe_stream_kernel<D, MD>), dim3(grid), dim3(512), lds, s, (const char*)A, (const char*)Bw, ldb, tm, tn, nk, out); \
+    } while (0)
+    switch (depth * 4 + mode) {
+        case 4: PROBE(1, 0); break;  case 5: PROBE(1, 1); break;  case 6: PROBE(1, 2); break;  case 7: PROBE(1, 3); break;
+        case 8: PROBE(2, 0); break;  case 9: PROBE(2, 1); break;  case 10: PROBE(2, 2); break; case 11: PROBE(2, 3); break;
+        case 12: PROBE(3, 0); break; case 13: PROBE(3, 1); break;
+        case 16: PROBE(4, 0); break; case 17: PROBE(4, 1); break;
+        default: return fail(RVLM_ERR_ARG, "rvlm_k_probe_operand_stream: depth / mode combination");
     }
+#undef PROBE
     RVLM_CHECK_LAUNCH();
     return RVLM_OK;
 }

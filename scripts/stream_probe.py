@@ -14,8 +14,8 @@ for name, M, N, K in (("cube8k", 8192, 8192, 8192), ("qkv", 128 * 256, 3072, 102
     g = torch.Generator(device=dev).manual_seed(0)
     A = torch.randn(M, K, generator=g, device=dev).bfloat16()
     B = torch.randn(N, K, generator=g, device=dev).bfloat16()
-    for depth in (1, 2, 3, 4):
-        def run(): L.check(lib.rvlm_k_probe_operand_stream(A.data_ptr(), B.data_ptr(), M, N, K, depth, out.data_ptr(), L.stream_ptr()))
+    for depth, mode in ((1, 0), (2, 0), (3, 0), (4, 0), (1, 1), (2, 1), (3, 1), (1, 2), (2, 2), (1, 3), (2, 3)):
+        def run(): L.check(lib.rvlm_k_probe_operand_stream(A.data_ptr(), B.data_ptr(), M, N, K, depth, mode, out.data_ptr(), L.stream_ptr()))
         for _ in range(5): run()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -26,5 +26,6 @@ for name, M, N, K in (("cube8k", 8192, 8192, 8192), ("qkv", 128 * 256, 3072, 102
         ksteps = (M // 256) * (N // 256) * (K // 64)            # tile K-steps, 64 KiB of operand requests each
         tb = ksteps * 65536 / (ms * 1e-3) / 1e12
         per_cu_us = ms * 1e3 / (ksteps / 256)
-        print(f"{name:7s} depth {depth} ({depth * 64:3d} KiB/CU in flight): {ms * 1e3:8.1f} us  {tb:6.2f} TB/s requested  "
+        tag = ("regs" if not mode & 2 else "LDS-DMA") + (" + barrier per K-step" if mode & 1 else "")
+        print(f"{name:7s} {tag:30s} depth {depth} ({depth * 64:3d} KiB/CU in flight): {ms * 1e3:8.1f} us  {tb:6.2f} TB/s requested  "
               f"{per_cu_us * 1e3:7.1f} ns per K-step and CU  (= {2.0 * 256 * 256 * 64 / (per_cu_us * 1e-6) * 256 / 1e12:7.0f} TFLOP/s if MFMA kept up)", flush=True)
