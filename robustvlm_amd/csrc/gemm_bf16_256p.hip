@@ -145,6 +145,15 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const int ntiles = tiles_m * tiles_n;
     constexpr bool OUT_F32 = (EPI == EPI_F32_RESID || EPI == EPI_F32);
+    constexpr bool SPREAD = (ABL & 16) != 0;   // schedule experiment: DMA pieces spread among the MFMAs
+    constexpr bool STAG = (ABL & 32) != 0;     // ... at different positions for the two waves of a SIMD (wm = 0 / 1)
+    // schedule experiment: the two waves of a SIMD (w, w + 4) take opposite roles inside a K-step.  One half of the
+    // workgroup requests ALL of B right after the barrier (it stalls in the texture queue while the other half issues
+    // MFMAs), the other half requests ALL of A at the END of its step (while the first half is in its MFMAs).
+    constexpr bool SPLIT = (ABL & 256) != 0;
+    constexpr bool SWAP = (ABL & 512) != 0;    // ... with waves 4-7 (not 0-3) as the B half
+    constexpr int NPIECE = SPLIT ? 8 : 4;      // DMA pieces per wave and operand half
+    constexpr int APOS = (ABL & 1024) ? 1 : (ABL & 2048) ? 2 : 3;   // the A half's requests go out after MFMA group 0 / 1 / 2
     // phase offset (performance only): with every workgroup in lockstep the epilogues' HBM bursts coincide chip-wide.  On
     // by default for the fc2 dgrad only (8 tiles per workgroup, epilogue reads act' from HBM: -3 %); measured neutral to
     // slightly negative for the other epilogues (2 tiles per workgroup: the offset costs as much tail as it hides)
@@ -205,15 +214,17 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
         a_loff[jp] = ((lane >> 3) * lda + clog * 8) * 2;
         b_loff[jp] = ((lane >> 3) * ldb + clog * 8) * 2;
     }
-    const int stage_wave_off = (w * 32) * 128;
+    const bool own_b = SPLIT ? ((w < 4) != SWAP) : true, own_a = SPLIT ? !own_b : true;
+    const int wrow = SPLIT ? (w & 3) * 64 : w * 32;     // first row (of each 256-row half) this wave requests
+    const int stage_wave_off = wrow * 128;
     // cursors: next stage to request = K-step a_kt of this workgroup's tile number a_ti (likewise b_*)
     int a_ti = 0, a_kt = 0, a_soff = 0, a_slot = 0;
     int b_ti = 0, b_kt = 0, b_soff = 0, b_slot = 0;
     {
         int m0, n0;
         tile_origin(blockIdx.x, m0, n0);
-        a_soff = (m0 + w * 32) * lda * 2;
-        b_soff = (b_row0(m0, n0) + w * 32) * ldb * 2;
+        a_soff = (m0 + wrow) * lda * 2;
+        b_soff = (b_row0(m0, n0) + wrow) * ldb * 2;
     }
     // experiment (ABL & 8): the same operand stream as plain buffer_load_dwordx4 into registers (folded into a sink one
     // K-step later) - compares the VGPR return path of the texture unit with the LDS-DMA path
@@ -222,6 +233,49 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) { pendA[j] = sink; pendB[j] = sink; }
     }
+    // piece-level forms (schedule experiments ABL & 16 / & 32: the 8 DMA instructions of a K-step are spread among
+    // its MFMAs instead of being issued back to back after the barrier, where the waves of a SIMD stall on them together)
+    auto a_piece = [&](int j) {
+        if (a_ti >= ntw) return;
+        __attribute__((address_space(3))) char* dst =
+            (__attribute__((address_space(3))) char*)lds + (a_slot * PA_SLOT + stage_wave_off);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            a_rs, (lds_ptr_t)(dst + j * 1024), 16, a_loff[j & 1],
+            __builtin_amdgcn_readfirstlane(a_soff + (a_kt + k0 >= nk ? a_kt + k0 - nk : a_kt + k0) * (P_K * 2) + j * 16 * lda), 0, 0);
+    };
+    auto a_advance = [&]() -> bool {
+        if (a_ti >= ntw) return false;
+        a_slot = (a_slot == 2) ? 0 : a_slot + 1;
+        if (++a_kt == nk) {
+            a_kt = 0;
+            if (++a_ti < ntw) {
+                int m0, n0;
+                tile_origin(blockIdx.x + a_ti * gridDim.x, m0, n0);
+                a_soff = (m0 + wrow) * lda * 2;
+            }
+        }
+        return true;
+    };
+    auto b_piece = [&](int j) {
+        if (b_ti >= ntw) return;
+        __attribute__((address_space(3))) char* dst =
+            (__attribute__((address_space(3))) char*)lds + (PB_BASE + b_slot * PB_SLOT + stage_wave_off);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            b_rs, (lds_ptr_t)(dst + j * 1024), 16, b_loff[j & 1],
+            __builtin_amdgcn_readfirstlane(b_soff + (b_kt + k0 >= nk ? b_kt + k0 - nk : b_kt + k0) * (P_K * 2) + j * 16 * ldb), 0, 0);
+    };
+    auto b_advance = [&]() {
+        if (b_ti >= ntw) return;
+        b_slot ^= 1;
+        if (++b_kt == nk) {
+            b_kt = 0;
+            if (++b_ti < ntw) {
+                int m0, n0;
+                tile_origin(blockIdx.x + b_ti * gridDim.x, m0, n0);
+                b_soff = (b_row0(m0, n0) + wrow) * ldb * 2;
+            }
+        }
+    };
     auto issue_a = [&]() -> bool {
         if (a_ti >= ntw) return false;
         if (ABL & 8) {
@@ -231,11 +285,11 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
                 pendA[j] = __builtin_amdgcn_raw_buffer_load_b128(
                     a_rs, a_loff[j & 1], __builtin_amdgcn_readfirstlane(a_soff + (a_kt + k0 >= nk ? a_kt + k0 - nk : a_kt + k0) * (P_K * 2) + j * 16 * lda), 0);
             }
-        } else if (!(ABL & 1)) {
+        } else if (!(ABL & 1) && own_a) {
             __attribute__((address_space(3))) char* dst =
                 (__attribute__((address_space(3))) char*)lds + (a_slot * PA_SLOT + stage_wave_off);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NPIECE; ++j)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(
                     a_rs, (lds_ptr_t)(dst + j * 1024), 16, a_loff[j & 1],
                     __builtin_amdgcn_readfirstlane(a_soff + (a_kt + k0 >= nk ? a_kt + k0 - nk : a_kt + k0) * (P_K * 2) + j * 16 * lda), 0, 0);
@@ -246,7 +300,7 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
             if (++a_ti < ntw) {
                 int m0, n0;
                 tile_origin(blockIdx.x + a_ti * gridDim.x, m0, n0);
-                a_soff = (m0 + w * 32) * lda * 2;
+                a_soff = (m0 + wrow) * lda * 2;
             }
         }
         return true;
@@ -260,11 +314,11 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
                 pendB[j] = __builtin_amdgcn_raw_buffer_load_b128(
                     b_rs, b_loff[j & 1], __builtin_amdgcn_readfirstlane(b_soff + (b_kt + k0 >= nk ? b_kt + k0 - nk : b_kt + k0) * (P_K * 2) + j * 16 * ldb), 0);
             }
-        } else if (!(ABL & 1)) {
+        } else if (!(ABL & 1) && own_b) {
             __attribute__((address_space(3))) char* dst =
                 (__attribute__((address_space(3))) char*)lds + (PB_BASE + b_slot * PB_SLOT + stage_wave_off);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NPIECE; ++j)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(
                     b_rs, (lds_ptr_t)(dst + j * 1024), 16, b_loff[j & 1],
                     __builtin_amdgcn_readfirstlane(b_soff + (b_kt + k0 >= nk ? b_kt + k0 - nk : b_kt + k0) * (P_K * 2) + j * 16 * ldb), 0, 0);
@@ -275,7 +329,7 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
             if (++b_ti < ntw) {
                 int m0, n0;
                 tile_origin(blockIdx.x + b_ti * gridDim.x, m0, n0);
-                b_soff = (b_row0(m0, n0) + w * 32) * ldb * 2;
+                b_soff = (b_row0(m0, n0) + wrow) * ldb * 2;
             }
         }
         return true;
@@ -307,6 +361,7 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
     f32x16 acc[4][2];
     auto mma = [&](const i32x4 (&a)[4], const i32x4 (&b)[2]) {
         if (ABL & 2) return;
+        if (ABL & 64) __builtin_amdgcn_s_setprio(1);   // experiment: piece-free MFMA groups at raised priority
 #ifdef RVLM_MFMA_PRIO
         __builtin_amdgcn_s_setprio(RVLM_MFMA_PRIO);                   // experiment: MFMA groups at raised wave priority
 #endif
@@ -320,6 +375,32 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
 #ifdef RVLM_MFMA_PRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
+        if (ABL & 64) __builtin_amdgcn_s_setprio(0);
+    };
+    // the same 8 MFMAs with DMA pieces between them.  which = 0: B pieces 1..3 (piece 0 went out right after the
+    // barrier) + cursor advance; which = 1: the 4 A pieces + advance (returns whether they were requested)
+    auto mma_pieces = [&](const i32x4 (&a)[4], const i32x4 (&b)[2], int which) -> bool {
+        const int shift = STAG ? (wm ^ 1) : 1;   // MFMA index (mod 2) after which a piece goes out
+        bool issued = true;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (!(ABL & 2))
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b[j]),
+                                                                        __builtin_bit_cast(bf16x8, a[i]), acc[i][j],
+                                                                        0, 0, 0);
+                if (j == shift) {
+                    if (which == 0) {
+                        if (i < 3) b_piece(i + 1);
+                        else b_advance();
+                    } else {
+                        a_piece(i);
+                        if (i == 3) issued = a_advance();
+                    }
+                }
+            }
+        return issued;
     };
     auto init_acc = [&](int mi, int ni) {
 #pragma unroll
@@ -332,7 +413,10 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
     issue_a(); issue_b();
     issue_a(); issue_b();
     bool a_ahead = issue_a();       // was the A half of stage g+2 requested at the previous barrier?
-    if (a_ahead) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    if (SPLIT) {                    // (B half: 16 pieces, all needed; A half: 24, the 8 of stage 2 may stay in flight)
+        if (own_a && a_ahead) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (a_ahead) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // (a single tile with two K-steps)
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -345,16 +429,18 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
     const int r0 = lane >> 3;                                         // flush: row r0 + 8*it, 16-B slot lane & 7
 
     auto stamp = [&](int ti, int k) {   // optional per-tile timeline (test hook rvlm_k_gemm_set_trace), wave 0 only
-        if (p.trace && w == 0 && ti < 7) {
+        if (!(ABL & 128) && p.trace && w == 0 && ti < 7) {
             const unsigned long long t = __builtin_amdgcn_s_memtime();
             if (lane == 0) p.trace[((long)blockIdx.x * 8 + ti) * 4 + k] = t;
         }
     };
-    if (p.trace && w == 0 && lane == 0) {   // clock calibration: s_memtime vs the constant 100 MHz s_memrealtime
+    if (!(ABL & 128) && p.trace && w == 0 && lane == 0) {   // clock calibration: s_memtime vs the constant 100 MHz s_memrealtime
         p.trace[((long)blockIdx.x * 8 + 7) * 4 + 0] = __builtin_amdgcn_s_memtime();
         p.trace[((long)blockIdx.x * 8 + 7) * 4 + 1] = __builtin_amdgcn_s_memrealtime();
     }
 
+    unsigned long long wt_vm = 0, wt_bar = 0, wt_dma = 0, wt_mark = 0;
+    const unsigned long long wt_begin = (ABL & 128) ? __builtin_amdgcn_s_memtime() : 0ull;
     for (int ti = 0; ti < ntw; ++ti) {
         int m0, n0;
         tile_origin(blockIdx.x + ti * gridDim.x, m0, n0);
@@ -370,38 +456,69 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
             load_frags(ca_slot, cb_slot, 1, a1, b1);
             asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
-            mma(a0, b0);
+            if (SPREAD && !first_of_tile) a_ahead = mma_pieces(a0, b0, 1);   // A of stage g+2 (slot freed at the last barrier)
+            else mma(a0, b0);
             __builtin_amdgcn_sched_barrier(0);
+            // SPLIT: the A half requests the stage for the slot freed at the PREVIOUS barrier behind some of its MFMAs
+            // (nothing is free yet in the very first step)
+            const bool a_go = !(first_of_tile && ti == 0);
+            if (SPLIT && APOS == 1) { a_ahead = a_go ? issue_a() : false; __builtin_amdgcn_sched_barrier(0); }
             load_frags(ca_slot, cb_slot, 2, a0, b0);
             asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             mma(a1, b1);
             __builtin_amdgcn_sched_barrier(0);
+            if (SPLIT && APOS == 2) { a_ahead = a_go ? issue_a() : false; __builtin_amdgcn_sched_barrier(0); }
             load_frags(ca_slot, cb_slot, 3, a1, b1);
             asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             mma(a0, b0);
             __builtin_amdgcn_sched_barrier(0);
             // first step of a later tile: the B half of the next stage was requested AFTER the epilogue's stores
-            if (a_ahead && !(first_of_tile && ti > 0)) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            unsigned long long tw0 = 0, tw1 = 0;
+            if (ABL & 128) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tw0 = __builtin_amdgcn_s_memtime(); }
+            if (SPLIT) {
+                // the A half's 8 youngest pieces may stay in flight, the B half waits for all of its own
+                if (APOS == 3) a_ahead = a_go ? issue_a() : false;
+                if (own_a && a_ahead) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            } else if (a_ahead && !(first_of_tile && ti > 0)) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if (ABL & 128) { tw1 = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
+            if (ABL & 128) {   // where a K-step's time goes (per wave, summed over the launch): operand wait, barrier wait
+                const unsigned long long tw2 = __builtin_amdgcn_s_memtime();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                wt_vm += tw1 - tw0; wt_bar += tw2 - tw1; wt_mark = tw2;
+            }
             if (first_of_tile) stamp(ti, 1);
-            if (!last_of_tile) issue_b();     // (deferred past the epilogue in a tile's last step: staging uses that slot)
-            a_ahead = issue_a();
-            if (!last_of_tile) load_frags(na_slot, nb_slot, 0, a0, b0);
+            if (SPLIT) {
+                if (!last_of_tile) { load_frags(na_slot, nb_slot, 0, a0, b0); issue_b(); }
+            } else if (SPREAD) {
+                // B piece 0 now, pieces 1..3 among the 8 MFMAs the caller issues next, the A pieces among the first 8
+                // MFMAs of the next step (same request order as below: B of stage g+2, then A of stage g+3)
+                if (!last_of_tile) b_piece(0);
+                else a_ahead = issue_a();     // tile seam: as below (the epilogue gives these all the time they need)
+            } else {
+                if (!last_of_tile) issue_b();     // (deferred past the epilogue in a tile's last step: staging uses that slot)
+                a_ahead = issue_a();
+            }
+            if (ABL & 128) { wt_dma += __builtin_amdgcn_s_memtime() - wt_mark; }
+            if (!SPLIT && !last_of_tile) load_frags(na_slot, nb_slot, 0, a0, b0);
             ca_slot = na_slot;
             cb_slot = nb_slot;
         };
         k_step(true, false);
         __builtin_amdgcn_sched_barrier(0);
-        mma(a1, b1);
+        if (SPREAD) mma_pieces(a1, b1, 0);
+        else mma(a1, b1);
         __builtin_amdgcn_sched_barrier(0);
         for (int kt = 1; kt < nk - 1; ++kt) {
             k_step(false, false);
             __builtin_amdgcn_sched_barrier(0);
-            mma(a1, b1);
+            if (SPREAD) mma_pieces(a1, b1, 0);
+            else mma(a1, b1);
             __builtin_amdgcn_sched_barrier(0);
         }
         const int stage_slot = cb_slot;   // B slot of the tile's last stage = epilogue staging area after its barrier
@@ -553,8 +670,12 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
             issue_b();
         }
     }
-    if (ABL == 0 && m_total > p.M) strip_tail<EPI, ACT>(p, p.M, m_total, lds, w, lane);
-    if (p.trace && w == 0 && lane == 0) {
+    if ((ABL & 128) && p.trace && lane == 0) {   // [workgroup][wave]{operand wait, barrier wait, DMA issue, tile loop total}
+        unsigned long long* t = p.trace + ((long)blockIdx.x * 8 + w) * 4;
+        t[0] = wt_vm; t[1] = wt_bar; t[2] = wt_dma; t[3] = __builtin_amdgcn_s_memtime() - wt_begin;
+    }
+    if ((ABL & 15) == 0 && m_total > p.M) strip_tail<EPI, ACT>(p, p.M, m_total, lds, w, lane);
+    if (!(ABL & 128) && p.trace && w == 0 && lane == 0) {
         p.trace[((long)blockIdx.x * 8 + 7) * 4 + 2] = __builtin_amdgcn_s_memtime();
         p.trace[((long)blockIdx.x * 8 + 7) * 4 + 3] = __builtin_amdgcn_s_memrealtime();
     }
@@ -596,6 +717,28 @@ static int launch_256p_act(const GemmBf16& p, int tiles_m, int tiles_n, int m_to
             case 4: return launch_256p_abl<EPI, ACT, 4>(p, tiles_m, tiles_n, m_total, s);
             case 5: return launch_256p_abl<EPI, ACT, 5>(p, tiles_m, tiles_n, m_total, s);
             case 6: return launch_256p_abl<EPI, ACT, 6>(p, tiles_m, tiles_n, m_total, s);
+            case 16: return launch_256p_abl<EPI, ACT, 16>(p, tiles_m, tiles_n, m_total, s);
+            case 48: return launch_256p_abl<EPI, ACT, 48>(p, tiles_m, tiles_n, m_total, s);
+            case 64: return launch_256p_abl<EPI, ACT, 64>(p, tiles_m, tiles_n, m_total, s);
+            case 112: return launch_256p_abl<EPI, ACT, 112>(p, tiles_m, tiles_n, m_total, s);
+            case 256: return launch_256p_abl<EPI, ACT, 256>(p, tiles_m, tiles_n, m_total, s);
+            case 768: return launch_256p_abl<EPI, ACT, 768>(p, tiles_m, tiles_n, m_total, s);
+            case 129: return launch_256p_abl<EPI, ACT, 129>(p, tiles_m, tiles_n, m_total, s);
+            case 132: return launch_256p_abl<EPI, ACT, 132>(p, tiles_m, tiles_n, m_total, s);
+            case 133: return launch_256p_abl<EPI, ACT, 133>(p, tiles_m, tiles_n, m_total, s);
+            case 897: return launch_256p_abl<EPI, ACT, 897>(p, tiles_m, tiles_n, m_total, s);
+            case 900: return launch_256p_abl<EPI, ACT, 900>(p, tiles_m, tiles_n, m_total, s);
+            case 901: return launch_256p_abl<EPI, ACT, 901>(p, tiles_m, tiles_n, m_total, s);
+            case 898: return launch_256p_abl<EPI, ACT, 898>(p, tiles_m, tiles_n, m_total, s);
+            case 1792: return launch_256p_abl<EPI, ACT, 1792>(p, tiles_m, tiles_n, m_total, s);
+            case 2816: return launch_256p_abl<EPI, ACT, 2816>(p, tiles_m, tiles_n, m_total, s);
+            case 1920: return launch_256p_abl<EPI, ACT, 1920>(p, tiles_m, tiles_n, m_total, s);
+            case 1280: return launch_256p_abl<EPI, ACT, 1280>(p, tiles_m, tiles_n, m_total, s);
+            case 384: return launch_256p_abl<EPI, ACT, 384>(p, tiles_m, tiles_n, m_total, s);
+            case 896: return launch_256p_abl<EPI, ACT, 896>(p, tiles_m, tiles_n, m_total, s);
+            case 128: return launch_256p_abl<EPI, ACT, 128>(p, tiles_m, tiles_n, m_total, s);
+            case 144: return launch_256p_abl<EPI, ACT, 144>(p, tiles_m, tiles_n, m_total, s);
+            case 130: return launch_256p_abl<EPI, ACT, 130>(p, tiles_m, tiles_n, m_total, s);
             case 14: return launch_256p_abl<EPI, ACT, 14>(p, tiles_m, tiles_n, m_total, s);
             case 12: return launch_256p_abl<EPI, ACT, 12>(p, tiles_m, tiles_n, m_total, s);
             default: break;
@@ -646,7 +789,7 @@ int gemm_bf16_nt_256p(const GemmBf16& p, int* rows_done, hipStream_t s) {
     static int krot = -999;
     if (krot == -999) { const char* e = getenv("RVLM_GEMM_KROT"); krot = e ? atoi(e) : 0; }
     q.group_m = group_m; q.wave_prio = wave_prio; q.krot = krot;
-    const bool tail = tail_on && g_persist_ablate == 0 && p.batch_m_rows == 0 && p.M > q.M;
+    const bool tail = tail_on && (g_persist_ablate & 15) == 0 && p.batch_m_rows == 0 && p.M > q.M;
     const int m_total = tail ? p.M : q.M;
     int rc;
     switch (q.epi) {

@@ -35,6 +35,10 @@ __device__ __forceinline__ u32x4p gload16(const char* sbase, unsigned voff) {
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
     return r;
 }
+// MODE bit 2: the 8 lanes of a row read its eight 16-B chunks in the XOR-permuted order the GEMM's LDS swizzle imposes on
+// the global side ((lane & 7) ^ ((row >> 1) & 7)); bit 3: permuted within 64-B halves only ((row >> 1) & 3);
+// MODE bit 4 (with bit 1): the LDS-DMA as MUBUF buffer_load ... lds with a descriptor, a per-lane offset and an SGPR offset
+// (the GEMM's form) instead of global_load_lds;
 // MODE bit 0: one s_barrier per K-step (every wave then waits for the slowest wave's pieces, as a GEMM K-step does);
 // MODE bit 1: the pieces go to LDS by LDS-DMA (global_load_lds_dwordx4) instead of to registers (DEPTH <= 2: 64 KiB each)
 template <int DEPTH, int MODE>
@@ -47,12 +51,24 @@ probe_stream_kernel(const char* __restrict__ A, const char* __restrict__ Bw, lon
     constexpr bool DMA = (MODE & 2) != 0;
     unsigned voff[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) voff[j] = (unsigned)((w * 32 + j * 8 + (lane >> 3)) * ld_bytes + (lane & 7) * 16);
+    for (int j = 0; j < 4; ++j) {
+        const int row = w * 32 + j * 8 + (lane >> 3);
+        const int chunk = (MODE & 4) ? ((lane & 7) ^ ((row >> 1) & 7)) : (MODE & 8) ? ((lane & 7) ^ ((row >> 1) & 3)) : (lane & 7);
+        voff[j] = (unsigned)(row * ld_bytes + chunk * 16);
+    }
     u32x4p P[DMA ? 1 : DEPTH][8], sink = {0u, 0u, 0u, 0u};
+    const auto a_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(A), 0, 0x7fffffff, 0x00020000);
+    const auto b_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Bw), 0, 0x7fffffff, 0x00020000);
     auto fetch = [&](int d, const char* a, const char* b, int k) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (DMA) {
+            if (DMA && (MODE & 16)) {
+                char* dst = plds + d * 65536 + w * 8192 + j * 1024;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (__attribute__((address_space(3))) void*)dst, 16, (int)voff[j],
+                                                         __builtin_amdgcn_readfirstlane((int)(a - A) + k * 128), 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, (__attribute__((address_space(3))) void*)(dst + 4096), 16, (int)voff[j],
+                                                         __builtin_amdgcn_readfirstlane((int)(b - Bw) + k * 128), 0, 0);
+            } else if (DMA) {
                 char* dst = plds + d * 65536 + w * 8192 + j * 1024;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a + (long)k * 128 + voff[j]),
                                                  (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
@@ -94,28 +110,123 @@ probe_stream_kernel(const char* __restrict__ A, const char* __restrict__ Bw, lon
     }
     if (sink.x == 0x12345678u && sink.y == 0x9abcdef0u) out[threadIdx.x] = sink.z ^ sink.w;
 }
+// The persistent GEMM's ring protocol itself, nothing else: 160 KiB of LDS as an A ring of 3 half-stage slots and a B ring
+// of 2; at the barrier that ends K-step g every wave requests B(g+2) then A(g+3); before the barrier it waits with
+// vmcnt(KEEP) (the GEMM keeps the 4 youngest pieces = the A half in flight).  ORDER 1 requests A before B.
+template <int KEEP, int ORDER>
+__global__ void __launch_bounds__(512)
+probe_ring_kernel(const char* __restrict__ A, const char* __restrict__ Bw, long ld_bytes, int tiles_m, int tiles_n, int nk) {
+    extern __shared__ __attribute__((aligned(1024))) char plds[];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ntiles = tiles_m * tiles_n;
+    unsigned voff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) voff[j] = (unsigned)((w * 32 + j * 8 + (lane >> 3)) * ld_bytes + (lane & 7) * 16);
+    const int ntw = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    auto origin = [&](int tile, long& m0, long& n0) {
+        const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = tile & 7, loc = tile >> 3;
+        const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+        const int group_size = 8 * tiles_n, first_m = (t / group_size) * 8, gm = min(tiles_m - first_m, 8);
+        m0 = (long)(first_m + (t % group_size) % gm) * 256; n0 = (long)((t % group_size) / gm) * 256;
+    };
+    // per-stream cursors over all tiles of this workgroup (next stage to request), advanced incrementally
+    const int total = ntw * nk;
+    int a_ti = 0, a_kt = 0, a_slot = 0, b_ti = 0, b_kt = 0, b_slot = 0;
+    const char *a_src, *b_src;
+    {
+        long m0, n0;
+        origin(blockIdx.x, m0, n0);
+        a_src = A + m0 * ld_bytes; b_src = Bw + n0 * ld_bytes;
+    }
+    auto issue = [&](bool is_a, int) {
+        int& ti = is_a ? a_ti : b_ti; int& kt = is_a ? a_kt : b_kt; int& slot = is_a ? a_slot : b_slot;
+        const char*& src = is_a ? a_src : b_src;
+        if (ti >= ntw) return;
+        char* dst = plds + (is_a ? slot * 32768 : 98304 + slot * 32768) + w * 4096;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (long)kt * 128 + voff[j]),
+                                             (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
+        slot = is_a ? (slot == 2 ? 0 : slot + 1) : (slot ^ 1);
+        if (++kt == nk) {
+            kt = 0;
+            if (++ti < ntw) {
+                long m0, n0;
+                origin(blockIdx.x + ti * gridDim.x, m0, n0);
+                src = is_a ? A + m0 * ld_bytes : Bw + n0 * ld_bytes;
+            }
+        }
+    };
+    int ga = 0, gb = 0;
+    issue(true, ga++); issue(false, gb++);
+    issue(true, ga++); issue(false, gb++);
+    issue(true, ga++);
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int g = 0; g < total; ++g) {
+        if (KEEP == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (KEEP == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (ORDER == 0) { issue(false, gb++); issue(true, ga++); }
+        else { issue(true, ga++); issue(false, gb++); }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 }  // namespace rvlm
 using namespace rvlm;
 
 extern "C" int rvlm_k_probe_operand_stream(const uint16_t* A, const uint16_t* Bw, int M, int N, int K, int depth, int mode,
                                            uint32_t* out, rvlm_stream_t stream) {
-    if (M % 256 || N % 256 || K % 64 || depth < 1 || depth > 4 || K / 64 < depth || mode < 0 || mode > 3 ||
-        ((mode & 2) && depth > 2))
+    if (M % 256 || N % 256 || K % 64 || depth < 1 || depth > 4 || K / 64 < depth || mode < 0 || mode > 35 ||
+        (mode < 32 && (mode & 2) && depth > 2))
         return fail(RVLM_ERR_ARG, "rvlm_k_probe_operand_stream: M, N % 256, K % 64, depth 1..4 (<= 2 with LDS-DMA), mode 0..3");
     const int tm = M / 256, tn = N / 256, nk = K / 64, grid = std::min(tm * tn, 256);
     const long ldb = (long)K * 2;
     hipStream_t s = (hipStream_t)stream;
+    if (mode >= 32) {
+        const size_t ring = 163840;
+#define RING(KP, OR)                                                                                                    \
+        do {                                                                                                             \
+            (void)hipFuncSetAttribute((const void*)probe_ring_kernel<KP, OR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring); \
+            hipLaunchKernelGGL((probe_ring_kernel<KP, OR>), dim3(grid), dim3(512), ring, s, (const char*)A, (const char*)Bw, ldb, tm, tn, nk); \
+        } while (0)
+        if (mode == 32) RING(4, 0); else if (mode == 33) RING(4, 1); else if (mode == 34) RING(0, 0); else RING(8, 0);
+#undef RING
+        RVLM_CHECK_LAUNCH();
+        return RVLM_OK;
+    }
     const size_t lds = (mode & 2) ? (size_t)depth * 65536 : 0;
 #define PROBE(D, MD)                                                                                                  \
     do {                                                                                                               \
         if (lds) (void)hipFuncSetAttribute((const void*)probe_stream_kernel<D, MD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((probe_stream_kernel<D, MD>), dim3(grid), dim3(512), lds, s, (const char*)A, (const char*)Bw, ldb, tm, tn, nk, out); \
     } while (0)
-    switch (depth * 4 + mode) {
-        case 4: PROBE(1, 0); break;  case 5: PROBE(1, 1); break;  case 6: PROBE(1, 2); break;  case 7: PROBE(1, 3); break;
-        case 8: PROBE(2, 0); break;  case 9: PROBE(2, 1); break;  case 10: PROBE(2, 2); break; case 11: PROBE(2, 3); break;
-        case 12: PROBE(3, 0); break; case 13: PROBE(3, 1); break;
-        case 16: PROBE(4, 0); break; case 17: PROBE(4, 1); break;
+    switch (depth * 32 + mode) {
+        case 32: PROBE(1, 0); break;
+        case 33: PROBE(1, 1); break;
+        case 34: PROBE(1, 2); break;
+        case 35: PROBE(1, 3); break;
+        case 64: PROBE(2, 0); break;
+        case 65: PROBE(2, 1); break;
+        case 66: PROBE(2, 2); break;
+        case 67: PROBE(2, 3); break;
+        case 96: PROBE(3, 0); break;
+        case 97: PROBE(3, 1); break;
+        case 128: PROBE(4, 0); break;
+        case 129: PROBE(4, 1); break;
+        case 36: PROBE(1, 4); break;
+        case 68: PROBE(2, 4); break;
+        case 39: PROBE(1, 7); break;
+        case 71: PROBE(2, 7); break;
+        case 40: PROBE(1, 8); break;
+        case 72: PROBE(2, 8); break;
+        case 43: PROBE(1, 11); break;
+        case 75: PROBE(2, 11); break;
+        case 50: PROBE(1, 18); break;
+        case 82: PROBE(2, 18); break;
+        case 51: PROBE(1, 19); break;
+        case 83: PROBE(2, 19); break;
         default: return fail(RVLM_ERR_ARG, "rvlm_k_probe_operand_stream: depth / mode combination");
     }
 #undef PROBE
