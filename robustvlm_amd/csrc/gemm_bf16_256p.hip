@@ -10,7 +10,10 @@
 //   * BK = 64 (128-B LDS rows = one full L2 line per operand row per K-step; 64-B rows halve the payload per request
 //     and measured 10 TB/s against 15 TB/s of operand DMA).  LDS = A ring of 3 half-stage slots + B ring of 2: the A
 //     halves run three K-steps ahead of the MFMAs, the B halves two, continuously across tile seams.  One barrier
-//     per K-step, fragments double-buffered in registers, counted vmcnt (the 4 youngest DMA pieces stay in flight).
+//     per K-step, fragments double-buffered in registers, counted vmcnt (the A half's youngest stage stays in flight).
+//   * the two waves of a SIMD take opposite roles in the operand traffic: waves 4-7 request all of B right after the
+//     barrier, waves 0-3 all of A at the end of their step, so one of them issues MFMAs while the other waits in the
+//     texture queue (see SPLIT below; +4-6 % on every shape over the lockstep form).
 //   * epilogue = wave-private LDS transpose (in the B slot the tile's last K-step freed, through inline-asm DS ops so
 //     that hipcc does not drain the operand stream) -> full-line 16-B-per-lane buffer stores; fp32 residual / h_pre
 //     are read in the same coalesced pattern, prefetched four 32x32 sub-tiles ahead; bias joins the accumulators
@@ -145,15 +148,31 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const int ntiles = tiles_m * tiles_n;
     constexpr bool OUT_F32 = (EPI == EPI_F32_RESID || EPI == EPI_F32);
-    constexpr bool SPREAD = (ABL & 16) != 0;   // schedule experiment: DMA pieces spread among the MFMAs
-    constexpr bool STAG = (ABL & 32) != 0;     // ... at different positions for the two waves of a SIMD (wm = 0 / 1)
-    // schedule experiment: the two waves of a SIMD (w, w + 4) take opposite roles inside a K-step.  One half of the
-    // workgroup requests ALL of B right after the barrier (it stalls in the texture queue while the other half issues
-    // MFMAs), the other half requests ALL of A at the END of its step (while the first half is in its MFMAs).
-    constexpr bool SPLIT = (ABL & 256) != 0;
-    constexpr bool SWAP = (ABL & 512) != 0;    // ... with waves 4-7 (not 0-3) as the B half
+    // Role split inside a K-step (production; ABL & 256 restores the lockstep form it replaced, kept as the measured
+    // baseline).  A `buffer_load ... lds` holds its wave until the CU's texture queue takes it (~15 cycles per 1-KB
+    // piece, queue shared by all 8 waves), and a waiting wave issues no MFMAs.  With every wave requesting 4 A + 4 B
+    // pieces right after the barrier, both waves of each SIMD sat in that queue together: ~890 cycles per K-step with
+    // the matrix pipe idle (per-wave s_memtime sums, profiles/r02_gemm_gemm_waits*.log).  Here one half of the
+    // workgroup requests ALL of B right after the barrier and the other half ALL of A at the END of its step, so on
+    // every SIMD one wave is in its MFMAs while its partner is in the queue.  The B half is waves 4-7: the
+    // second-dispatched wave of a SIMD loses MFMA arbitration to its partner anyway, so its early stall costs least
+    // (ABL & 512 swaps the halves: measured +1-2 % against +4-6 %).
+#ifdef RVLM_GEMM_LOCKSTEP            // A/B build of the whole library with the lockstep form (scripts/trip_r2s.sh)
+    constexpr bool SPLIT = false;
+#else
+    constexpr bool SPLIT = (ABL & 256) == 0 && (ABL & 8) == 0;   // (the register-path experiment keeps the lockstep form)
+#endif
+    constexpr bool SWAP = (ABL & 512) == 0;
     constexpr int NPIECE = SPLIT ? 8 : 4;      // DMA pieces per wave and operand half
-    constexpr int APOS = (ABL & 1024) ? 1 : (ABL & 2048) ? 2 : 3;   // the A half's requests go out after MFMA group 0 / 1 / 2
+    // Fragment reads between the MFMAs of the previous k-slice (2 ds_read_b128 after each of its first three MFMAs)
+    // instead of 6 in a row between two groups of 8 MFMAs: with the role split each wave runs alone on its SIMD while
+    // its partner sits in the texture queue or at the barrier, and every non-MFMA issue slot between groups is then
+    // pipe idle time.  ABL & 1024 restores the grouped form.
+    constexpr bool FINE = (ABL & 1024) == 0;
+    // ... and the 8 DMA pieces of a wave likewise, one behind each MFMA of a k-slice (the B half's in the slice right
+    // after the barrier, the A half's in the last slice before it): the wave still waits ~60 cycles in the texture queue
+    // per piece, but its own MFMAs run meanwhile.  ABL & 2048 restores the burst.
+    constexpr bool PIECEWISE = SPLIT && FINE && (ABL & 2048) != 0;   // (experiment: off in production)
     // phase offset (performance only): with every workgroup in lockstep the epilogues' HBM bursts coincide chip-wide.  On
     // by default for the fc2 dgrad only (8 tiles per workgroup, epilogue reads act' from HBM: -3 %); measured neutral to
     // slightly negative for the other epilogues (2 tiles per workgroup: the offset costs as much tail as it hides)
@@ -204,9 +223,11 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
     const int ntw = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // tiles of this workgroup
 
     // ---- operand streams.  Stage g (global K-step counter over all tiles of this workgroup) has its A half in A
-    // slot g % 3 and its B half in B slot g % 2; A runs three stages ahead of the MFMAs, B two.  Wave w loads rows
-    // [32w, 32w+32) of each half, 8 rows x 128 B per DMA; row of piece j: 32w + 8j + (lane>>3); its 16-B chunk
-    // (lane&7) holds logical chunk (lane&7) ^ ((row>>1)&7), which only depends on the parity of j.
+    // slot g % 3 and its B half in B slot g % 2; A runs three stages ahead of the MFMAs, B two.  One DMA instruction
+    // moves 8 rows x 128 B.  Split roles: waves 4-7 request the B half (wave w rows [64(w&3), +64) = 8 pieces), waves
+    // 0-3 the A half likewise; lockstep form: wave w requests rows [32w, 32w+32) of both halves.  Row of piece j:
+    // first row + 8j + (lane>>3); its 16-B chunk (lane&7) holds logical chunk (lane&7) ^ ((row>>1)&7), which only
+    // depends on the parity of j.
     int a_loff[2], b_loff[2];
 #pragma unroll
     for (int jp = 0; jp < 2; ++jp) {
@@ -215,6 +236,7 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
         b_loff[jp] = ((lane >> 3) * ldb + clog * 8) * 2;
     }
     const bool own_b = SPLIT ? ((w < 4) != SWAP) : true, own_a = SPLIT ? !own_b : true;
+    const bool lane_own_b = SPLIT ? ((threadIdx.x < 256) != SWAP) : true, lane_own_a = SPLIT ? !lane_own_b : true;
     const int wrow = SPLIT ? (w & 3) * 64 : w * 32;     // first row (of each 256-row half) this wave requests
     const int stage_wave_off = wrow * 128;
     // cursors: next stage to request = K-step a_kt of this workgroup's tile number a_ti (likewise b_*)
@@ -233,17 +255,18 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) { pendA[j] = sink; pendB[j] = sink; }
     }
-    // piece-level forms (schedule experiments ABL & 16 / & 32: the 8 DMA instructions of a K-step are spread among
-    // its MFMAs instead of being issued back to back after the barrier, where the waves of a SIMD stall on them together)
-    auto a_piece = [&](int j) {
-        if (a_ti >= ntw) return;
+    // one DMA piece (8 rows x 128 B per wave instruction) of the next A / B stage, and the cursor step behind its last
+    auto a_piece = [&](int j) __attribute__((always_inline)) {
+        // (the role test is a per-LANE predicate on purpose: an EXEC-masked region keeps the MFMA groups around it in one
+        // block, a scalar branch between MFMAs made hipcc copy accumulators around and spill)
+        if ((ABL & 1) || !(lane_own_a && a_ti < ntw)) return;
         __attribute__((address_space(3))) char* dst =
             (__attribute__((address_space(3))) char*)lds + (a_slot * PA_SLOT + stage_wave_off);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
             a_rs, (lds_ptr_t)(dst + j * 1024), 16, a_loff[j & 1],
             __builtin_amdgcn_readfirstlane(a_soff + (a_kt + k0 >= nk ? a_kt + k0 - nk : a_kt + k0) * (P_K * 2) + j * 16 * lda), 0, 0);
     };
-    auto a_advance = [&]() -> bool {
+    auto a_advance = [&]() __attribute__((always_inline)) -> bool {
         if (a_ti >= ntw) return false;
         a_slot = (a_slot == 2) ? 0 : a_slot + 1;
         if (++a_kt == nk) {
@@ -256,16 +279,16 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
         }
         return true;
     };
-    auto b_piece = [&](int j) {
-        if (b_ti >= ntw) return;
+    auto b_piece = [&](int j) __attribute__((always_inline)) {
+        if ((ABL & 1) || !(lane_own_b && b_ti < ntw)) return;
         __attribute__((address_space(3))) char* dst =
             (__attribute__((address_space(3))) char*)lds + (PB_BASE + b_slot * PB_SLOT + stage_wave_off);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
             b_rs, (lds_ptr_t)(dst + j * 1024), 16, b_loff[j & 1],
             __builtin_amdgcn_readfirstlane(b_soff + (b_kt + k0 >= nk ? b_kt + k0 - nk : b_kt + k0) * (P_K * 2) + j * 16 * ldb), 0, 0);
     };
-    auto b_advance = [&]() {
-        if (b_ti >= ntw) return;
+    auto b_advance = [&]() __attribute__((always_inline)) -> bool {
+        if (b_ti >= ntw) return false;
         b_slot ^= 1;
         if (++b_kt == nk) {
             b_kt = 0;
@@ -275,64 +298,37 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
                 b_soff = (b_row0(m0, n0) + wrow) * ldb * 2;
             }
         }
+        return true;
     };
-    auto issue_a = [&]() -> bool {
-        if (a_ti >= ntw) return false;
+    auto issue_a = [&]() -> bool {     // a whole stage in one burst
         if (ABL & 8) {
+            if (a_ti >= ntw) return false;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 sink ^= pendA[j];
                 pendA[j] = __builtin_amdgcn_raw_buffer_load_b128(
                     a_rs, a_loff[j & 1], __builtin_amdgcn_readfirstlane(a_soff + (a_kt + k0 >= nk ? a_kt + k0 - nk : a_kt + k0) * (P_K * 2) + j * 16 * lda), 0);
             }
-        } else if (!(ABL & 1) && own_a) {
-            __attribute__((address_space(3))) char* dst =
-                (__attribute__((address_space(3))) char*)lds + (a_slot * PA_SLOT + stage_wave_off);
+        } else {
 #pragma unroll
-            for (int j = 0; j < NPIECE; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                    a_rs, (lds_ptr_t)(dst + j * 1024), 16, a_loff[j & 1],
-                    __builtin_amdgcn_readfirstlane(a_soff + (a_kt + k0 >= nk ? a_kt + k0 - nk : a_kt + k0) * (P_K * 2) + j * 16 * lda), 0, 0);
+            for (int j = 0; j < NPIECE; ++j) a_piece(j);
         }
-        a_slot = (a_slot == 2) ? 0 : a_slot + 1;
-        if (++a_kt == nk) {
-            a_kt = 0;
-            if (++a_ti < ntw) {
-                int m0, n0;
-                tile_origin(blockIdx.x + a_ti * gridDim.x, m0, n0);
-                a_soff = (m0 + wrow) * lda * 2;
-            }
-        }
-        return true;
+        return a_advance();
     };
     auto issue_b = [&]() -> bool {
-        if (b_ti >= ntw) return false;
         if (ABL & 8) {
+            if (b_ti >= ntw) return false;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 sink ^= pendB[j];
                 pendB[j] = __builtin_amdgcn_raw_buffer_load_b128(
                     b_rs, b_loff[j & 1], __builtin_amdgcn_readfirstlane(b_soff + (b_kt + k0 >= nk ? b_kt + k0 - nk : b_kt + k0) * (P_K * 2) + j * 16 * ldb), 0);
             }
-        } else if (!(ABL & 1) && own_b) {
-            __attribute__((address_space(3))) char* dst =
-                (__attribute__((address_space(3))) char*)lds + (PB_BASE + b_slot * PB_SLOT + stage_wave_off);
+        } else {
 #pragma unroll
-            for (int j = 0; j < NPIECE; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                    b_rs, (lds_ptr_t)(dst + j * 1024), 16, b_loff[j & 1],
-                    __builtin_amdgcn_readfirstlane(b_soff + (b_kt + k0 >= nk ? b_kt + k0 - nk : b_kt + k0) * (P_K * 2) + j * 16 * ldb), 0, 0);
+            for (int j = 0; j < NPIECE; ++j) b_piece(j);
         }
-        b_slot ^= 1;
-        if (++b_kt == nk) {
-            b_kt = 0;
-            if (++b_ti < ntw) {
-                int m0, n0;
-                tile_origin(blockIdx.x + b_ti * gridDim.x, m0, n0);
-                b_soff = (b_row0(m0, n0) + wrow) * ldb * 2;
-            }
-        }
-        return true;
+        return b_advance();
     };
 
     // ---- fragment addresses = per-lane part (fa / fb, by k-slice) + ring slot offset.  The slot offsets are kept
@@ -361,7 +357,6 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
     f32x16 acc[4][2];
     auto mma = [&](const i32x4 (&a)[4], const i32x4 (&b)[2]) {
         if (ABL & 2) return;
-        if (ABL & 64) __builtin_amdgcn_s_setprio(1);   // experiment: piece-free MFMA groups at raised priority
 #ifdef RVLM_MFMA_PRIO
         __builtin_amdgcn_s_setprio(RVLM_MFMA_PRIO);                   // experiment: MFMA groups at raised wave priority
 #endif
@@ -375,13 +370,14 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
 #ifdef RVLM_MFMA_PRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
-        if (ABL & 64) __builtin_amdgcn_s_setprio(0);
     };
-    // the same 8 MFMAs with DMA pieces between them.  which = 0: B pieces 1..3 (piece 0 went out right after the
-    // barrier) + cursor advance; which = 1: the 4 A pieces + advance (returns whether they were requested)
-    auto mma_pieces = [&](const i32x4 (&a)[4], const i32x4 (&b)[2], int which) -> bool {
-        const int shift = STAG ? (wm ^ 1) : 1;   // MFMA index (mod 2) after which a piece goes out
-        bool issued = true;
+    // 8 MFMAs of one k-slice (fragments a, b) with the 6 fragment reads of slice kk of stage (sa, sb) into (na, nb)
+    // issued between them
+    auto mma_lf = [&](const i32x4 (&a)[4], const i32x4 (&b)[2], int sa, int sb, int kk, i32x4 (&na)[4], i32x4 (&nb)[2],
+                      int pieces /* 0 none, 1 the B stage, 2 the A stage */) __attribute__((always_inline)) {
+        int oa = sa * PA_SLOT, ob = sb * PB_SLOT + ab_delta;
+        asm volatile("" : "+s"(oa), "+s"(ob));
+        const unsigned aa = fa[kk] + oa, bb = fa[kk] + ob;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -390,17 +386,23 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b[j]),
                                                                         __builtin_bit_cast(bf16x8, a[i]), acc[i][j],
                                                                         0, 0, 0);
-                if (j == shift) {
-                    if (which == 0) {
-                        if (i < 3) b_piece(i + 1);
-                        else b_advance();
-                    } else {
-                        a_piece(i);
-                        if (i == 3) issued = a_advance();
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(ABL & 4)) {
+                    if (i == 0 && j == 0) {
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(nb[0]) : "v"(bb));
+                        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(nb[1]) : "v"(bb));
+                    } else if (i == 0 && j == 1) {
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(na[0]) : "v"(aa));
+                        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(na[1]) : "v"(aa));
+                    } else if (i == 1 && j == 0) {
+                        asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(na[2]) : "v"(aa));
+                        asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(na[3]) : "v"(aa));
                     }
                 }
+                if (pieces == 1) b_piece(i * 2 + j);
+                if (pieces == 2) a_piece(i * 2 + j);
+                __builtin_amdgcn_sched_barrier(0);
             }
-        return issued;
     };
     auto init_acc = [&](int mi, int ni) {
 #pragma unroll
@@ -453,33 +455,47 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
         // next step may leave exactly the 4 youngest pieces, the A half, in flight).
         auto k_step = [&](bool first_of_tile, bool last_of_tile) {
             const int na_slot = (ca_slot == 2) ? 0 : ca_slot + 1, nb_slot = cb_slot ^ 1;
-            load_frags(ca_slot, cb_slot, 1, a1, b1);
-            asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            if (SPREAD && !first_of_tile) a_ahead = mma_pieces(a0, b0, 1);   // A of stage g+2 (slot freed at the last barrier)
-            else mma(a0, b0);
-            __builtin_amdgcn_sched_barrier(0);
-            // SPLIT: the A half requests the stage for the slot freed at the PREVIOUS barrier behind some of its MFMAs
-            // (nothing is free yet in the very first step)
-            const bool a_go = !(first_of_tile && ti == 0);
-            if (SPLIT && APOS == 1) { a_ahead = a_go ? issue_a() : false; __builtin_amdgcn_sched_barrier(0); }
-            load_frags(ca_slot, cb_slot, 2, a0, b0);
-            asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            mma(a1, b1);
-            __builtin_amdgcn_sched_barrier(0);
-            if (SPLIT && APOS == 2) { a_ahead = a_go ? issue_a() : false; __builtin_amdgcn_sched_barrier(0); }
-            load_frags(ca_slot, cb_slot, 3, a1, b1);
-            asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            mma(a0, b0);
-            __builtin_amdgcn_sched_barrier(0);
+            if (FINE) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                mma_lf(a0, b0, ca_slot, cb_slot, 1, a1, b1, 0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                mma_lf(a1, b1, ca_slot, cb_slot, 2, a0, b0, 0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                if (PIECEWISE) {
+                    // (nothing is free yet in the very first step: compile-time first_of_tile, so the extra body exists
+                    // only in the first step's copy)
+                    if (first_of_tile && ti == 0) { mma_lf(a0, b0, ca_slot, cb_slot, 3, a1, b1, 0); a_ahead = false; }
+                    else { mma_lf(a0, b0, ca_slot, cb_slot, 3, a1, b1, 2); a_ahead = a_advance(); }
+                } else {
+                    mma_lf(a0, b0, ca_slot, cb_slot, 3, a1, b1, 0);
+                }
+            } else {
+                load_frags(ca_slot, cb_slot, 1, a1, b1);
+                asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                mma(a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                load_frags(ca_slot, cb_slot, 2, a0, b0);
+                asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                mma(a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+                load_frags(ca_slot, cb_slot, 3, a1, b1);
+                asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                mma(a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             // first step of a later tile: the B half of the next stage was requested AFTER the epilogue's stores
             unsigned long long tw0 = 0, tw1 = 0;
             if (ABL & 128) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tw0 = __builtin_amdgcn_s_memtime(); }
             if (SPLIT) {
-                // the A half's 8 youngest pieces may stay in flight, the B half waits for all of its own
-                if (APOS == 3) a_ahead = a_go ? issue_a() : false;
+                // the A half requests the stage for the slot freed at the PREVIOUS barrier (nothing is free yet in the
+                // very first step); its 8 youngest pieces may stay in flight, the B half waits for all of its own
+                if (!PIECEWISE) a_ahead = (first_of_tile && ti == 0) ? false : issue_a();
                 if (own_a && a_ahead) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             } else if (a_ahead && !(first_of_tile && ti > 0)) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
@@ -494,30 +510,32 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
             }
             if (first_of_tile) stamp(ti, 1);
             if (SPLIT) {
-                if (!last_of_tile) { load_frags(na_slot, nb_slot, 0, a0, b0); issue_b(); }
-            } else if (SPREAD) {
-                // B piece 0 now, pieces 1..3 among the 8 MFMAs the caller issues next, the A pieces among the first 8
-                // MFMAs of the next step (same request order as below: B of stage g+2, then A of stage g+3)
-                if (!last_of_tile) b_piece(0);
-                else a_ahead = issue_a();     // tile seam: as below (the epilogue gives these all the time they need)
+                // (B is deferred past the epilogue in a tile's last step: staging uses that slot)
+                if (!last_of_tile) {
+                    if (!FINE) load_frags(na_slot, nb_slot, 0, a0, b0);     // (FINE: among the caller's 8 MFMAs)
+                    if (!PIECEWISE) issue_b();                              // (PIECEWISE: likewise)
+                }
             } else {
-                if (!last_of_tile) issue_b();     // (deferred past the epilogue in a tile's last step: staging uses that slot)
+                if (!last_of_tile) issue_b();
                 a_ahead = issue_a();
             }
             if (ABL & 128) { wt_dma += __builtin_amdgcn_s_memtime() - wt_mark; }
-            if (!SPLIT && !last_of_tile) load_frags(na_slot, nb_slot, 0, a0, b0);
+            if (!SPLIT && !FINE && !last_of_tile) load_frags(na_slot, nb_slot, 0, a0, b0);
             ca_slot = na_slot;
             cb_slot = nb_slot;
         };
         k_step(true, false);
         __builtin_amdgcn_sched_barrier(0);
-        if (SPREAD) mma_pieces(a1, b1, 0);
+        // + the next stage's first fragments (its barrier is behind us) and the B half's requests
+        if (PIECEWISE) { mma_lf(a1, b1, ca_slot, cb_slot, 0, a0, b0, 1); b_advance(); }
+        else if (FINE) mma_lf(a1, b1, ca_slot, cb_slot, 0, a0, b0, 0);
         else mma(a1, b1);
         __builtin_amdgcn_sched_barrier(0);
         for (int kt = 1; kt < nk - 1; ++kt) {
             k_step(false, false);
             __builtin_amdgcn_sched_barrier(0);
-            if (SPREAD) mma_pieces(a1, b1, 0);
+            if (PIECEWISE) { mma_lf(a1, b1, ca_slot, cb_slot, 0, a0, b0, 1); b_advance(); }
+            else if (FINE) mma_lf(a1, b1, ca_slot, cb_slot, 0, a0, b0, 0);
             else mma(a1, b1);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -717,28 +735,17 @@ static int launch_256p_act(const GemmBf16& p, int tiles_m, int tiles_n, int m_to
             case 4: return launch_256p_abl<EPI, ACT, 4>(p, tiles_m, tiles_n, m_total, s);
             case 5: return launch_256p_abl<EPI, ACT, 5>(p, tiles_m, tiles_n, m_total, s);
             case 6: return launch_256p_abl<EPI, ACT, 6>(p, tiles_m, tiles_n, m_total, s);
-            case 16: return launch_256p_abl<EPI, ACT, 16>(p, tiles_m, tiles_n, m_total, s);
-            case 48: return launch_256p_abl<EPI, ACT, 48>(p, tiles_m, tiles_n, m_total, s);
-            case 64: return launch_256p_abl<EPI, ACT, 64>(p, tiles_m, tiles_n, m_total, s);
-            case 112: return launch_256p_abl<EPI, ACT, 112>(p, tiles_m, tiles_n, m_total, s);
-            case 256: return launch_256p_abl<EPI, ACT, 256>(p, tiles_m, tiles_n, m_total, s);
-            case 768: return launch_256p_abl<EPI, ACT, 768>(p, tiles_m, tiles_n, m_total, s);
+            case 128: return launch_256p_abl<EPI, ACT, 128>(p, tiles_m, tiles_n, m_total, s);
             case 129: return launch_256p_abl<EPI, ACT, 129>(p, tiles_m, tiles_n, m_total, s);
             case 132: return launch_256p_abl<EPI, ACT, 132>(p, tiles_m, tiles_n, m_total, s);
             case 133: return launch_256p_abl<EPI, ACT, 133>(p, tiles_m, tiles_n, m_total, s);
-            case 897: return launch_256p_abl<EPI, ACT, 897>(p, tiles_m, tiles_n, m_total, s);
-            case 900: return launch_256p_abl<EPI, ACT, 900>(p, tiles_m, tiles_n, m_total, s);
-            case 901: return launch_256p_abl<EPI, ACT, 901>(p, tiles_m, tiles_n, m_total, s);
-            case 898: return launch_256p_abl<EPI, ACT, 898>(p, tiles_m, tiles_n, m_total, s);
-            case 1792: return launch_256p_abl<EPI, ACT, 1792>(p, tiles_m, tiles_n, m_total, s);
-            case 2816: return launch_256p_abl<EPI, ACT, 2816>(p, tiles_m, tiles_n, m_total, s);
-            case 1920: return launch_256p_abl<EPI, ACT, 1920>(p, tiles_m, tiles_n, m_total, s);
-            case 1280: return launch_256p_abl<EPI, ACT, 1280>(p, tiles_m, tiles_n, m_total, s);
+            case 256: return launch_256p_abl<EPI, ACT, 256>(p, tiles_m, tiles_n, m_total, s);
             case 384: return launch_256p_abl<EPI, ACT, 384>(p, tiles_m, tiles_n, m_total, s);
-            case 896: return launch_256p_abl<EPI, ACT, 896>(p, tiles_m, tiles_n, m_total, s);
-            case 128: return launch_256p_abl<EPI, ACT, 128>(p, tiles_m, tiles_n, m_total, s);
-            case 144: return launch_256p_abl<EPI, ACT, 144>(p, tiles_m, tiles_n, m_total, s);
-            case 130: return launch_256p_abl<EPI, ACT, 130>(p, tiles_m, tiles_n, m_total, s);
+            case 512: return launch_256p_abl<EPI, ACT, 512>(p, tiles_m, tiles_n, m_total, s);
+            case 1024: return launch_256p_abl<EPI, ACT, 1024>(p, tiles_m, tiles_n, m_total, s);
+            case 2048: return launch_256p_abl<EPI, ACT, 2048>(p, tiles_m, tiles_n, m_total, s);
+            case 2176: return launch_256p_abl<EPI, ACT, 2176>(p, tiles_m, tiles_n, m_total, s);
+            case 1152: return launch_256p_abl<EPI, ACT, 1152>(p, tiles_m, tiles_n, m_total, s);
             case 14: return launch_256p_abl<EPI, ACT, 14>(p, tiles_m, tiles_n, m_total, s);
             case 12: return launch_256p_abl<EPI, ACT, 12>(p, tiles_m, tiles_n, m_total, s);
             default: break;

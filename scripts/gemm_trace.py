@@ -12,7 +12,7 @@ dev = torch.device("cuda:0")
 M = 128 * 257
 shapes = [("qkv", M, 3072, 1024, 0), ("out", M, 1024, 1024, 1), ("fc1", M, 4096, 1024, 2), ("fc2", M, 1024, 4096, 1),
           ("fc2_dgrad", M, 4096, 1024, 3), ("plain_f32", M, 1024, 1024, 4), ("cube8k", 8192, 8192, 8192, 0)]
-lib.rvlm_k_gemm_set_variant(1)
+lib.rvlm_k_gemm_set_variant(int(os.environ.get("GEMM_VARIANT", "2")))
 if os.environ.get("GEMM_ABLATE"):
     lib.rvlm_k_gemm_set_ablate(int(os.environ["GEMM_ABLATE"]))
 only = os.environ.get("TRACE_ONLY")
