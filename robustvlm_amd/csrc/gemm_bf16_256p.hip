@@ -157,7 +157,7 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
     // every SIMD one wave is in its MFMAs while its partner is in the queue.  The B half is waves 4-7: the
     // second-dispatched wave of a SIMD loses MFMA arbitration to its partner anyway, so its early stall costs least
     // (ABL & 512 swaps the halves: measured +1-2 % against +4-6 %).
-#ifdef RVLM_GEMM_LOCKSTEP            // A/B build of the whole library with the lockstep form (scripts/trip_r2s.sh)
+#ifdef RVLM_GEMM_LOCKSTEP            // A/B build of the whole library with the schedule this round started from (scripts/trip_r2s.sh)
     constexpr bool SPLIT = false;
 #else
     constexpr bool SPLIT = (ABL & 256) == 0 && (ABL & 8) == 0;   // (the register-path experiment keeps the lockstep form)
@@ -168,11 +168,11 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
     // instead of 6 in a row between two groups of 8 MFMAs: with the role split each wave runs alone on its SIMD while
     // its partner sits in the texture queue or at the barrier, and every non-MFMA issue slot between groups is then
     // pipe idle time.  ABL & 1024 restores the grouped form.
+#ifdef RVLM_GEMM_LOCKSTEP
+    constexpr bool FINE = false;
+#else
     constexpr bool FINE = (ABL & 1024) == 0;
-    // ... and the 8 DMA pieces of a wave likewise, one behind each MFMA of a k-slice (the B half's in the slice right
-    // after the barrier, the A half's in the last slice before it): the wave still waits ~60 cycles in the texture queue
-    // per piece, but its own MFMAs run meanwhile.  ABL & 2048 restores the burst.
-    constexpr bool PIECEWISE = SPLIT && FINE && (ABL & 2048) != 0;   // (experiment: off in production)
+#endif
     // phase offset (performance only): with every workgroup in lockstep the epilogues' HBM bursts coincide chip-wide.  On
     // by default for the fc2 dgrad only (8 tiles per workgroup, epilogue reads act' from HBM: -3 %); measured neutral to
     // slightly negative for the other epilogues (2 tiles per workgroup: the offset costs as much tail as it hides)
@@ -235,8 +235,6 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
         a_loff[jp] = ((lane >> 3) * lda + clog * 8) * 2;
         b_loff[jp] = ((lane >> 3) * ldb + clog * 8) * 2;
     }
-    const bool own_b = SPLIT ? ((w < 4) != SWAP) : true, own_a = SPLIT ? !own_b : true;
-    const bool lane_own_b = SPLIT ? ((threadIdx.x < 256) != SWAP) : true, lane_own_a = SPLIT ? !lane_own_b : true;
     const int wrow = SPLIT ? (w & 3) * 64 : w * 32;     // first row (of each 256-row half) this wave requests
     const int stage_wave_off = wrow * 128;
     // cursors: next stage to request = K-step a_kt of this workgroup's tile number a_ti (likewise b_*)
@@ -255,11 +253,14 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) { pendA[j] = sink; pendB[j] = sink; }
     }
+    // The tile loop exists twice, once per role (ROLE 1 = A half, 2 = B half; 0 = lockstep form, every wave both): a wave
+    // picks its copy once, so inside the loop the role is a compile-time fact and costs no branch.
+    auto run = [&](auto role_c) __attribute__((always_inline)) {
+    constexpr int ROLE = decltype(role_c)::value;
+    constexpr bool own_a = ROLE != 2, own_b = ROLE != 1;
     // one DMA piece (8 rows x 128 B per wave instruction) of the next A / B stage, and the cursor step behind its last
     auto a_piece = [&](int j) __attribute__((always_inline)) {
-        // (the role test is a per-LANE predicate on purpose: an EXEC-masked region keeps the MFMA groups around it in one
-        // block, a scalar branch between MFMAs made hipcc copy accumulators around and spill)
-        if ((ABL & 1) || !(lane_own_a && a_ti < ntw)) return;
+        if ((ABL & 1) || !own_a || a_ti >= ntw) return;
         __attribute__((address_space(3))) char* dst =
             (__attribute__((address_space(3))) char*)lds + (a_slot * PA_SLOT + stage_wave_off);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
@@ -280,7 +281,7 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
         return true;
     };
     auto b_piece = [&](int j) __attribute__((always_inline)) {
-        if ((ABL & 1) || !(lane_own_b && b_ti < ntw)) return;
+        if ((ABL & 1) || !own_b || b_ti >= ntw) return;
         __attribute__((address_space(3))) char* dst =
             (__attribute__((address_space(3))) char*)lds + (PB_BASE + b_slot * PB_SLOT + stage_wave_off);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
@@ -373,8 +374,8 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
     };
     // 8 MFMAs of one k-slice (fragments a, b) with the 6 fragment reads of slice kk of stage (sa, sb) into (na, nb)
     // issued between them
-    auto mma_lf = [&](const i32x4 (&a)[4], const i32x4 (&b)[2], int sa, int sb, int kk, i32x4 (&na)[4], i32x4 (&nb)[2],
-                      int pieces /* 0 none, 1 the B stage, 2 the A stage */) __attribute__((always_inline)) {
+    auto mma_lf = [&](const i32x4 (&a)[4], const i32x4 (&b)[2], int sa, int sb, int kk, i32x4 (&na)[4], i32x4 (&nb)[2])
+                      __attribute__((always_inline)) {
         int oa = sa * PA_SLOT, ob = sb * PB_SLOT + ab_delta;
         asm volatile("" : "+s"(oa), "+s"(ob));
         const unsigned aa = fa[kk] + oa, bb = fa[kk] + ob;
@@ -399,8 +400,6 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
                         asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(na[3]) : "v"(aa));
                     }
                 }
-                if (pieces == 1) b_piece(i * 2 + j);
-                if (pieces == 2) a_piece(i * 2 + j);
                 __builtin_amdgcn_sched_barrier(0);
             }
     };
@@ -458,20 +457,13 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
             if (FINE) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
-                mma_lf(a0, b0, ca_slot, cb_slot, 1, a1, b1, 0);
+                mma_lf(a0, b0, ca_slot, cb_slot, 1, a1, b1);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
-                mma_lf(a1, b1, ca_slot, cb_slot, 2, a0, b0, 0);
+                mma_lf(a1, b1, ca_slot, cb_slot, 2, a0, b0);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
-                if (PIECEWISE) {
-                    // (nothing is free yet in the very first step: compile-time first_of_tile, so the extra body exists
-                    // only in the first step's copy)
-                    if (first_of_tile && ti == 0) { mma_lf(a0, b0, ca_slot, cb_slot, 3, a1, b1, 0); a_ahead = false; }
-                    else { mma_lf(a0, b0, ca_slot, cb_slot, 3, a1, b1, 2); a_ahead = a_advance(); }
-                } else {
-                    mma_lf(a0, b0, ca_slot, cb_slot, 3, a1, b1, 0);
-                }
+                mma_lf(a0, b0, ca_slot, cb_slot, 3, a1, b1);
             } else {
                 load_frags(ca_slot, cb_slot, 1, a1, b1);
                 asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
@@ -495,7 +487,7 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
             if (SPLIT) {
                 // the A half requests the stage for the slot freed at the PREVIOUS barrier (nothing is free yet in the
                 // very first step); its 8 youngest pieces may stay in flight, the B half waits for all of its own
-                if (!PIECEWISE) a_ahead = (first_of_tile && ti == 0) ? false : issue_a();
+                a_ahead = (first_of_tile && ti == 0) ? false : issue_a();
                 if (own_a && a_ahead) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             } else if (a_ahead && !(first_of_tile && ti > 0)) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
@@ -513,7 +505,7 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
                 // (B is deferred past the epilogue in a tile's last step: staging uses that slot)
                 if (!last_of_tile) {
                     if (!FINE) load_frags(na_slot, nb_slot, 0, a0, b0);     // (FINE: among the caller's 8 MFMAs)
-                    if (!PIECEWISE) issue_b();                              // (PIECEWISE: likewise)
+                    issue_b();
                 }
             } else {
                 if (!last_of_tile) issue_b();
@@ -526,16 +518,14 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
         };
         k_step(true, false);
         __builtin_amdgcn_sched_barrier(0);
-        // + the next stage's first fragments (its barrier is behind us) and the B half's requests
-        if (PIECEWISE) { mma_lf(a1, b1, ca_slot, cb_slot, 0, a0, b0, 1); b_advance(); }
-        else if (FINE) mma_lf(a1, b1, ca_slot, cb_slot, 0, a0, b0, 0);
+        // + the next stage's first fragments (its barrier is behind us)
+        if (FINE) mma_lf(a1, b1, ca_slot, cb_slot, 0, a0, b0);
         else mma(a1, b1);
         __builtin_amdgcn_sched_barrier(0);
         for (int kt = 1; kt < nk - 1; ++kt) {
             k_step(false, false);
             __builtin_amdgcn_sched_barrier(0);
-            if (PIECEWISE) { mma_lf(a1, b1, ca_slot, cb_slot, 0, a0, b0, 1); b_advance(); }
-            else if (FINE) mma_lf(a1, b1, ca_slot, cb_slot, 0, a0, b0, 0);
+            if (FINE) mma_lf(a1, b1, ca_slot, cb_slot, 0, a0, b0);
             else mma(a1, b1);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -692,6 +682,10 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
         unsigned long long* t = p.trace + ((long)blockIdx.x * 8 + w) * 4;
         t[0] = wt_vm; t[1] = wt_bar; t[2] = wt_dma; t[3] = __builtin_amdgcn_s_memtime() - wt_begin;
     }
+    };
+    if (!SPLIT) run(std::integral_constant<int, 0>{});
+    else if ((w < 4) != SWAP) run(std::integral_constant<int, 2>{});
+    else run(std::integral_constant<int, 1>{});
     if ((ABL & 15) == 0 && m_total > p.M) strip_tail<EPI, ACT>(p, p.M, m_total, lds, w, lane);
     if (!(ABL & 128) && p.trace && w == 0 && lane == 0) {
         p.trace[((long)blockIdx.x * 8 + 7) * 4 + 2] = __builtin_amdgcn_s_memtime();
@@ -743,8 +737,6 @@ static int launch_256p_act(const GemmBf16& p, int tiles_m, int tiles_n, int m_to
             case 384: return launch_256p_abl<EPI, ACT, 384>(p, tiles_m, tiles_n, m_total, s);
             case 512: return launch_256p_abl<EPI, ACT, 512>(p, tiles_m, tiles_n, m_total, s);
             case 1024: return launch_256p_abl<EPI, ACT, 1024>(p, tiles_m, tiles_n, m_total, s);
-            case 2048: return launch_256p_abl<EPI, ACT, 2048>(p, tiles_m, tiles_n, m_total, s);
-            case 2176: return launch_256p_abl<EPI, ACT, 2176>(p, tiles_m, tiles_n, m_total, s);
             case 1152: return launch_256p_abl<EPI, ACT, 1152>(p, tiles_m, tiles_n, m_total, s);
             case 14: return launch_256p_abl<EPI, ACT, 14>(p, tiles_m, tiles_n, m_total, s);
             case 12: return launch_256p_abl<EPI, ACT, 12>(p, tiles_m, tiles_n, m_total, s);
