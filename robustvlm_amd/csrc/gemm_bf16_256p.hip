@@ -430,17 +430,19 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
     const int r0 = lane >> 3;                                         // flush: row r0 + 8*it, 16-B slot lane & 7
 
     auto stamp = [&](int ti, int k) {   // optional per-tile timeline (test hook rvlm_k_gemm_set_trace), wave 0 only
-        if (!(ABL & 128) && p.trace && w == 0 && ti < 7) {
+        if (!(ABL & (128 | 2048)) && p.trace && w == 0 && ti < 7) {
             const unsigned long long t = __builtin_amdgcn_s_memtime();
             if (lane == 0) p.trace[((long)blockIdx.x * 8 + ti) * 4 + k] = t;
         }
     };
-    if (!(ABL & 128) && p.trace && w == 0 && lane == 0) {   // clock calibration: s_memtime vs the constant 100 MHz s_memrealtime
+    if (!(ABL & (128 | 2048)) && p.trace && w == 0 && lane == 0) {   // clock calibration: s_memtime vs the constant 100 MHz s_memrealtime
         p.trace[((long)blockIdx.x * 8 + 7) * 4 + 0] = __builtin_amdgcn_s_memtime();
         p.trace[((long)blockIdx.x * 8 + 7) * 4 + 1] = __builtin_amdgcn_s_memrealtime();
     }
 
     unsigned long long wt_vm = 0, wt_bar = 0, wt_dma = 0, wt_mark = 0;
+    unsigned long long tl[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // (ABL & 2048) stamps: barrier passed, B requested, slice-3 MFMAs
+    int gstep = 0;                                          // issued, slices 0 / 1 / 2, A requested, operands landed
     const unsigned long long wt_begin = (ABL & 128) ? __builtin_amdgcn_s_memtime() : 0ull;
     for (int ti = 0; ti < ntw; ++ti) {
         int m0, n0;
@@ -458,12 +460,15 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 mma_lf(a0, b0, ca_slot, cb_slot, 1, a1, b1);
+                if (ABL & 2048) tl[3] = __builtin_amdgcn_s_memtime();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 mma_lf(a1, b1, ca_slot, cb_slot, 2, a0, b0);
+                if (ABL & 2048) tl[4] = __builtin_amdgcn_s_memtime();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 mma_lf(a0, b0, ca_slot, cb_slot, 3, a1, b1);
+                if (ABL & 2048) tl[5] = __builtin_amdgcn_s_memtime();
             } else {
                 load_frags(ca_slot, cb_slot, 1, a1, b1);
                 asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
@@ -488,8 +493,19 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
                 // the A half requests the stage for the slot freed at the PREVIOUS barrier (nothing is free yet in the
                 // very first step); its 8 youngest pieces may stay in flight, the B half waits for all of its own
                 a_ahead = (first_of_tile && ti == 0) ? false : issue_a();
+                if (ABL & 2048) tl[6] = __builtin_amdgcn_s_memtime();
                 if (own_a && a_ahead) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                if (ABL & 2048) {
+                    tl[7] = __builtin_amdgcn_s_memtime();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    // timeline of K-steps 8 and 9 of the first tile, every wave of workgroup 0: [wave][step][stamp]
+                    if (p.trace && blockIdx.x == 0 && ti == 0 && (gstep == 8 || gstep == 9) && lane == 0) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) p.trace[(w * 2 + (gstep - 8)) * 8 + i] = tl[i];
+                    }
+                    ++gstep;
+                }
             } else if (a_ahead && !(first_of_tile && ti > 0)) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             if (ABL & 128) { tw1 = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -501,6 +517,7 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
                 wt_vm += tw1 - tw0; wt_bar += tw2 - tw1; wt_mark = tw2;
             }
             if (first_of_tile) stamp(ti, 1);
+            if (ABL & 2048) tl[0] = __builtin_amdgcn_s_memtime();
             if (SPLIT) {
                 // (B is deferred past the epilogue in a tile's last step: staging uses that slot)
                 if (!last_of_tile) {
@@ -512,6 +529,7 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
                 a_ahead = issue_a();
             }
             if (ABL & 128) { wt_dma += __builtin_amdgcn_s_memtime() - wt_mark; }
+            if (ABL & 2048) tl[1] = __builtin_amdgcn_s_memtime();
             if (!SPLIT && !FINE && !last_of_tile) load_frags(na_slot, nb_slot, 0, a0, b0);
             ca_slot = na_slot;
             cb_slot = nb_slot;
@@ -527,6 +545,7 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
             __builtin_amdgcn_sched_barrier(0);
             if (FINE) mma_lf(a1, b1, ca_slot, cb_slot, 0, a0, b0);
             else mma(a1, b1);
+            if (ABL & 2048) tl[2] = __builtin_amdgcn_s_memtime();
             __builtin_amdgcn_sched_barrier(0);
         }
         const int stage_slot = cb_slot;   // B slot of the tile's last stage = epilogue staging area after its barrier
@@ -687,7 +706,7 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
     else if ((w < 4) != SWAP) run(std::integral_constant<int, 2>{});
     else run(std::integral_constant<int, 1>{});
     if ((ABL & 15) == 0 && m_total > p.M) strip_tail<EPI, ACT>(p, p.M, m_total, lds, w, lane);
-    if (!(ABL & 128) && p.trace && w == 0 && lane == 0) {
+    if (!(ABL & (128 | 2048)) && p.trace && w == 0 && lane == 0) {
         p.trace[((long)blockIdx.x * 8 + 7) * 4 + 2] = __builtin_amdgcn_s_memtime();
         p.trace[((long)blockIdx.x * 8 + 7) * 4 + 3] = __builtin_amdgcn_s_memrealtime();
     }
@@ -737,6 +756,8 @@ static int launch_256p_act(const GemmBf16& p, int tiles_m, int tiles_n, int m_to
             case 384: return launch_256p_abl<EPI, ACT, 384>(p, tiles_m, tiles_n, m_total, s);
             case 512: return launch_256p_abl<EPI, ACT, 512>(p, tiles_m, tiles_n, m_total, s);
             case 1024: return launch_256p_abl<EPI, ACT, 1024>(p, tiles_m, tiles_n, m_total, s);
+            case 2048: return launch_256p_abl<EPI, ACT, 2048>(p, tiles_m, tiles_n, m_total, s);
+            case 2053: return launch_256p_abl<EPI, ACT, 2053>(p, tiles_m, tiles_n, m_total, s);
             case 1152: return launch_256p_abl<EPI, ACT, 1152>(p, tiles_m, tiles_n, m_total, s);
             case 14: return launch_256p_abl<EPI, ACT, 14>(p, tiles_m, tiles_n, m_total, s);
             case 12: return launch_256p_abl<EPI, ACT, 12>(p, tiles_m, tiles_n, m_total, s);
