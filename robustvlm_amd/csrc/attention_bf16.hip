@@ -21,6 +21,9 @@
 #include "kernels.h"
 
 namespace rvlm {
+// element strides of the (image, head) blocks: token-major [B][S][3W] (b = S*ld, h = 64) or head-blocked [3][B*H][S][64]
+struct AttnLayout { long qkv_b, qkv_h, o_b, o_h; };
+
 
 typedef __attribute__((address_space(3))) char lds_char;
 
@@ -237,7 +240,7 @@ attn_fwd_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict__ o,
 template <int NK>
 __global__ void __launch_bounds__(NK * 64, 4)    // 4 waves per SIMD = two 8-wave workgroups per CU (128 VGPRs)
 attn_fwd_odd_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict__ o, long ldo,
-                    float* __restrict__ lse2, int H, int W, float scale_log2) {
+                    float* __restrict__ lse2, int H, long W, float scale_log2, AttnLayout lay) {
     constexpr int S = 32 * NK + 1, Sp = 32 * NK + 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Kt = smem;
@@ -247,7 +250,7 @@ attn_fwd_odd_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict_
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const bf16_t* base = qkv + (long)b * S * ld + h * 64;
+    const bf16_t* base = qkv + (long)b * lay.qkv_b + (long)h * lay.qkv_h;   // (W = element offset from Q to K, K to V)
     stage_tile(Kt, base + W, ld, S, Sp, w, NK, lane);
     stage_tile(Vt, base + 2 * W, ld, S, Sp, w, NK, lane);
     __syncthreads();
@@ -325,7 +328,7 @@ attn_fwd_odd_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict_
         odd_key(qf, m, l, oacc);
         const float ltot = l + __shfl_xor(l, 32, 64);
         const float inv = 1.0f / ltot;
-        bf16_t* orow = o + ((long)b * S + q) * ldo + h * 64;
+        bf16_t* orow = o + (long)b * lay.o_b + (long)h * lay.o_h + (long)q * ldo;
         // A lane holds 4 consecutive d per (dt, g) and its partner lane ^ 32 the next 4: v_permlane32_swap pairs the two
         // 8-byte halves of the even chunk on the lower lanes and of the odd chunk on the upper lanes, so that the row leaves
         // as four 16-byte stores per lane instead of eight 8-byte ones (the store tail of this kernel is issue-bound).
@@ -404,7 +407,7 @@ attn_fwd_odd_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict_
             L = fmaf(mrg[i * 66 + 1], c, L);
             O = fmaf(mrg[i * 66 + 2 + lane], c, O);
         }
-        o[((long)b * S + S - 1) * ldo + h * 64 + lane] = (bf16_t)(O / L);
+        o[(long)b * lay.o_b + (long)h * lay.o_h + (long)(S - 1) * ldo + lane] = (bf16_t)(O / L);
         if (lane == 0 && lse2) lse2[((long)b * H + h) * Sp + S - 1] = M + log2f(L);
     }
 }
@@ -641,8 +644,8 @@ template <int NK>
 __global__ void __launch_bounds__(NK * 64)
 attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __restrict__ o, long ldo,
                       const bf16_t* __restrict__ d_o, long lddo, const float* __restrict__ lse2,
-                      bf16_t* __restrict__ dqkv, long lddq, int H, int S, int W, float scale, float scale_log2,
-                      unsigned long long* __restrict__ trace, int desync) {
+                      bf16_t* __restrict__ dqkv, long lddq, int H, int S, long W, float scale, float scale_log2,
+                      unsigned long long* __restrict__ trace, int desync, AttnLayout lay) {
     // optional phase timeline (RVLM_ATTN_TRACE=1: 5 s_memtime stamps per workgroup into the dsum scratch buffer)
     auto stamp = [&](int k) {
         if (trace && threadIdx.x == 0) trace[(long)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memtime();
@@ -670,9 +673,9 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const bf16_t* base = qkv + (long)b * S * ld + h * 64;
-    const bf16_t* dob = d_o + (long)b * S * lddo + h * 64;
-    const bf16_t* ob = o + (long)b * S * ldo + h * 64;
+    const bf16_t* base = qkv + (long)b * lay.qkv_b + (long)h * lay.qkv_h;
+    const bf16_t* dob = d_o + (long)b * lay.o_b + (long)h * lay.o_h;
+    const bf16_t* ob = o + (long)b * lay.o_b + (long)h * lay.o_h;
 
     // ---- phase 0: stage Q, dO, K, V; lse -------------------------------------------------------------------
     stage_tile(Qt, base, ld, S, Sp, w, NK, lane);
@@ -802,7 +805,7 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
         rd[r] = row * 64 + (((4 * qb + (i16 & 3)) ^ ((row >> 2) & 7)) << 3);
     }
     const float4 ke4 = *(const float4*)(Ke + 16 * db + 4 * G);        // k[odd key][d], d = 16 db + 4 G + 0..3
-    bf16_t* dq_out = dqkv + (long)b * S * lddq + h * 64 + 16 * db + 4 * G;
+    bf16_t* dq_out = dqkv + (long)b * lay.qkv_b + (long)h * lay.qkv_h + 16 * db + 4 * G;
     f32x16 dk[2] = {zero16(), zero16()}, dv[2] = {zero16(), zero16()};
     for (int qt = 0; qt < NT; ++qt) {
         f32x16 s = zero16(), dp = zero16();
@@ -890,7 +893,7 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
     {
         lds_char* tile = (lds_char*)area + 2 * NK * FB2_TILE + w * 4096;
         const int r8 = lane >> 3, c8 = lane & 7;
-        bf16_t* kbase = dqkv + ((long)b * S + w * 32) * lddq + W + h * 64 + c8 * 8;
+        bf16_t* kbase = dqkv + (long)b * lay.qkv_b + (long)h * lay.qkv_h + (long)(w * 32) * lddq + W + c8 * 8;
 #pragma unroll
         for (int which = 0; which < 2; ++which) {
 #pragma unroll
@@ -918,7 +921,7 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
         float ak = 0.0f, av = 0.0f;
 #pragma unroll
         for (int ww = 0; ww <= NK; ++ww) { ak += KVe[(ww * 2 + 0) * 64 + lane]; av += KVe[(ww * 2 + 1) * 64 + lane]; }
-        bf16_t* krow = dqkv + ((long)b * S + SE) * lddq + W + h * 64;
+        bf16_t* krow = dqkv + (long)b * lay.qkv_b + (long)h * lay.qkv_h + (long)SE * lddq + W;
         krow[lane] = (bf16_t)(ak * scale);
         krow[W + lane] = (bf16_t)av;
     }
@@ -958,7 +961,17 @@ int attn_fwd_bf16(const bf16_t* qkv, long ldqkv, bf16_t* o, long ldo, float* lse
         constexpr int NK = 8;
         const size_t lds_o = (size_t)(32 * NK + 32) * 256 + (size_t)NK * 66 * sizeof(float) + (size_t)NK * 64;
         if ((rc = set_lds(attn_fwd_odd_kernel<NK>, lds_o))) return rc;
-        hipLaunchKernelGGL((attn_fwd_odd_kernel<NK>), dim3(B * H), dim3(NK * 64), lds_o, s, qkv, ldqkv, o, ldo, lse, H, W, sl2);
+        static int hm = -1;      // timing probe: read the same buffers as head-blocked [3][B*H][S][64] / [B*H][S][64]
+        if (hm < 0) { const char* e = getenv("RVLM_ATTN_HM"); hm = e ? atoi(e) : 0; }
+        if (hm) {
+            const AttnLayout lay = {(long)H * S * 64, (long)S * 64, (long)H * S * 64, (long)S * 64};
+            hipLaunchKernelGGL((attn_fwd_odd_kernel<NK>), dim3(B * H), dim3(NK * 64), lds_o, s, qkv, 64L, o, 64L, lse, H,
+                               (long)B * H * S * 64, sl2, lay);
+        } else {
+            const AttnLayout lay = {(long)S * ldqkv, 64L, (long)S * ldo, 64L};
+            hipLaunchKernelGGL((attn_fwd_odd_kernel<NK>), dim3(B * H), dim3(NK * 64), lds_o, s, qkv, ldqkv, o, ldo, lse, H,
+                               (long)W, sl2, lay);
+        }
         RVLM_CHECK_LAUNCH();
         return RVLM_OK;
     }
@@ -994,8 +1007,19 @@ int attn_bwd_bf16(const bf16_t* qkv, long ldqkv, const bf16_t* o, long ldo, cons
         static int trace = -1, desync = -1;
         if (trace < 0) { const char* e = getenv("RVLM_ATTN_TRACE"); trace = e ? atoi(e) : 0; }
         if (desync < 0) { const char* e = getenv("RVLM_ATTN_DESYNC"); desync = e ? atoi(e) : 5; }
-        hipLaunchKernelGGL((attn_bwd_fused_kernel<NK>), dim3(B * H), dim3(NK * 64), lds_f, s, qkv, ldqkv, o, ldo, d_o, lddo,
-                           lse, dqkv, lddqkv, H, S, W, scale, sl2, trace ? (unsigned long long*)dsum_scratch : nullptr, desync);
+        static int hm = -1;
+        if (hm < 0) { const char* e = getenv("RVLM_ATTN_HM"); hm = e ? atoi(e) : 0; }
+        if (hm) {
+            const AttnLayout lay = {(long)H * S * 64, (long)S * 64, (long)H * S * 64, (long)S * 64};
+            hipLaunchKernelGGL((attn_bwd_fused_kernel<NK>), dim3(B * H), dim3(NK * 64), lds_f, s, qkv, 64L, o, 64L, d_o, 64L,
+                               lse, dqkv, 64L, H, S, (long)B * H * S * 64, scale, sl2,
+                               trace ? (unsigned long long*)dsum_scratch : nullptr, desync, lay);
+        } else {
+            const AttnLayout lay = {(long)S * ldqkv, 64L, (long)S * ldo, 64L};
+            hipLaunchKernelGGL((attn_bwd_fused_kernel<NK>), dim3(B * H), dim3(NK * 64), lds_f, s, qkv, ldqkv, o, ldo, d_o, lddo,
+                               lse, dqkv, lddqkv, H, S, (long)W, scale, sl2,
+                               trace ? (unsigned long long*)dsum_scratch : nullptr, desync, lay);
+        }
         RVLM_CHECK_LAUNCH();
         return RVLM_OK;
     }
