@@ -645,7 +645,7 @@ __global__ void __launch_bounds__(NK * 64)
 attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __restrict__ o, long ldo,
                       const bf16_t* __restrict__ d_o, long lddo, const float* __restrict__ lse2,
                       bf16_t* __restrict__ dqkv, long lddq, int H, int S, long W, float scale, float scale_log2,
-                      unsigned long long* __restrict__ trace, int desync, AttnLayout lay) {
+                      unsigned long long* __restrict__ trace, int desync, AttnLayout lay, int prefetch) {
     // optional phase timeline (RVLM_ATTN_TRACE=1: 5 s_memtime stamps per workgroup into the dsum scratch buffer)
     auto stamp = [&](int k) {
         if (trace && threadIdx.x == 0) trace[(long)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memtime();
@@ -786,6 +786,29 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
     }
     __syncthreads();   // K / V tiles are dead: the area becomes the partial slots; Ds / Pe / De are complete
     stamp(2);
+    // Experiment (RVLM_ATTN_PREFETCH=n, default off): cache warm-up for the workgroup that follows this one on the chip
+    // (blockIdx + n, the same XCD): one dword per 128-byte row of its Q, K, V, dO, O blocks, requested now that this CU's own
+    // staging is over.  A CU pulls HBM misses at only ~12 B per clock (the staging phase above: 144 KB in ~11.8 k cycles
+    // whatever the layout or the other CUs do).  Measured (profiles/r02_attn_next_wg_prefetch.log): the next staging drops
+    // to ~8 k cycles, but the misses now occupy the CU's miss path during the tile loop, whose dQ stores queue behind them
+    // (+2.4 k cycles): the kernel's wall time does not move.  The three result registers are never read; they stay
+    // allocated until the end of the kernel.
+    int pf[3] = {0, 0, 0};
+    if (prefetch > 0 && (int)blockIdx.x + prefetch < (int)gridDim.x) {
+        const int nb = ((int)blockIdx.x + prefetch) / H, nh = ((int)blockIdx.x + prefetch) % H;
+        const bf16_t* nq = qkv + (long)nb * lay.qkv_b + (long)nh * lay.qkv_h;
+        const bf16_t* ndo = d_o + (long)nb * lay.o_b + (long)nh * lay.o_h;
+        const bf16_t* no = o + (long)nb * lay.o_b + (long)nh * lay.o_h;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int idx = tid + i * NK * 64;                 // 5 blocks x S rows
+            if (idx < 5 * S) {
+                const int t = idx / S, row = idx - t * S;
+                const bf16_t* ptr = t < 3 ? nq + (long)row * ld + t * W : (t == 3 ? ndo + (long)row * lddo : no + (long)row * ldo);
+                asm volatile("global_load_dword %0, %1, off" : "=v"(pf[i]) : "v"(ptr) : "memory");
+            }
+        }
+    }
 
     // ---- phase 2: lockstep walk over the query tiles -------------------------------------------------------------
     // Per tile: S, dP (8 MFMA) -> P, dS in registers -> dS tile to LDS -> ONE barrier -> dV, dK from the registers
@@ -925,6 +948,8 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
         krow[lane] = (bf16_t)(ak * scale);
         krow[W + lane] = (bf16_t)av;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" :: "v"(pf[0]), "v"(pf[1]), "v"(pf[2]));
     stamp(4);
 }
 
@@ -1007,18 +1032,19 @@ int attn_bwd_bf16(const bf16_t* qkv, long ldqkv, const bf16_t* o, long ldo, cons
         static int trace = -1, desync = -1;
         if (trace < 0) { const char* e = getenv("RVLM_ATTN_TRACE"); trace = e ? atoi(e) : 0; }
         if (desync < 0) { const char* e = getenv("RVLM_ATTN_DESYNC"); desync = e ? atoi(e) : 5; }
-        static int hm = -1;
+        static int hm = -1, prefetch = -1;
         if (hm < 0) { const char* e = getenv("RVLM_ATTN_HM"); hm = e ? atoi(e) : 0; }
+        if (prefetch < 0) { const char* e = getenv("RVLM_ATTN_PREFETCH"); prefetch = e ? atoi(e) : 0; }   // (measured: off)
         if (hm) {
             const AttnLayout lay = {(long)H * S * 64, (long)S * 64, (long)H * S * 64, (long)S * 64};
             hipLaunchKernelGGL((attn_bwd_fused_kernel<NK>), dim3(B * H), dim3(NK * 64), lds_f, s, qkv, 64L, o, 64L, d_o, 64L,
                                lse, dqkv, 64L, H, S, (long)B * H * S * 64, scale, sl2,
-                               trace ? (unsigned long long*)dsum_scratch : nullptr, desync, lay);
+                               trace ? (unsigned long long*)dsum_scratch : nullptr, desync, lay, prefetch);
         } else {
             const AttnLayout lay = {(long)S * ldqkv, 64L, (long)S * ldo, 64L};
             hipLaunchKernelGGL((attn_bwd_fused_kernel<NK>), dim3(B * H), dim3(NK * 64), lds_f, s, qkv, ldqkv, o, ldo, d_o, lddo,
                                lse, dqkv, lddqkv, H, S, (long)W, scale, sl2,
-                               trace ? (unsigned long long*)dsum_scratch : nullptr, desync, lay);
+                               trace ? (unsigned long long*)dsum_scratch : nullptr, desync, lay, prefetch);
         }
         RVLM_CHECK_LAUNCH();
         return RVLM_OK;
