@@ -40,7 +40,6 @@ int rvlm_k_gemm_set_variant(int v);
 #define RVLM_GEMM_K_256Q 8        /* 4-wave persistent kernel (EXPERIMENTAL builds only) */
 #define RVLM_GEMM_K_SPLITK 16     /* split-K slabs on the 128x128 kernel + splitk_reduce_kernel */
 #define RVLM_GEMM_K_STRIP 32      /* remainder rows computed by the persistent kernel's strip phase (same launch) */
-#define RVLM_GEMM_K_ODDROW 64     /* M % 257 == 0: the persistent kernel ran 257-row tiles (no remainder rows) */
 int rvlm_k_gemm_last_kernels(void);
 /* persistent 256x256 kernel: device buffer of 256*8*4 uint64 receiving per-tile s_memtime stamps (tile start, first
  * K-step done, mainloop done, epilogue issued); NULL switches tracing off */

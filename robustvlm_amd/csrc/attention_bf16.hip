@@ -948,8 +948,10 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
         krow[lane] = (bf16_t)(ak * scale);
         krow[W + lane] = (bf16_t)av;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("" :: "v"(pf[0]), "v"(pf[1]), "v"(pf[2]));
+    if (prefetch > 0) {     // (only then: a wave that ends with its stores in flight must not wait for them)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("" :: "v"(pf[0]), "v"(pf[1]), "v"(pf[2]));
+    }
     stamp(4);
 }
 

@@ -185,7 +185,6 @@ splitk_reduce_kernel(const float* __restrict__ slabs, int splitk, GemmBf16 p) {
 
 
 int gemm_bf16_nt_256p(const GemmBf16& p, int* rows_done, hipStream_t s);
-bool gemm_256p_last_odd();
 #ifdef RVLM_EXPERIMENTAL_GEMM   // ablation kernels (make EXPERIMENTAL=1): not part of the shipped library
 int gemm_bf16_nt_256(const GemmBf16& p, int* rows_done, hipStream_t s);
 int gemm_bf16_nt_256q(const GemmBf16& p, int* rows_done, hipStream_t s);
@@ -359,10 +358,6 @@ int gemm_bf16_nt(const GemmBf16& p, hipStream_t s) {
         const float fill = (float)t256 / (float)(((t256 + 255) / 256) * 256);
         // deep-K tiles amortise the persistent kernel's per-tile cost: there only a really empty chip (< 45 %) switches
         sparse = variant != 3 && (fill < 0.45f || (fill < min_fill && p.K <= 1024));
-        // M = 257 x images (the ViT-L/14 token count): every image is one 257-row tile row of the persistent kernel, and a
-        // row's arithmetic then does not depend on the batch size of the call - which it would if small batches went to the
-        // 128x128 kernel (tests/test_gpu_fullsize.py: a 16-image shard against the same images inside B = 128)
-        if (p.M % 257 == 0 && p.batch_m_rows == 0) sparse = false;
     }
     if (variant != 0 && gemm_persist() && !small_m && !sparse) {
         int rc;
@@ -373,7 +368,7 @@ int gemm_bf16_nt(const GemmBf16& p, hipStream_t s) {
 #endif
         {
             rc = gemm_bf16_nt_256p(p, &done, s);
-            if (done) g_last_kernels |= RVLM_GEMM_K_PERSISTENT | (gemm_256p_last_odd() ? RVLM_GEMM_K_ODDROW : done > (p.M / 256) * 256 ? RVLM_GEMM_K_STRIP : 0);
+            if (done) g_last_kernels |= RVLM_GEMM_K_PERSISTENT | (done > (p.M / 256) * 256 ? RVLM_GEMM_K_STRIP : 0);
         }
         if (rc) return rc;
         if (done >= p.M) return RVLM_OK;

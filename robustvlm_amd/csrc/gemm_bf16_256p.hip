@@ -210,7 +210,7 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
         const int group_size = p.group_m * tiles_n;
         const int first_m = (t / group_size) * p.group_m;
         const int gm = min(tiles_m - first_m, p.group_m);
-        m0 = __builtin_amdgcn_readfirstlane((first_m + (t % group_size) % gm) * (P_M + p.odd_row));
+        m0 = __builtin_amdgcn_readfirstlane((first_m + (t % group_size) % gm) * P_M);
         n0 = __builtin_amdgcn_readfirstlane(((t % group_size) / gm) * P_N);
     };
     const int nk = p.K / P_K;
@@ -258,51 +258,6 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
     auto run = [&](auto role_c) __attribute__((always_inline)) {
     constexpr int ROLE = decltype(role_c)::value;
     constexpr bool own_a = ROLE != 2, own_b = ROLE != 1;
-    // ---- the 257th row of a tile (p.odd_row: M = 257 x tile rows, e.g. 256 patch tokens + the class token of one image
-    // per tile row, so the encoder's M = 257 B has no remainder rows).  Rows 0..255 of the tile are the MFMA tile; row 256
-    // is a dot product of its 64 A values per K-step with the B fragments waves 0-3 already hold in registers for their
-    // MFMAs (lane (l31, hi) of wave wn: column 64 wn + 32 j + l31, k = 16 kk + 8 hi + 0..7 of slice kk) - 32
-    // v_dot2_f32_bf16 per K-step in the waves that otherwise wait ~700 cycles at the barrier.  The row's 128 B per K-step
-    // come by one buffer_load_dword per wave (lane i = dword i), requested a step ahead and older than the A burst, so
-    // the step's counted vmcnt covers it; v_readlane spreads the dwords.  Always compiled into the A role (no branch
-    // between MFMAs): without p.odd_row the loads read row 0 of the tile and the result is dropped.
-    constexpr bool ODD = (ROLE == 1);
-    const i32x4 a_desc = {(int)(unsigned)(size_t)p.A, (int)(unsigned)((size_t)p.A >> 32), (int)((unsigned)((p.M - 1) * lda + p.K) * 2u),
-                          0x00020000};      // the same words make_rsrc builds (asm operand form)
-    float acc_odd[2] = {0.0f, 0.0f};
-    int va_cur = 0, va_next = 0;
-    int o_ti = 0, o_kt = 0, o_soff = 0;     // cursor of the odd row's loads: the stage AFTER the one being consumed
-    auto odd_row_off = [&](int tile) {
-        int m0, n0;
-        tile_origin(tile, m0, n0);
-        return (m0 + (p.odd_row ? P_M : 0)) * lda * 2;
-    };
-    auto odd_request = [&](int& dst) {      // dword (lane & 31) of the row's 128-B chunk of stage (o_ti, o_kt); advances the cursor
-        if (!ODD) return;
-        const int soff = __builtin_amdgcn_readfirstlane(o_soff + (o_kt + k0 >= nk ? o_kt + k0 - nk : o_kt + k0) * (P_K * 2));
-        asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(dst) : "v"((lane & 31) * 4), "s"(a_desc), "s"(soff) : "memory");
-        if (++o_kt == nk) {
-            o_kt = 0;
-            ++o_ti;
-            o_soff = odd_row_off(blockIdx.x + (o_ti < ntw ? o_ti : 0) * gridDim.x);   // (past the end: any valid row)
-        }
-    };
-    auto odd_dot = [&](int kk, const i32x4 (&b)[2]) __attribute__((always_inline)) {
-        if (!ODD) return;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int lo = __builtin_amdgcn_readlane(va_cur, kk * 8 + e), up = __builtin_amdgcn_readlane(va_cur, kk * 8 + 4 + e);
-            const int av = hi ? up : lo;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                // (hipcc 7.2: __builtin_bit_cast applied DIRECTLY to a vector element, bit_cast(bf16x2, b[j][e]), reads
-                // element 0 for every e - copy the element to a scalar first)
-                const int bw = b[j][e];
-                acc_odd[j] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, bw), __builtin_bit_cast(bf16x2, av),
-                                                             acc_odd[j], false);
-            }
-        }
-    };
     // one DMA piece (8 rows x 128 B per wave instruction) of the next A / B stage, and the cursor step behind its last
     auto a_piece = [&](int j) __attribute__((always_inline)) {
         if ((ABL & 1) || !own_a || a_ti >= ntw) return;
@@ -456,7 +411,6 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
     for (int mi = 0; mi < 4; ++mi) { init_acc(mi, 0); init_acc(mi, 1); }
 
     // ---- prologue: stages 0 and 1 complete, A of stage 2 ----
-    if (ODD) { o_soff = odd_row_off(blockIdx.x); odd_request(va_cur); }   // (older than every DMA piece below)
     issue_a(); issue_b();
     issue_a(); issue_b();
     bool a_ahead = issue_a();       // was the A half of stage g+2 requested at the previous barrier?
@@ -467,7 +421,6 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
     else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // (a single tile with two K-steps)
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (ODD) asm volatile("" : "+v"(va_cur));      // the row's first chunk has landed only now: nothing that reads it may move up
 
     i32x4 a0[4], b0[2], a1[4], b1[2];
     // lane offsets of the epilogue's coalesced accesses (bytes); one instruction = 8 rows (16 for the 64-B rows)
@@ -506,22 +459,15 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
             if (FINE) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
-                odd_request(va_next);
                 mma_lf(a0, b0, ca_slot, cb_slot, 1, a1, b1);
-                odd_dot(0, b0);
-                __builtin_amdgcn_sched_barrier(0);
                 if (ABL & 2048) tl[3] = __builtin_amdgcn_s_memtime();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 mma_lf(a1, b1, ca_slot, cb_slot, 2, a0, b0);
-                odd_dot(1, b1);
-                __builtin_amdgcn_sched_barrier(0);
                 if (ABL & 2048) tl[4] = __builtin_amdgcn_s_memtime();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 mma_lf(a0, b0, ca_slot, cb_slot, 3, a1, b1);
-                odd_dot(2, b0);
-                __builtin_amdgcn_sched_barrier(0);
                 if (ABL & 2048) tl[5] = __builtin_amdgcn_s_memtime();
             } else {
                 load_frags(ca_slot, cb_slot, 1, a1, b1);
@@ -563,7 +509,6 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
             } else if (a_ahead && !(first_of_tile && ti > 0)) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             if (ABL & 128) { tw1 = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-            if (ODD) asm volatile("" : "+v"(va_next));   // (landed with the wait above; see the prologue)
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             if (ABL & 128) {   // where a K-step's time goes (per wave, summed over the launch): operand wait, barrier wait
@@ -594,14 +539,12 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
         // + the next stage's first fragments (its barrier is behind us)
         if (FINE) mma_lf(a1, b1, ca_slot, cb_slot, 0, a0, b0);
         else mma(a1, b1);
-        odd_dot(3, b1); va_cur = va_next;
         __builtin_amdgcn_sched_barrier(0);
         for (int kt = 1; kt < nk - 1; ++kt) {
             k_step(false, false);
             __builtin_amdgcn_sched_barrier(0);
             if (FINE) mma_lf(a1, b1, ca_slot, cb_slot, 0, a0, b0);
             else mma(a1, b1);
-            odd_dot(3, b1); va_cur = va_next;
             if (ABL & 2048) tl[2] = __builtin_amdgcn_s_memtime();
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -639,36 +582,6 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
         if (EPI == EPI_BF16_DACT) { load_side(0); load_side(1); }
         __builtin_amdgcn_sched_barrier(0);
         mma(a1, b1);
-        odd_dot(3, b1); va_cur = va_next;
-        __builtin_amdgcn_sched_barrier(0);
-        if (ODD) {
-            // row 256 of the tile: the two lane halves hold the two halves of every k-slice; lanes 0..31 then own the columns
-            // n0 + 64 wn + 32 j + l31 (wm = 0 in this role).  Same epilogue arithmetic as the tile's, one element per lane.
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                float v = acc_odd[j] + __shfl_xor(acc_odd[j], 32, 64);
-                acc_odd[j] = 0.0f;
-                const int n = n0 + wn * 64 + j * 32 + l31;
-                if (p.odd_row && hi == 0) {
-                    if (p.bias) v += p.bias[n];
-                    const long o = (long)(m0 + P_M) * p.ldo + n;
-                    if (EPI == EPI_BF16) {
-                        ((bf16_t*)p.out)[o] = (bf16_t)v;
-                    } else if (EPI == EPI_F32_RESID) {
-                        ((float*)p.out)[o] = v + p.residual[o];
-                    } else if (EPI == EPI_BF16_ACT) {
-                        float av, dv;
-                        actp_pair<ACT>(v, av, dv);
-                        if (p.out_pre) p.out_pre[o] = (bf16_t)dv;
-                        ((bf16_t*)p.out)[o] = (bf16_t)av;
-                    } else if (EPI == EPI_BF16_DACT) {
-                        ((bf16_t*)p.out)[o] = (bf16_t)(v * (float)p.h_pre[o]);
-                    } else {
-                        ((float*)p.out)[o] = v;
-                    }
-                }
-            }
-        }
         __builtin_amdgcn_sched_barrier(0);
         // bias joins the accumulators here, so that its registers are free for the side-input prefetch
 #pragma unroll
@@ -804,8 +717,6 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
     }
 }
 
-static bool g_persist_last_odd = false;
-bool gemm_256p_last_odd() { return g_persist_last_odd; }   // did the last launch use 257-row tiles (test surface)
 int g_persist_ablate = 0;
 void gemm_set_ablate(int v) { g_persist_ablate = v; }
 unsigned long long* g_persist_trace = nullptr;   // [256 workgroups][8 tiles][4 stamps] or null
@@ -879,19 +790,8 @@ int gemm_bf16_nt_256p(const GemmBf16& p, int* rows_done, hipStream_t s) {
         if ((long)(p.M / p.batch_m_rows) * p.N * p.ldb * 2 >= lim) return RVLM_OK;
     }
     GemmBf16 q = p;
-    // M = 257 x rows of tiles (the encoder: 257 tokens per image): 257-row tiles, no remainder rows (see ODD in the kernel);
-    // needs the split-role schedule with fragment reads between MFMAs (not the ablation forms)
-    static int odd_on = -1;
-    if (odd_on < 0) { const char* e = getenv("RVLM_GEMM_ODD"); odd_on = e ? atoi(e) : 1; }
-#ifdef RVLM_GEMM_LOCKSTEP
-    const bool odd = false;
-#else
-    const bool odd = odd_on && p.batch_m_rows == 0 && p.M % (P_M + 1) == 0 && (g_persist_ablate & (8 | 256 | 1024)) == 0;
-#endif
-    q.odd_row = odd ? 1 : 0;
-    g_persist_last_odd = odd;
-    const int tiles_m = p.M / (P_M + q.odd_row), tiles_n = p.N / P_N;
-    q.M = odd ? p.M : tiles_m * P_M;
+    const int tiles_m = p.M / P_M, tiles_n = p.N / P_N;
+    q.M = tiles_m * P_M;
     if (q.epi == EPI_F32_RESID && !q.residual) q.epi = EPI_F32;
     // the remainder rows ride along in the same launch (strip_tail) unless RVLM_GEMM_TAIL=0 / an ablation build is on
     static int tail_on = -1;

@@ -56,8 +56,6 @@ struct GemmBf16 {
     int group_m = 8;                    // persistent kernel only: m-tiles per tile-order group (RVLM_GEMM_GROUP_M experiment)
     int wave_prio = 0;                  // persistent kernel only: s_setprio for waves 4-7 (RVLM_GEMM_PRIO experiment)
     int krot = 0;                       // persistent kernel only: K-step rotation per workgroup (RVLM_GEMM_KROT experiment)
-    int odd_row = 0;                    // persistent kernel only, 1: tiles are 257 rows tall (set by its launcher when M % 257 == 0:
-                                        // one image of 256 + 1 tokens per tile row, no remainder rows) - see gemm_bf16_256p.hip
     int batch_m_rows = 0;               // persistent kernel only, > 0: batched form - rows [b*batch_m_rows, ...) of A meet
                                         // rows [b*N, (b+1)*N) of Bw (the split-K weight-gradient GEMM, gemm_bf16_wgrad)
 };

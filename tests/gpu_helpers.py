@@ -37,14 +37,12 @@ def pad_rows(t, mult=128):
     return buf
 
 
-K_128, K_256, K_PERSISTENT, K_256Q, K_SPLITK, K_STRIP, K_ODDROW = 1, 2, 4, 8, 16, 32, 64   # include/rvlm_kernels.h RVLM_GEMM_K_*
+K_128, K_256, K_PERSISTENT, K_256Q, K_SPLITK, K_STRIP = 1, 2, 4, 8, 16, 32   # include/rvlm_kernels.h RVLM_GEMM_K_*
 
 
 def persistent_expected(M, N, K):
     """Kernel families rvlm_k_gemm_set_variant(3) must launch for an [M,K] x [N,K]^T problem."""
     if M >= 256 and N % 256 == 0 and K % 128 == 0:
-        if M % 257 == 0:
-            return K_PERSISTENT | K_ODDROW      # 257-row tiles: no remainder rows
         return K_PERSISTENT | (K_STRIP if M % 256 else 0)
     return None
 

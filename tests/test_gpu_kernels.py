@@ -5,7 +5,7 @@ import torch
 
 from robustvlm_amd import _lib as L
 from tests.gpu_helpers import (dev, st, lib, cos_sim, rel_max, gemm_bf16, act_ref, dact_ref, attn_ref,
-                               persistent_expected, K_128, K_PERSISTENT, K_SPLITK, K_STRIP, K_ODDROW)
+                               persistent_expected, K_128, K_PERSISTENT, K_SPLITK, K_STRIP)
 
 pytestmark = pytest.mark.gpu
 
@@ -359,41 +359,6 @@ def test_gemm_bf16_act_epilogue_without_derivative_output(M, N, K, variant, fam,
     assert torch.equal(out, ref_out)
 
 
-@pytest.mark.parametrize("T", [1, 3, 9])
-@pytest.mark.parametrize("N,K", [(256, 128), (768, 1024), (512, 4096)])
-def test_gemm_bf16_odd_row_tiles(T, N, K):
-    """M = 257 T: the persistent kernel runs 257-row tiles - rows 0..255 of a tile by MFMA, row 256 as dot products of its
-    A values with the B fragments in registers (v_dot2_f32_bf16, fp32 accumulation).  Every epilogue, every row class."""
-    lib().rvlm_k_gemm_set_variant(3)
-    try:
-        M = 257 * T
-        g = torch.Generator(device="cuda").manual_seed(T + N + K)
-        A = torch.randn(M, K, generator=g, device=dev()).bfloat16()
-        Bw = (torch.randn(N, K, generator=g, device=dev()) * K ** -0.5).bfloat16()
-        bias = torch.randn(N, generator=g, device=dev())
-        res = torch.randn(M, N, generator=g, device=dev())
-        hp = torch.randn(M, N, generator=g, device=dev()).bfloat16()
-        acc = (A.float() @ Bw.float().t()).double()
-        fam = K_PERSISTENT | K_ODDROW
-        odd = slice(256, M, 257)
-        out, _ = gemm_bf16(A, Bw, epi=4, bias=bias, expect=fam)
-        assert rel_max(out, acc + bias.double()) < 3e-5
-        assert rel_max(out[odd], (acc + bias.double())[odd]) < 3e-5
-        out, _ = gemm_bf16(A, Bw, epi=1, bias=bias, residual=res, expect=fam)
-        assert rel_max(out, acc + bias.double() + res.double()) < 3e-5
-        out, _ = gemm_bf16(A, Bw, epi=0, expect=fam)
-        assert rel_max(out.float(), acc) < 1e-2
-        assert rel_max(out[odd].float(), acc[odd]) < 1e-2
-        out, pre = gemm_bf16(A, Bw, epi=2, bias=bias, act=0, expect=fam)
-        assert rel_max(out.float(), act_ref(acc + bias.double(), 0)) < 1.5e-2
-        assert rel_max(pre[odd].float(), dact_ref(acc + bias.double(), 0)[odd]) < 1.5e-2
-        out, _ = gemm_bf16(A, Bw, epi=3, h_pre=hp, expect=fam)
-        assert rel_max(out.float(), acc * hp.double()) < 1.5e-2
-        assert rel_max(out[odd].float(), (acc * hp.double())[odd]) < 1.5e-2
-    finally:
-        lib().rvlm_k_gemm_set_variant(-1)
-
-
 # the eight GEMM launch types of one ViT-L/14 block at the headline batch (B = 128: M = 128 * 257 = 32 896 rows), as
 # (name, N, K, epilogue): forward QKV / out-proj / fc1 / fc2 and their dgrads (robustvlm_amd/csrc/engine.hip)
 HEADLINE_GEMMS = [("qkv_fwd", 3072, 1024, 0), ("out_fwd", 1024, 1024, 1), ("fc1_fwd", 4096, 1024, 2),
@@ -404,8 +369,9 @@ HEADLINE_GEMMS = [("qkv_fwd", 3072, 1024, 0), ("out_fwd", 1024, 1024, 1), ("fc1_
 @pytest.mark.parametrize("name,N,K,epi", HEADLINE_GEMMS, ids=[h[0] for h in HEADLINE_GEMMS])
 def test_gemm_bf16_headline_shapes_production_dispatch(name, N, K, epi):
     """The exact shapes bench.py times (BASELINE config 2), under the PRODUCTION dispatch (no variant override): the
-    persistent kernel with 257-row tiles must be what runs, and its result must match an fp32-accumulated matmul of the
-    same bf16 operands - the dominant kernel of the headline number is compared with something other than itself."""
+    persistent 256x256 kernel + its in-launch strip phase must be what runs, and its result must match an fp32-
+    accumulated matmul of the same bf16 operands - the dominant kernel of the headline number is compared with
+    something other than itself."""
     lib().rvlm_k_gemm_set_variant(-1)
     M = 128 * 257
     g = torch.Generator(device="cuda").manual_seed(N + K + epi)
@@ -415,7 +381,7 @@ def test_gemm_bf16_headline_shapes_production_dispatch(name, N, K, epi):
     acc = (A.float() @ Bw.float().t()).double()
     if bias is not None:
         acc = acc + bias.double()
-    fam = K_PERSISTENT | K_ODDROW       # M = 257 x 128: 257-row tiles (256 MFMA rows + one dot-product row), no strip phase
+    fam = K_PERSISTENT | K_STRIP
     if epi == 0:
         out, _ = gemm_bf16(A, Bw, epi=0, bias=bias, expect=fam)
         assert rel_max(out.float(), acc) < 1e-2
@@ -431,8 +397,8 @@ def test_gemm_bf16_headline_shapes_production_dispatch(name, N, K, epi):
         hp = torch.randn(M, N, generator=g, device=dev()).bfloat16()
         out, _ = gemm_bf16(A, Bw, epi=3, h_pre=hp, expect=fam)
         assert rel_max(out.float(), acc * hp.double()) < 1.5e-2
-    # every tile's 257th row (the dot-product path) separately: a bug there would be 0.4 % of the elements
-    tail = slice(256, M, 257)
+    # the last rows (strip phase) separately: a bug there would be 0.4 % of the elements
+    tail = slice(M - 128, M)
     if epi in (0, 2, 3):
         ref_t = acc[tail] if epi == 0 else (act_ref(acc[tail], 0) if epi == 2 else acc[tail] * hp[tail].double())
         assert rel_max(out[tail].float(), ref_t) < 1.5e-2
