@@ -797,7 +797,9 @@ int gemm_bf16_nt_256p(const GemmBf16& p, int* rows_done, hipStream_t s) {
     static int tail_on = -1;
     if (tail_on < 0) { const char* e = getenv("RVLM_GEMM_TAIL"); tail_on = e ? atoi(e) : 1; }
     static int stagger = -1;
-    if (stagger < 0) { const char* e = getenv("RVLM_GEMM_STAGGER"); stagger = e ? atoi(e) : 2; }
+    // (default 0 since the split-role schedule: the late start that gained 3 % on the fc2 dgrad under the lockstep schedule
+    // now costs it 4 %, profiles/r02_gemm_knobs_split.log)
+    if (stagger < 0) { const char* e = getenv("RVLM_GEMM_STAGGER"); stagger = e ? atoi(e) : 0; }
     static int stagger_mask = -1;   // bit e: apply to epilogue kind e
     if (stagger_mask < 0) { const char* e = getenv("RVLM_GEMM_STAGGER_EPI"); stagger_mask = e ? atoi(e) : 8; }
     static int stagger_ph = -1;     // phase mask: 3 = 4 phases
