@@ -645,18 +645,13 @@ __global__ void __launch_bounds__(NK * 64)
 attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __restrict__ o, long ldo,
                       const bf16_t* __restrict__ d_o, long lddo, const float* __restrict__ lse2,
                       bf16_t* __restrict__ dqkv, long lddq, int H, int S, long W, float scale, float scale_log2,
-                      unsigned long long* __restrict__ trace, int desync, AttnLayout lay, int prefetch) {
-    // optional phase timeline (RVLM_ATTN_TRACE=1: 5 s_memtime stamps per workgroup into the dsum scratch buffer)
-    auto stamp = [&](int k) {
-        if (trace && threadIdx.x == 0) trace[(long)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memtime();
-    };
+                      unsigned long long* __restrict__ trace, int desync, AttnLayout lay, int nbh) {
     // Phase offset: every CU would otherwise stage its head at the same moment (6 TB/s-bound, 22 % of the kernel spent
     // waiting for HBM) and compute at the same moment (HBM idle).  The first workgroup of each CU starts up to 7 x desync
     // kilo-cycles late; the stagger then persists, one CU's staging hides under the others' compute.
     if (desync > 0 && blockIdx.x < 256) {
         for (int i = 0; i < (int)((blockIdx.x >> 3) & 7) * desync; ++i) __builtin_amdgcn_s_sleep(16);   // 16 x 64 cycles
     }
-    stamp(0);
     constexpr int NT = NK + 1, Sp = NT * 32, SE = NK * 32;   // query tiles, padded rows, index of the odd key
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Qt = smem;
@@ -670,16 +665,42 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
     float* De = Pe + Sp;                                       // dS[q][odd key]
     float* Ke = De + Sp;                                       // k[odd key][0..63] as fp32
     float* KVe = Ke + 64;                                      // [NK + 1][2][64] per-wave (+ odd query) dK / dV of the odd key
-    const int b = blockIdx.x / H, h = blockIdx.x % H;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // PERSISTENT over the (image, head) pairs bh = blockIdx.x, + gridDim.x, ... (the launcher gives <= 256 workgroups when
+    // RVLM_ATTN_PERSIST is on): while a head's query-tile loop runs, the NEXT head's Q and dO tiles are requested into the
+    // LDS tile slots the loop has finished with (one 1-KiB DMA per wave and step, through inline asm: a compiler-visible
+    // LDS-DMA would make hipcc drain vmcnt in front of every LDS read that might alias it).  A CU pulls HBM misses at only
+    // ~12 B per clock, so the 144 KB staging of a head cost 27 % of the kernel; half of it now arrives under the loop.
+    bool have_qd = false;       // Q / dO of the head about to start are already in LDS
+    for (int bh = blockIdx.x; bh < nbh; bh += gridDim.x) {
+    // (opaque per iteration: otherwise every lane-derived offset of the phases below is hoisted out of this loop, lives
+    // across the whole head - 256 VGPRs, 52 spilled dwords - and the kernel ran 40 % slower than its one-head form)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, w = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
+    // optional phase timeline (RVLM_ATTN_TRACE=1: 5 s_memtime stamps per head into the dsum scratch buffer)
+    auto stamp = [&](int k) {
+        if (trace && threadIdx.x == 0) trace[(long)bh * 8 + k] = __builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
+    const int b = bh / H, h = bh % H;
+    const int nxt = bh + (int)gridDim.x;
+    const bool prefetch_next = nxt < nbh;
     const bf16_t* base = qkv + (long)b * lay.qkv_b + (long)h * lay.qkv_h;
     const bf16_t* dob = d_o + (long)b * lay.o_b + (long)h * lay.o_h;
     const bf16_t* ob = o + (long)b * lay.o_b + (long)h * lay.o_h;
-
-    // ---- phase 0: stage Q, dO, K, V; lse -------------------------------------------------------------------
-    stage_tile(Qt, base, ld, S, Sp, w, NK, lane);
-    stage_tile(Dt, dob, lddo, S, Sp, w, NK, lane);
+    // the next head's Q / dO blocks (8 rows = one DMA instruction): wave w < 4 takes block 4 t + w of Q, the others of dO
+    const bf16_t* nsrc = nullptr;
+    if (prefetch_next) {
+        const int nb = nxt / H, nh = nxt % H;
+        nsrc = w < 4 ? qkv + (long)nb * lay.qkv_b + (long)nh * lay.qkv_h : d_o + (long)nb * lay.o_b + (long)nh * lay.o_h;
+    }
+    const long nld = w < 4 ? ld : lddo;
+    // ---- phase 0: stage Q, dO (unless they came in under the previous head's loop), K, V; lse ----------------------
+    if (!have_qd) {
+        stage_tile(Qt, base, ld, S, Sp, w, NK, lane);
+        stage_tile(Dt, dob, lddo, S, Sp, w, NK, lane);
+    }
     stage_tile(Kt, base + W, ld, S, Sp, w, NK, lane);
     stage_tile(Vt, base + 2 * W, ld, S, Sp, w, NK, lane);
     for (int i = tid; i < Sp; i += NK * 64) Ls[i] = (i < S) ? lse2[((long)b * H + h) * Sp + i] : INFINITY;
@@ -694,6 +715,7 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
         odd_do = (float)dob[(long)SE * lddo + lane]; odd_o = (float)ob[(long)SE * ldo + lane];
         odd_q = (float)base[(long)SE * ld + lane]; odd_v = (float)base[(long)SE * ld + 2 * W + lane];
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the inline-asm requests of the previous head's loop)
     __syncthreads();
     stamp(1);
 
@@ -786,30 +808,6 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
     }
     __syncthreads();   // K / V tiles are dead: the area becomes the partial slots; Ds / Pe / De are complete
     stamp(2);
-    // Experiment (RVLM_ATTN_PREFETCH=n, default off): cache warm-up for the workgroup that follows this one on the chip
-    // (blockIdx + n, the same XCD): one dword per 128-byte row of its Q, K, V, dO, O blocks, requested now that this CU's own
-    // staging is over.  A CU pulls HBM misses at only ~12 B per clock (the staging phase above: 144 KB in ~11.8 k cycles
-    // whatever the layout or the other CUs do).  Measured (profiles/r02_attn_next_wg_prefetch.log): the next staging drops
-    // to ~8 k cycles, but the misses now occupy the CU's miss path during the tile loop, whose dQ stores queue behind them
-    // (+2.4 k cycles): the kernel's wall time does not move.  The three result registers are never read; they stay
-    // allocated until the end of the kernel.
-    int pf[3] = {0, 0, 0};
-    if (prefetch > 0 && (int)blockIdx.x + prefetch < (int)gridDim.x) {
-        const int nb = ((int)blockIdx.x + prefetch) / H, nh = ((int)blockIdx.x + prefetch) % H;
-        const bf16_t* nq = qkv + (long)nb * lay.qkv_b + (long)nh * lay.qkv_h;
-        const bf16_t* ndo = d_o + (long)nb * lay.o_b + (long)nh * lay.o_h;
-        const bf16_t* no = o + (long)nb * lay.o_b + (long)nh * lay.o_h;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int idx = tid + i * NK * 64;                 // 5 blocks x S rows
-            if (idx < 5 * S) {
-                const int t = idx / S, row = idx - t * S;
-                const bf16_t* ptr = t < 3 ? nq + (long)row * ld + t * W : (t == 3 ? ndo + (long)row * lddo : no + (long)row * ldo);
-                asm volatile("global_load_dword %0, %1, off" : "=v"(pf[i]) : "v"(ptr) : "memory");
-            }
-        }
-    }
-
     // ---- phase 2: lockstep walk over the query tiles -------------------------------------------------------------
     // Per tile: S, dP (8 MFMA) -> P, dS in registers -> dS tile to LDS -> ONE barrier -> dV, dK from the registers
     // (8 MFMA) and this wave's dQ^T block from the NK waves' dS tiles (NK v_mfma_f32_16x16x32_bf16) -> dQ stored.
@@ -830,6 +828,16 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
     const float4 ke4 = *(const float4*)(Ke + 16 * db + 4 * G);        // k[odd key][d], d = 16 db + 4 G + 0..3
     bf16_t* dq_out = dqkv + (long)b * lay.qkv_b + (long)h * lay.qkv_h + 16 * db + 4 * G;
     f32x16 dk[2] = {zero16(), zero16()}, dv[2] = {zero16(), zero16()};
+    // the next head's tile t of Q / dO into the slot of this head's tile t: legal once every wave has passed the barrier of
+    // step t (its fragment reads of the tile are waited for before that barrier).  Issued BEFORE the barrier of step t + 1:
+    // the request stalls its wave for a couple of hundred cycles in the texture queue, which the early waves would
+    // otherwise spend waiting at that barrier
+    auto prefetch_tile = [&](int t) {
+        const int blk = 4 * t + (w & 3), row = blk * 8 + (lane >> 3);
+        const bf16_t* gp = nsrc + (long)min(row, S - 1) * nld + ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+        const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_char*)((w < 4 ? Qt : Dt) + blk * 1024));
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gp), "s"(dst) : "memory", "m0");
+    };
     for (int qt = 0; qt < NT; ++qt) {
         f32x16 s = zero16(), dp = zero16();
 #pragma unroll
@@ -868,6 +876,7 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
                 dot[ks][dt] = frag_tr(Dt, qt * 32 + ks * 16, fo, dt);
                 qtr[ks][dt] = frag_tr(Qt, qt * 32 + ks * 16, fo, dt);
             }
+        if (prefetch_next && qt > 0) prefetch_tile(qt - 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the dS tile is in LDS
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -907,6 +916,7 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
         }
     }
 
+    if (prefetch_next) prefetch_tile(NT - 1);
     stamp(3);
     // ---- phase 3: dK, dV of this wave's keys; the odd key ------------------------------------------------------
     // Through a wave-private 4 KiB LDS tile ([32 keys][64 d] bf16, 16-B chunk index XOR (key & 7)), so that the global
@@ -948,11 +958,10 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
         krow[lane] = (bf16_t)(ak * scale);
         krow[W + lane] = (bf16_t)av;
     }
-    if (prefetch > 0) {     // (only then: a wave that ends with its stores in flight must not wait for them)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("" :: "v"(pf[0]), "v"(pf[1]), "v"(pf[2]));
-    }
     stamp(4);
+    have_qd = prefetch_next;
+    __syncthreads();      // the next head's staging overwrites the K / V area (dS tiles, store transposes) and the small arrays
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1034,19 +1043,20 @@ int attn_bwd_bf16(const bf16_t* qkv, long ldqkv, const bf16_t* o, long ldo, cons
         static int trace = -1, desync = -1;
         if (trace < 0) { const char* e = getenv("RVLM_ATTN_TRACE"); trace = e ? atoi(e) : 0; }
         if (desync < 0) { const char* e = getenv("RVLM_ATTN_DESYNC"); desync = e ? atoi(e) : 5; }
-        static int hm = -1, prefetch = -1;
+        static int hm = -1, persist = -1;
         if (hm < 0) { const char* e = getenv("RVLM_ATTN_HM"); hm = e ? atoi(e) : 0; }
-        if (prefetch < 0) { const char* e = getenv("RVLM_ATTN_PREFETCH"); prefetch = e ? atoi(e) : 0; }   // (measured: off)
+        if (persist < 0) { const char* e = getenv("RVLM_ATTN_PERSIST"); persist = e ? atoi(e) : 1; }
+        const int nbh = B * H, grid = persist ? std::min(nbh, 256) : nbh;
         if (hm) {
             const AttnLayout lay = {(long)H * S * 64, (long)S * 64, (long)H * S * 64, (long)S * 64};
-            hipLaunchKernelGGL((attn_bwd_fused_kernel<NK>), dim3(B * H), dim3(NK * 64), lds_f, s, qkv, 64L, o, 64L, d_o, 64L,
+            hipLaunchKernelGGL((attn_bwd_fused_kernel<NK>), dim3(grid), dim3(NK * 64), lds_f, s, qkv, 64L, o, 64L, d_o, 64L,
                                lse, dqkv, 64L, H, S, (long)B * H * S * 64, scale, sl2,
-                               trace ? (unsigned long long*)dsum_scratch : nullptr, desync, lay, prefetch);
+                               trace ? (unsigned long long*)dsum_scratch : nullptr, desync, lay, nbh);
         } else {
             const AttnLayout lay = {(long)S * ldqkv, 64L, (long)S * ldo, 64L};
-            hipLaunchKernelGGL((attn_bwd_fused_kernel<NK>), dim3(B * H), dim3(NK * 64), lds_f, s, qkv, ldqkv, o, ldo, d_o, lddo,
+            hipLaunchKernelGGL((attn_bwd_fused_kernel<NK>), dim3(grid), dim3(NK * 64), lds_f, s, qkv, ldqkv, o, ldo, d_o, lddo,
                                lse, dqkv, lddqkv, H, S, (long)W, scale, sl2,
-                               trace ? (unsigned long long*)dsum_scratch : nullptr, desync, lay, prefetch);
+                               trace ? (unsigned long long*)dsum_scratch : nullptr, desync, lay, nbh);
         }
         RVLM_CHECK_LAUNCH();
         return RVLM_OK;
