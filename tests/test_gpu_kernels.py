@@ -110,7 +110,9 @@ def test_ds_read_tr16_semantics():
 
 
 @pytest.mark.parametrize("use_tr", [1, 0])
-@pytest.mark.parametrize("B,H,S", [(2, 1, 17), (3, 2, 50), (2, 4, 257), (1, 2, 577)])
+# (20, 16, 257): 320 (image, head) pairs > 256 - some workgroups of the persistent backward walk two heads, the second one
+# with its Q / dO tiles prefetched under the first one's tile loop
+@pytest.mark.parametrize("B,H,S", [(2, 1, 17), (3, 2, 50), (2, 4, 257), (1, 2, 577), (20, 16, 257)])
 def test_attention_bf16_fwd_bwd(B, H, S, use_tr):
     l = lib()
     l.rvlm_k_attn_set_use_tr(use_tr)
