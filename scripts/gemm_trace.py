@@ -11,7 +11,8 @@ lib = L.load()
 dev = torch.device("cuda:0")
 M = 128 * 257
 shapes = [("qkv", M, 3072, 1024, 0), ("out", M, 1024, 1024, 1), ("fc1", M, 4096, 1024, 2), ("fc2", M, 1024, 4096, 1),
-          ("fc2_dgrad", M, 4096, 1024, 3), ("plain_f32", M, 1024, 1024, 4), ("cube8k", 8192, 8192, 8192, 0)]
+          ("fc2_dgrad", M, 4096, 1024, 3), ("fc1_dgrad", M, 1024, 4096, 0), ("plain_f32", M, 1024, 1024, 4),
+          ("cube8k", 8192, 8192, 8192, 0)]
 lib.rvlm_k_gemm_set_variant(int(os.environ.get("GEMM_VARIANT", "2")))
 if os.environ.get("GEMM_ABLATE"):
     lib.rvlm_k_gemm_set_ablate(int(os.environ["GEMM_ABLATE"]))
@@ -19,6 +20,10 @@ only = os.environ.get("TRACE_ONLY")
 if only:
     shapes = [s for s in shapes if s[0] in only.split(",")]
 g = torch.Generator(device=dev).manual_seed(0)
+_wa = torch.randn(8192, 8192, device=dev).bfloat16()     # leave the idle clocks before the first stamp is taken
+for _ in range(300):
+    torch.matmul(_wa, _wa)
+torch.cuda.synchronize()
 trace = torch.zeros(256 * 8 * 4, dtype=torch.int64, device=dev)
 for name, m, n, k, epi in shapes:
     mp = (m + 255) // 256 * 256
@@ -50,6 +55,11 @@ for name, m, n, k, epi in shapes:
     ghz = ticks / (real / 100) / 1000
     print(f"   kernel {real / 100:.1f} us, shader clock {ghz:.3f} GHz")
     print(f"{name}: {ntile} tiles/WG, K-steps/tile {k // 64}; columns in shader cycles")
+    last = min(ntile, 7) - 1
+    tail = (cal[:, 2] - t[:, last, 3])
+    head = (t[:, 0, 0] - cal[:, 0])
+    print(f"   before the first tile (prologue) {head.mean():7.0f} cycles | after the last tile's epilogue (remainder-row phase + drain) "
+          f"{tail.mean():7.0f} cycles (min {tail.min():.0f}, max {tail.max():.0f})")
     for i in range(min(ntile, 7)):
         s = t[:, i, :]
         first = (s[:, 1] - s[:, 0]).mean()
