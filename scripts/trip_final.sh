@@ -1,0 +1,5 @@
+#!/bin/bash
+mkdir -p gpurun_out
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -2
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+timeout 600 python bench.py 2>/dev/null | tail -1 | cut -c1-220
