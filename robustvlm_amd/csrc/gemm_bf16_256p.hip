@@ -10,7 +10,8 @@
 //   * BK = 64 (128-B LDS rows = one full L2 line per operand row per K-step; 64-B rows halve the payload per request
 //     and measured 10 TB/s against 15 TB/s of operand DMA).  LDS = A ring of 3 half-stage slots + B ring of 2: the A
 //     halves run three K-steps ahead of the MFMAs, the B halves two, continuously across tile seams.  One barrier
-//     per K-step, fragments double-buffered in registers, counted vmcnt (the A half's youngest stage stays in flight).
+//     per K-step, fragments double-buffered in registers and read between the MFMAs of the previous k-slice, counted
+//     vmcnt (the A half's youngest stage stays in flight).
 //   * the two waves of a SIMD take opposite roles in the operand traffic: waves 4-7 request all of B right after the
 //     barrier, waves 0-3 all of A at the end of their step, so one of them issues MFMAs while the other waits in the
 //     texture queue (see SPLIT below; +4-6 % on every shape over the lockstep form).
@@ -173,9 +174,9 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
 #else
     constexpr bool FINE = (ABL & 1024) == 0;
 #endif
-    // phase offset (performance only): with every workgroup in lockstep the epilogues' HBM bursts coincide chip-wide.  On
-    // by default for the fc2 dgrad only (8 tiles per workgroup, epilogue reads act' from HBM: -3 %); measured neutral to
-    // slightly negative for the other epilogues (2 tiles per workgroup: the offset costs as much tail as it hides)
+    // phase offset (performance only, RVLM_GEMM_STAGGER, default off): with every workgroup in lockstep the epilogues' HBM
+    // bursts coincide chip-wide.  It gained 3 % on the fc2 dgrad under the lockstep schedule and costs it 4 % under the
+    // split-role one; neutral to slightly negative for the other epilogues (profiles/r02_gemm_knobs_split.log)
     if ((p.stagger & 255) > 0) {
         const int phase = (blockIdx.x >> 3) & ((p.stagger >> 8) & 255);   // phases per XCD (blockIdx & 7 = XCD): mask in the high bits
         for (int i = 0; i < (p.stagger & 255) * phase; ++i) __builtin_amdgcn_s_sleep(127);
