@@ -134,6 +134,20 @@ def cpu_baseline(iterations_full=10, l14_sample=True):
     return out
 
 
+def _baseline_config_name(attack: str, world: int, per_gpu_batch: int) -> str:
+    """Which BASELINE.json `configs` entry a run is: [1] one GPU, [3] = the same 128 images per GPU on 8 GPUs
+    (global batch 1024); 2 / 4 GPUs are the intermediate points of the 1/2/4/8 curve of that same per-GPU workload."""
+    if attack == "apgd":
+        return "BASELINE configs[2]" + ("" if world == 1 else f" per GPU x {world}")
+    if attack != "pgd":
+        return "BASELINE configs[4], n_restarts=1 (the reference's AutoAttack default is 5)" + ("" if world == 1 else f" per GPU x {world}")
+    if world == 1:
+        return "BASELINE configs[1]"
+    if world == 8 and per_gpu_batch == 128:
+        return "BASELINE configs[3]: global batch 1024 = 8 x 128, data-parallel"
+    return f"BASELINE configs[1] per GPU x {world} ranks: a point of the 1/2/4/8 curve that ends at configs[3]"
+
+
 def bench_train(args, R, cfg, sd, dev, dist, world, rank):
     """Full training step (the 'next' row of SURVEY.md 8(f)): reported separately from the headline metric."""
     from robustvlm_amd.trainer import AdversarialTrainer
@@ -209,11 +223,15 @@ def bind_rank_to_numa(local_rank: int, local_world: int):
 
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
+    # `python bench.py --gpus N` without a launcher creates its N ranks itself (and exits with their exit code);
+    # under a launcher (WORLD_SIZE set) this process is one rank and --gpus must agree with it
+    from robustvlm_amd.launch import ensure_ranks
+    plan = ensure_ranks(args.gpus)
+    world = plan.world
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     affinity = bind_rank_to_numa(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
@@ -222,8 +240,6 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
     import robustvlm_amd as R
     cfg = R.CONFIGS[args.model]
@@ -311,7 +327,7 @@ def main():
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": (f"{'FARE' if args.attack == 'pgd' else 'TeCoA-CE'} {args.attack.upper()} {args.iterations}-step eps=4/255 on {args.model} "
                                     f"{args.precision}, batch={B} per GPU, 224x224x3 synthetic, seeded random-init weights "
-                                    f"(BASELINE configs[{(1 if world == 1 else 3) if args.attack == 'pgd' else 2 if args.attack == 'apgd' else 4}])")
+                                    f"({_baseline_config_name(args.attack, world, B)})")
                                    if args.attack != "square" else
                                    (f"black-box SquareAttack, {args.iterations} queries, eps=4/255 on {args.model} {args.precision} + "
                                     f"1000-class zero-shot head, batch={B} per GPU (clip_robustbench.py --blackbox_only route; "
@@ -326,6 +342,9 @@ def main():
                                           args.attack == "square" else args.iterations + 1.5) / 1e12,
         }
         res["ranks"] = {"rccl_ranks": world if dist is not None else 0,
+                        "launcher": "none (single process)" if world == 1 else
+                                    "bench.py self-launch (torch.distributed.run, 127.0.0.1)" if os.environ.get("RVLM_SELF_LAUNCHED")
+                                    else "external torch.distributed.run",
                         "per_rank_images_per_sec_min": min(B * args.steps / t for t in per_rank_s),
                         "per_rank_images_per_sec_max": max(B * args.steps / t for t in per_rank_s),
                         "cpu_affinity_rank0": affinity}
