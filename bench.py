@@ -162,11 +162,11 @@ def bench_train(args, R, cfg, sd, dev, dist, world, rank):
             dist.barrier()
         torch.cuda.synchronize()
     for _ in range(args.warmup):
-        tr.train_step(x, None)
+        tr.train_step(x, None, global_batch=world * B)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = tr.train_step(x, None)
+        out = tr.train_step(x, None, global_batch=world * B)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     if dist is not None:

@@ -14,7 +14,7 @@ import torch
 
 from . import _lib as L
 from .apgd_train import _apgd_linf_generic, apgd_schedule
-from .clip_model import ClassificationModel, ce
+from .clip_model import ClassificationModel, _CeLogitsFn
 from .engine import _require_cuda, _f32c
 
 
@@ -112,7 +112,9 @@ class APGDAttack():
             x_best_adv, x_best, loss_best, acc = (torch.cat([p[i] for p in parts]) for i in range(4))
             return x_best, acc.bool(), loss_best, x_best_adv
         if self.loss == 'ce':
-            crit = lambda lg, yy: ce(lg, yy, reduction='none')   # noqa: E731  (rvlm_ce_logits)
+            # nn.CrossEntropyLoss(reduction='none') (autopgd_base.py:249) on rvlm_ce_logits: unlike the trainer's ce() it
+            # has no batch > 1 assert - a restart can be left with ONE robust point (autopgd_base.py:494-500)
+            crit = lambda lg, yy: _CeLogitsFn.apply(lg, yy, L.RED_NONE)   # noqa: E731
         else:
             crit = self.dlr_loss if self.loss == 'dlr' else self.dlr_loss_targeted
         return _apgd_linf_generic(self.model, crit, x, y, self.eps, self.n_iter, step0, False, x_init=start)

@@ -247,12 +247,13 @@ class ClassificationModel(torch.nn.Module):
 
     def forward(self, vision, output_normalize=True):
         assert output_normalize
-        vision = self.resizer(vision)
         mb = self.model.max_batch
         if vision.shape[0] > mb and not (torch.is_grad_enabled() and vision.requires_grad):
             # evaluation batches larger than the engine's workspace (AutoAttack's bs=250 on a max_batch=128 engine)
-            # are encoded in chunks; a differentiable call must fit (one saved forward per engine)
+            # are encoded in chunks; a differentiable call must fit (one saved forward per engine).  Chunks are cut
+            # BEFORE the resizer so that each image passes through it exactly once
             return torch.cat([self.forward(vision[i:i + mb]) for i in range(0, vision.shape[0], mb)], 0)
+        vision = self.resizer(vision)
         embedding_norm_ = self.vision(vision, True)
         return _HeadLogitsFn.apply(embedding_norm_, self.text_embedding,
                                    self.logit_scale_value if self.logit_scale else 1.0)

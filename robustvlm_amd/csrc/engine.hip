@@ -79,6 +79,7 @@ struct rvlm_vit {
     size_t bytes = 0;
     int saved_B = 0;
     int saved_mode = 0;
+    int next_param_stage = 0;   // rvlm_vit_backward_params_stages: the stage the saved forward's backward continues at
     bool saved_norm = false;
     // profiling
     bool prof = false;
@@ -479,7 +480,7 @@ static int forward_impl(rvlm_vit* h, const float* x, const float* delta, int B, 
             if ((rc = l2_normalize_fwd(h->emb_raw, out_emb, h->inv_norm, B, D, s))) return rc;
         }
     }
-    if (save) { h->saved_B = B; h->saved_norm = normalize != 0; h->saved_mode = save; }
+    if (save) { h->saved_B = B; h->saved_norm = normalize != 0; h->saved_mode = save; h->next_param_stage = 0; }
     return RVLM_OK;
 }
 
@@ -965,6 +966,7 @@ extern "C" int rvlm_vit_backward_params(rvlm_vit* h, const float* d_emb, int B, 
     if (h->saved_B != B || B <= 0 || h->saved_mode != 2)
         return fail(RVLM_ERR_STATE, "rvlm_vit_backward_params: needs a forward with save_for_backward == 2 for this batch");
     hipStream_t s = (hipStream_t)stream;
+    h->next_param_stage = h->L + 2;
     return h->bf16 ? backward_params_impl<bf16_t>(h, d_emb, B, grads, accumulate, 0, h->L + 2, s)
                    : backward_params_impl<float>(h, d_emb, B, grads, accumulate, 0, h->L + 2, s);
 }
@@ -977,9 +979,17 @@ extern "C" int rvlm_vit_backward_params_stages(rvlm_vit* h, const float* d_emb, 
         return fail(RVLM_ERR_STATE, "rvlm_vit_backward_params_stages: needs a forward with save_for_backward == 2 for this batch");
     RVLM_REQUIRE(stage_begin >= 0 && stage_begin < stage_end && stage_end <= h->L + 2,
                  "rvlm_vit_backward_params_stages: need 0 <= stage_begin < stage_end <= layers + 2");
+    // stages of one backward hand the residual gradient to each other through the handle: stage k reads what stage
+    // k-1 left.  A range that does not continue where the saved forward's backward stands (a skipped or repeated
+    // stage) would read stale gradients and write wrong ones silently - refuse it.  Stage 0 restarts the backward.
+    if (stage_begin != 0 && stage_begin != h->next_param_stage)
+        return fail(RVLM_ERR_STATE, "rvlm_vit_backward_params_stages: stages of one backward must run in order from 0 "
+                                    "(stage_begin does not continue the previous call's stage_end)");
     hipStream_t s = (hipStream_t)stream;
-    return h->bf16 ? backward_params_impl<bf16_t>(h, d_emb, B, grads, accumulate, stage_begin, stage_end, s)
-                   : backward_params_impl<float>(h, d_emb, B, grads, accumulate, stage_begin, stage_end, s);
+    const int rc = h->bf16 ? backward_params_impl<bf16_t>(h, d_emb, B, grads, accumulate, stage_begin, stage_end, s)
+                           : backward_params_impl<float>(h, d_emb, B, grads, accumulate, stage_begin, stage_end, s);
+    h->next_param_stage = rc == RVLM_OK ? stage_end : -1;
+    return rc;
 }
 
 static int loss_step(rvlm_vit* h, const rvlm_loss_spec* ls, int B, int reduction, float* loss_scalar,

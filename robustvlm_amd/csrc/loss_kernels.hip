@@ -266,7 +266,8 @@ extern "C" int rvlm_ce_logits(const float* logits, const int64_t* targets, int B
                               rvlm_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     RVLM_REQUIRE(logits && targets && d_logits && loss_per_sample && B > 0 && C > 0, "rvlm_ce_logits: bad arguments");
-    RVLM_REQUIRE(B > 1, "rvlm_ce_logits: batch size must be > 1 (reference asserts out.shape[0] > 1)");
+    // no B > 1 here: the batch-size assert belongs to the trainer's ce() (train/adversarial_training_clip.py:526, kept in
+    // clip_model.ce); AutoPGD's nn.CrossEntropyLoss(reduction='none') (autoattack/autopgd_base.py:249) takes one sample
     RVLM_REQUIRE(reduction == RVLM_RED_MEAN || reduction == RVLM_RED_NONE, "rvlm_ce_logits: unknown reduction");
     const float gscale = (reduction == RVLM_RED_MEAN) ? 1.0f / (float)B : 1.0f;
     if (d_logits != logits) RVLM_HIP(hipMemcpyAsync(d_logits, logits, (size_t)B * C * 4, hipMemcpyDeviceToDevice, s));

@@ -180,12 +180,15 @@ class AdversarialTrainer:
                 w.wait()                                                         # the compute stream waits, not the host
         return loss.detach(), emb
 
-    def _shard_weight(self, n_local: int) -> float:
+    def _shard_weight(self, n_local: int, global_batch: int | None = None) -> float:
         """The reference's loss is the mean over the GLOBAL batch (DataParallel gathers the outputs first, …clip.py:
         184-191).  Here every rank takes the mean over its shard and AdamW divides the summed gradients by world_size;
-        the factor n_local * world / n_global makes that exact for uneven shards too (1.0 for equal ones)."""
+        the factor n_local * world / n_global makes that exact for uneven shards too (1.0 for equal ones).  A caller
+        that knows the global batch size passes it: no collective and no host sync in front of the backward then."""
         if self.world == 1:
             return 1.0
+        if global_batch is not None:
+            return n_local * self.world / float(global_batch)
         n = torch.tensor([float(n_local)], dtype=torch.float64)
         if self._device_collectives:
             n = n.to(self.device)
@@ -221,17 +224,19 @@ class AdversarialTrainer:
                                             L.stream_ptr()), "rvlm_argmax_eq")
         return (pred.sum() / B).item() * 100
 
-    def train_step(self, data, targets, data_adv=None):
+    def train_step(self, data, targets, data_adv=None, global_batch=None):
         """One optimizer step on this rank's shard.  Returns dict(loss, loss_clean, loss_total, lr) and, with
         ``metrics`` on, the reference's logging values cos_sim_clean, cos_sim, acc, racc (acc / racc None unless
         ``targets`` are labels and a text head was given).  ``data_adv`` (optional) bypasses the attack with
-        precomputed adversarial images (tests)."""
+        precomputed adversarial images (tests).  ``global_batch`` (optional): the number of images all ranks hold in
+        this step, when the caller knows it (equal shards: world * len(data)) - skips the size all-reduce.  The
+        returned loss / metrics are this rank's SHARD values (the reference's DataParallel logs global-batch values)."""
         with torch.no_grad():
             e0 = self.model_orig(data, self.output_normalize)                   # …clip.py:296-297
         if data_adv is None:
             data_adv = self._attack(data, targets, e0)
         cw = self.clean_weight
-        wshard = self._shard_weight(data.shape[0])
+        wshard = self._shard_weight(data.shape[0], global_batch)
         dp = self._reduce
         loss_clean = torch.zeros((), device=self.device)
         emb_clean = None

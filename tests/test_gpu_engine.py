@@ -614,3 +614,38 @@ def test_apgdattack_batches_beyond_the_engine_workspace():
         outs.append(atk.perturb(x, y))
     assert torch.equal(outs[0], outs[1])
     big.close(); small.close()
+
+
+def test_apgdattack_single_sample():
+    """one surviving robust point (autopgd_base.py:494-500 hands attack_single_run a batch of ONE; the reference's
+    nn.CrossEntropyLoss(reduction='none') has no batch limit).  The one-sample run must equal that sample's result inside a
+    batch (per-sample attack; fp32 mode sums k in order for every row), for perturb() and attack_single_run(), CE and DLR."""
+    cfg = V.VIT_TINY2
+    w = V.init_weights(cfg, seed=9)
+    g = torch.Generator(device="cuda").manual_seed(4)
+    T = torch.nn.functional.normalize(torch.randn(cfg.out_dim, 10, generator=g, device=dev()), dim=0)
+    x = torch.rand(3, 3, cfg.image_size, cfg.image_size, generator=g, device=dev())
+    eng = make_engine(cfg, w, "fp32", max_batch=4)
+    clf = R.ClassificationModel(eng, T).eval()
+    with torch.no_grad():
+        y = clf(x).argmax(1)
+    for loss in ("ce", "dlr"):
+        atk = R.APGDAttack(clf, n_iter=6, norm="Linf", n_restarts=1, eps=4 / 255, seed=0, loss=loss, device=dev(), use_rs=False)
+        atk.init_hyperparam(x)
+        xb3, acc3, lb3, adv3 = atk.attack_single_run(x, y)
+        xb1, acc1, lb1, adv1 = atk.attack_single_run(x[1:2], y[1:2])
+        assert xb1.shape == x[1:2].shape and acc1.shape == (1,) and lb1.shape == (1,)
+        assert float((adv1 - x[1:2]).abs().max()) <= float(np.float32(4 / 255)) + 1e-7
+        # fused route (B = 3: emb @ (100 T)) vs generic route (B = 1: (emb @ T) * 100): equal to fp32 rounding
+        np.testing.assert_allclose(lb1.cpu().numpy(), lb3[1:2].cpu().numpy(), rtol=2e-2)
+        assert float((xb1 == xb3[1:2]).float().mean()) > 0.97
+        out = atk.perturb(x[1:2], y[1:2])
+        assert out.shape == x[1:2].shape and torch.isfinite(out).all()
+    # the logits-level CE kernel takes one row; the trainer's ce() keeps the reference's batch > 1 assert
+    lg = torch.randn(1, 10, device=dev())
+    from robustvlm_amd.clip_model import _CeLogitsFn
+    got = _CeLogitsFn.apply(lg, y[:1], L.RED_NONE)
+    np.testing.assert_allclose(got.cpu().numpy(), torch.nn.functional.cross_entropy(lg, y[:1], reduction="none").cpu().numpy(), rtol=1e-6)
+    with pytest.raises(AssertionError):
+        R.ce(lg, y[:1])
+    eng.close()

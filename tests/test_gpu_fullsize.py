@@ -181,3 +181,107 @@ def test_config5_apgd_ce_100_b256(setup):
     # measured: identical pixels 0.990, loss_best ratio 0.99995
     assert same > 0.95, same
     assert 0.98 < loss_ratio < 1.02, loss_ratio
+
+
+def _oracle_pgd_trajectory(ref, xc, dc, e0c, iterations=10):
+    """oracle pgd_ref on a slice with its per-iteration gradients, and the iterates delta_0 .. delta_{I-1} it evaluated
+    them at (replayed from the traced gradients with the oracle's own update)."""
+    trace = []
+    x_or = A.pgd_ref(ref, Lr.ComputeLossWrapperRef(e0c, None, "mean", "l2", 100.), xc, None, "linf", EPS, iterations, STEP,
+                     False, perturbation=dc.clone(), mode="max", trace=trace)
+    xn = xc.numpy().astype(np.float32)
+    delta, vel = dc.numpy().astype(np.float32).copy(), np.zeros_like(xn)
+    deltas = []
+    for t in trace:
+        deltas.append(delta.copy())
+        delta, vel = A.pgd_linf_update_ref(xn, t["grad"], delta, vel, EPS, STEP, 0.9, "max")
+    assert np.array_equal(xn + delta, x_or.numpy()), "trajectory replay must reproduce the oracle's result"
+    return x_or, trace, deltas
+
+
+def test_config2_gradient_signs_along_the_oracle_trajectory_b128(setup):
+    """VERDICT r2 weak 1(b,c): the ENGINE AS A WHOLE under the B = 128 production dispatch (M = 32 896: persistent GEMM +
+    strip phase, fused attention, class-token tail), not only its GEMM shapes one by one.  The oracle attacks the first
+    NS images; at each of its iterates delta_k the HIP path evaluates forward + loss + input gradient of the FULL batch
+    (images NS.. carry their own delta_0) and the slice's embeddings / gradients are compared with the oracle's at the
+    same point.  sign(g) is all the L-inf update uses, so per-iteration sign agreement is the bf16 gate that the
+    end-to-end identical-pixel fraction (ten compounding iterations) cannot be."""
+    s = setup
+    B = 128
+    x, d0 = s["x"][:B].to(dev()), s["d0"][:B].to(dev())
+    xc, dc = s["x"][:NS], s["d0"][:NS]
+    with torch.no_grad():
+        e0c = s["ref"](xc, False)
+    _, trace, deltas = _oracle_pgd_trajectory(s["ref"], xc, dc, e0c)
+    eng = s["eng"]
+    e0 = eng.forward(x, None, False, save=False)
+    assert cos_sim_rows(e0[:NS].cpu(), e0c) > 0.9999
+    signs, coss, losses = [], [], []
+    for k in (0, 1, 2, 4, 9):
+        d = d0.clone()
+        d[:NS] = torch.from_numpy(deltas[k]).to(dev())
+        emb, per, _, g = eng.fwd_inputgrad(x, d, "l2", "mean", e0, None, False)
+        torch.cuda.synchronize()
+        gk, gr = g[:NS].cpu().numpy(), trace[k]["grad"]
+        signs.append(float(np.mean(np.sign(gk) == np.sign(gr))))
+        coss.append(float((gk.astype(np.float64) * gr).sum() / (np.linalg.norm(gk.astype(np.float64)) * np.linalg.norm(gr.astype(np.float64)))))
+        with torch.no_grad():
+            per_or = ((s["ref"](xc + torch.from_numpy(deltas[k]), False) - e0c) ** 2).sum(1)
+        losses.append(float((per[:NS].cpu() / per_or).mean()))
+    record("config2_gradient_signs_along_the_oracle_trajectory_b128",
+           **{f"sign_agree_it{k}": v for k, v in zip((0, 1, 2, 4, 9), signs)},
+           **{f"grad_cos_it{k}": v for k, v in zip((0, 1, 2, 4, 9), coss)},
+           **{f"loss_ratio_it{k}": v for k, v in zip((0, 1, 2, 4, 9), losses)})
+    assert signs[0] >= 0.99, signs                # iteration 0: the start point is exactly the oracle's
+    assert min(signs) >= 0.985, signs             # later iterates: larger |delta|, same bar within half a percent
+    assert min(coss) > 0.999, coss
+    assert all(0.99 < r < 1.01 for r in losses), losses
+
+
+def cos_sim_rows(a, b):
+    a, b = a.double(), b.double()
+    return float(((a * b).sum(1) / (a.norm(dim=1) * b.norm(dim=1))).min())
+
+
+def test_config1_fare_pgd_b32_b8():
+    """configs[0] (the reference's own CPU-runnable case) THROUGH THE HIP PATH as an attack: FARE PGD 10-step eps=4/255
+    on ViT-B/32, batch 8, torch.rand images (seed 0), delta0 ~ U(-eps, eps) (seed 1) - exactly the problem bench.py's
+    cpu_baseline times - against oracle pgd_ref (train/pgd_train.py:5-68).  The engine's fp32 mode is the tight check
+    (identical pixels >= 0.99, final loss within 1 %); the bf16 mode is held to the layered bar."""
+    torch.set_num_threads(32)
+    cfg = V.VIT_B_32
+    w = V.init_weights(cfg, seed=0)
+    ref = V.ClipVisionModelRef(cfg, w).eval()
+    B = 8
+    x = torch.rand(B, 3, 224, 224, generator=torch.Generator().manual_seed(0))
+    d0 = torch.zeros_like(x).uniform_(-EPS, EPS, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        e0c = ref(x, False)
+    x_or, trace, _ = _oracle_pgd_trajectory(ref, x, d0, e0c)
+    with torch.no_grad():
+        l_or = ((ref(x_or, False) - e0c) ** 2).sum(1)
+    wd = {k: v.to(dev()) for k, v in w.items()}
+    out = {}
+    for prec in ("fp32", "bf16"):
+        eng = R.VitEngine(to_cfg(cfg), wd, precision=prec, max_batch=B)
+        model = R.ClipVisionModel(eng).eval()
+        xd = x.to(dev())
+        e0 = model(xd, False)
+        wrap = R.ComputeLossWrapper(e0, None, "mean", "l2", 100.)
+        xa = R.pgd(model, wrap, xd, None, "linf", EPS, 10, STEP, False, perturbation=d0.to(dev()), mode="max")
+        assert torch.equal(xa, R.pgd(model, wrap, xd, None, "linf", EPS, 10, STEP, False, perturbation=d0.to(dev()), mode="max"))
+        ball_and_range(xa, xd)
+        # first-iteration gradient at the oracle's own start point
+        _, _, _, g0 = eng.fwd_inputgrad(xd, d0.to(dev()), "l2", "mean", e0, None, False)
+        sign0 = float(np.mean(np.sign(g0.cpu().numpy()) == np.sign(trace[0]["grad"])))
+        with torch.no_grad():
+            l_hip = ((ref(xa.cpu(), False) - e0c) ** 2).sum(1)         # both judged by the oracle encoder
+        out[prec] = dict(same=float((xa.cpu() == x_or).float().mean()), loss_ratio=float((l_hip / l_or).mean()),
+                         sign0=sign0, emb_rel=float((e0.cpu() - e0c).abs().max() / e0c.abs().max()))
+        eng.close()
+    record("config1_fare_pgd_b32_b8", **{f"{k}_{p}": v for p, d in out.items() for k, v in d.items()})
+    torch.set_num_threads(8)
+    assert out["fp32"]["emb_rel"] < 1e-4, out                      # north_star: fp32 embeddings within 1e-4 relative
+    assert out["fp32"]["same"] >= 0.99 and 0.99 < out["fp32"]["loss_ratio"] < 1.01, out
+    assert out["fp32"]["sign0"] > 0.999, out
+    assert out["bf16"]["sign0"] > 0.98 and out["bf16"]["same"] > 0.70 and 0.97 < out["bf16"]["loss_ratio"] < 1.03, out
