@@ -40,10 +40,18 @@ int rvlm_k_gemm_set_variant(int v);
 #define RVLM_GEMM_K_256Q 8        /* 4-wave persistent kernel (EXPERIMENTAL builds only) */
 #define RVLM_GEMM_K_SPLITK 16     /* split-K slabs on the 128x128 kernel + splitk_reduce_kernel */
 #define RVLM_GEMM_K_STRIP 32      /* remainder rows computed by the persistent kernel's strip phase (same launch) */
+#define RVLM_GEMM_K_PINGPONG 64   /* gemm_bf16_nt_256x_kernel, the persistent kernel with phase-shifted wave groups */
 int rvlm_k_gemm_last_kernels(void);
 /* persistent 256x256 kernel: device buffer of 256*8*4 uint64 receiving per-tile s_memtime stamps (tile start, first
  * K-step done, mainloop done, epilogue issued); NULL switches tracing off */
 int rvlm_k_gemm_set_trace(void* ptr);
+/* Phase-shifted (ping-pong) persistent kernel, gemm_bf16_256x.hip: `mask` bit e sends epilogue kind e (0 bf16, 1 fp32 +
+ * residual, 2 activation pair, 3 x stored act', 4 fp32) to it for K <= kmax when the shape qualifies; mask < 0 restores
+ * the environment / default (RVLM_GEMM_PINGPONG, RVLM_GEMM_PINGPONG_KMAX).  rvlm_k_gemm_x_set_trace: device buffer of
+ * 256 * 8 * 26 uint64 receiving, per workgroup and wave, s_memtime at kernel start / end and at the start of the MFMAs,
+ * the end of the MFMAs and the end of the epilogue of the wave's first 8 tiles; NULL switches tracing off. */
+int rvlm_k_gemm_set_pingpong(int mask, int kmax);
+int rvlm_k_gemm_x_set_trace(void* ptr);
 /* persistent kernel timing experiments (results become garbage): bit 0 no operand DMA, bit 1 no MFMA, bit 2 no LDS
  * fragment reads; 0 = normal */
 int rvlm_k_gemm_set_ablate(int v);

@@ -185,6 +185,7 @@ splitk_reduce_kernel(const float* __restrict__ slabs, int splitk, GemmBf16 p) {
 
 
 int gemm_bf16_nt_256p(const GemmBf16& p, int* rows_done, hipStream_t s);
+int gemm_bf16_nt_256x(const GemmBf16& p, int* rows_done, hipStream_t s);
 #ifdef RVLM_EXPERIMENTAL_GEMM   // ablation kernels (make EXPERIMENTAL=1): not part of the shipped library
 int gemm_bf16_nt_256(const GemmBf16& p, int* rows_done, hipStream_t s);
 int gemm_bf16_nt_256q(const GemmBf16& p, int* rows_done, hipStream_t s);
@@ -214,6 +215,17 @@ static int gemm_persist() {
 // kernel and the 128x128 kernel.)
 static int g_gemm_variant = -1;
 void gemm_set_variant(int v) { g_gemm_variant = v; }
+// RVLM_GEMM_PINGPONG: bit mask over epilogue kinds (GemmEpi) that take gemm_bf16_256x.hip; RVLM_GEMM_PINGPONG_KMAX: largest K
+static int g_pingpong_mask = -1, g_pingpong_kmax = -1;
+static int gemm_pingpong_mask() {
+    if (g_pingpong_mask < 0) { const char* e = getenv("RVLM_GEMM_PINGPONG"); g_pingpong_mask = e ? atoi(e) : RVLM_PINGPONG_DEFAULT_MASK; }
+    return g_pingpong_mask;
+}
+static int gemm_pingpong_kmax() {
+    if (g_pingpong_kmax < 0) { const char* e = getenv("RVLM_GEMM_PINGPONG_KMAX"); g_pingpong_kmax = e ? atoi(e) : RVLM_PINGPONG_DEFAULT_KMAX; }
+    return g_pingpong_kmax;
+}
+void gemm_set_pingpong(int mask, int kmax) { g_pingpong_mask = mask; g_pingpong_kmax = kmax; }
 static int gemm_variant() {
     if (g_gemm_variant < 0) {
         const char* e = getenv("RVLM_GEMM_VARIANT");
@@ -367,8 +379,18 @@ int gemm_bf16_nt(const GemmBf16& p, hipStream_t s) {
         else
 #endif
         {
-            rc = gemm_bf16_nt_256p(p, &done, s);
-            if (done) g_last_kernels |= RVLM_GEMM_K_PERSISTENT | (done > (p.M / 256) * 256 ? RVLM_GEMM_K_STRIP : 0);
+            rc = RVLM_OK;
+            // the phase-shifted (ping-pong) form of the persistent kernel, per epilogue kind (bit e of the mask) and up
+            // to a K limit: it hides the fused epilogue under the other wave group's MFMAs, which pays where the
+            // epilogue is a large share of the tile (K = 1024 shapes, fp32 / activation epilogues)
+            if (((gemm_pingpong_mask() >> p.epi) & 1) && p.K <= gemm_pingpong_kmax()) {
+                rc = gemm_bf16_nt_256x(p, &done, s);
+                if (done) g_last_kernels |= RVLM_GEMM_K_PINGPONG | (done > (p.M / 256) * 256 ? RVLM_GEMM_K_STRIP : 0);
+            }
+            if (!rc && !done) {
+                rc = gemm_bf16_nt_256p(p, &done, s);
+                if (done) g_last_kernels |= RVLM_GEMM_K_PERSISTENT | (done > (p.M / 256) * 256 ? RVLM_GEMM_K_STRIP : 0);
+            }
         }
         if (rc) return rc;
         if (done >= p.M) return RVLM_OK;

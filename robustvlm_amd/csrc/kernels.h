@@ -60,6 +60,14 @@ struct GemmBf16 {
                                         // rows [b*N, (b+1)*N) of Bw (the split-K weight-gradient GEMM, gemm_bf16_wgrad)
 };
 int gemm_bf16_nt(const GemmBf16& p, hipStream_t s);
+// default routing to the phase-shifted persistent kernel (gemm_bf16_256x.hip): epilogue-kind mask and K limit, from
+// same-box A/Bs on the encoder's shapes (profiles/r03_*); RVLM_GEMM_PINGPONG / RVLM_GEMM_PINGPONG_KMAX override
+#ifndef RVLM_PINGPONG_DEFAULT_MASK
+#define RVLM_PINGPONG_DEFAULT_MASK 0
+#endif
+#ifndef RVLM_PINGPONG_DEFAULT_KMAX
+#define RVLM_PINGPONG_DEFAULT_KMAX 1024
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // LayerNorm over the last dim (eps 1e-5, biased variance), one wave per row.

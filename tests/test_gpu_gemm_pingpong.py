@@ -1,0 +1,121 @@
+"""gemm_bf16_256x.hip - the persistent GEMM with phase-shifted wave groups - against an fp32/fp64 torch
+product AND against the lockstep persistent kernel it replaces on the same operands: every epilogue, the shortest K it
+takes, one tile per workgroup and many, a weight-panel switch inside a workgroup's walk (N = 3072), the remainder rows
+riding in the same launch, and the kernel family asserted through rvlm_k_gemm_last_kernels()."""
+import pytest
+import torch
+
+from robustvlm_amd import _lib as L
+from tests.gpu_helpers import dev, lib, rel_max, gemm_bf16, act_ref, dact_ref, K_PERSISTENT, K_STRIP
+
+pytestmark = pytest.mark.gpu
+K_PINGPONG = 64
+
+
+@pytest.fixture()
+def pingpong():
+    l = lib()
+    l.rvlm_k_gemm_set_variant(3)
+    l.rvlm_k_gemm_set_pingpong(31, 1 << 30)
+    yield l
+    l.rvlm_k_gemm_set_pingpong(-1, -1)
+    l.rvlm_k_gemm_set_variant(-1)
+
+
+def operands(M, N, K, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    A = torch.randn(M, K, generator=g, device=dev()).bfloat16()
+    Bw = (torch.randn(N, K, generator=g, device=dev()) * K ** -0.5).bfloat16()
+    bias = torch.randn(N, generator=g, device=dev())
+    return g, A, Bw, bias
+
+
+def lockstep(l, *a, **kw):
+    """the same call on gemm_bf16_nt_256p_kernel"""
+    l.rvlm_k_gemm_set_pingpong(0, 0)
+    try:
+        return gemm_bf16(*a, **kw)
+    finally:
+        l.rvlm_k_gemm_set_pingpong(31, 1 << 30)
+
+
+@pytest.mark.parametrize("M,N,K", [(16384, 1024, 512),            # one tile per workgroup, the shortest K (nk = 8)
+                                   (16384 + 128, 1024, 1024),     # + remainder rows (strip phase)
+                                   (32896, 3072, 1024),           # qkv forward: 6 tiles per workgroup, panel switches
+                                   (32896, 1024, 3072)])          # qkv dgrad: 2 tiles, 48 K-steps
+def test_pingpong_plain_and_fp32(pingpong, M, N, K):
+    l = pingpong
+    g, A, Bw, bias = operands(M, N, K, M + N + K)
+    fam = K_PINGPONG | (K_STRIP if M % 256 else 0)
+    acc = A.float() @ Bw.float().t()
+    out, _ = gemm_bf16(A, Bw, epi=4, bias=bias, expect=fam)             # fp32 out: only accumulation-order error
+    assert rel_max(out, acc + bias) < 3e-5, "operand staging / fragment layout / K rotation"
+    ref_l, _ = lockstep(l, A, Bw, epi=4, bias=bias, expect=K_PERSISTENT | (K_STRIP if M % 256 else 0))
+    assert rel_max(out, ref_l) < 2e-5                                    # same products, rotated fp32 sum order
+    assert torch.equal(out[(M // 256) * 256:], ref_l[(M // 256) * 256:])     # the strip phase is the same code
+    out, _ = gemm_bf16(A, Bw, epi=4, expect=fam)                         # null bias
+    assert rel_max(out, acc) < 3e-5
+    outb, _ = gemm_bf16(A, Bw, epi=0, bias=bias, expect=fam)
+    assert rel_max(outb.float(), acc + bias) < 1e-2
+    refb, _ = lockstep(l, A, Bw, epi=0, bias=bias)
+    assert float((outb != refb).float().mean()) < 2e-3                   # bf16 rounding of sums that differ in the last fp32 bits
+    # deterministic
+    again, _ = gemm_bf16(A, Bw, epi=0, bias=bias, expect=fam)
+    assert torch.equal(outb, again)
+
+
+@pytest.mark.parametrize("M,N,K", [(16384, 1024, 1024), (32896, 1024, 1024), (32896, 1024, 4096)])
+def test_pingpong_fp32_residual(pingpong, M, N, K):
+    """out-proj / fc2 forward: fp32 out = acc + bias + fp32 residual, also IN PLACE (out aliases the residual)."""
+    l = pingpong
+    g, A, Bw, bias = operands(M, N, K, 3 * M + K)
+    res = torch.randn(M, N, generator=g, device=dev())
+    fam = K_PINGPONG | (K_STRIP if M % 256 else 0)
+    want = (A.float() @ Bw.float().t()).double() + bias.double() + res.double()
+    out, _ = gemm_bf16(A, Bw, epi=1, bias=bias, residual=res, expect=fam)
+    assert rel_max(out, want) < 3e-5
+    inplace = res.clone()
+    Ap = torch.zeros((M + 255) // 256 * 256, K, dtype=torch.bfloat16, device=dev())
+    Ap[:M] = A
+    L.check(l.rvlm_k_gemm_bf16_nt(Ap.data_ptr(), K, Bw.data_ptr(), K, M, N, K, Ap.shape[0], 1, bias.data_ptr(),
+                                  inplace.data_ptr(), N, None, None, inplace.data_ptr(), 0, L.stream_ptr()), "gemm")
+    torch.cuda.synchronize()
+    assert l.rvlm_k_gemm_last_kernels() == fam
+    assert torch.equal(inplace, out)
+
+
+@pytest.mark.parametrize("act", [0, 1])
+def test_pingpong_activation_epilogues(pingpong, act):
+    """fc1 forward (activation pair: act(h) and act'(h), and the one-output forward-only form) and the fc2 dgrad
+    (x stored act'(h)) at the encoder's shape."""
+    l = pingpong
+    M, N, K = 32896, 4096, 1024
+    g, A, Bw, bias = operands(M, N, K, 11 + act)
+    fam = K_PINGPONG | K_STRIP
+    h = (A.float() @ Bw.float().t()) + bias
+    out, pre = gemm_bf16(A, Bw, epi=2, bias=bias, act=act, expect=fam)
+    assert rel_max(pre.float(), dact_ref(h.double(), act)) < 1.5e-2
+    assert rel_max(out.float(), act_ref(h.double(), act)) < 1.5e-2
+    ref_o, ref_p = lockstep(l, A, Bw, epi=2, bias=bias, act=act)
+    assert float((out != ref_o).float().mean()) < 2e-3 and float((pre != ref_p).float().mean()) < 2e-3
+    # forward-only callers: out_pre = null -> one output, four epilogue steps
+    Ap = torch.zeros((M + 255) // 256 * 256, K, dtype=torch.bfloat16, device=dev())
+    Ap[:M] = A
+    only = torch.zeros(M, N, dtype=torch.bfloat16, device=dev())
+    L.check(l.rvlm_k_gemm_bf16_nt(Ap.data_ptr(), K, Bw.data_ptr(), K, M, N, K, Ap.shape[0], 2, bias.data_ptr(),
+                                  only.data_ptr(), N, None, None, None, act, L.stream_ptr()), "gemm")
+    torch.cuda.synchronize()
+    assert l.rvlm_k_gemm_last_kernels() == fam
+    assert torch.equal(only, out)
+    del ref_o, ref_p, only
+    hp = torch.randn(M, N, generator=g, device=dev()).bfloat16()
+    out, _ = gemm_bf16(A, Bw, epi=3, h_pre=hp, act=act, expect=fam)
+    assert rel_max(out.float(), (h - bias).double() * hp.double()) < 1.5e-2
+
+
+def test_pingpong_shapes_it_does_not_take_fall_back(pingpong):
+    """tiles that do not split into whole 32-tile blocks per XCD, short K: the lockstep persistent kernel runs instead."""
+    for (M, N, K) in [(256 * 10 + 128, 256 * 30, 1024), (16384, 1024, 256), (4096, 2048, 1024)]:
+        g, A, Bw, bias = operands(M, N, K, 5)
+        out, _ = gemm_bf16(A, Bw, epi=4, bias=bias, expect=K_PERSISTENT | (K_STRIP if M % 256 else 0))
+        assert rel_max(out, (A.float() @ Bw.float().t()) + bias) < 3e-5
