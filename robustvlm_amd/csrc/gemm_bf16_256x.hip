@@ -1,32 +1,32 @@
-// bf16 MFMA GEMM for gfx950, PERSISTENT 256x256 tiles with the two wave groups of a workgroup PHASE-SHIFTED by half a
-// tile ("256x": cross-phased / ping-pong form of gemm_bf16_256p.hip).
+// bf16 MFMA GEMM for gfx950, PERSISTENT 256x256 tiles with the two wave groups of a workgroup ALTERNATING between MFMAs
+// and everything else ("256x": ping-pong form of gemm_bf16_256p.hip).
 //
 // Why: the 256p kernel's mainloop is within 4 % of what two waves per SIMD and one
 // barrier per K-step give, but its fused epilogues - 4 k (bf16) to 17 k (fp32 + residual) shader cycles beside 38 k of
-// mainloop at K = 1024 - run with all 8 waves in lockstep, i.e. with the matrix pipe idle: the kernel's own cube rate is
-// 1 440 TFLOP/s, its average over the encoder's launches 1 040.
+// mainloop at K = 1024 - run with all 8 waves in lockstep, i.e. with the matrix pipe idle.
 //
-// Structure.  A workgroup is two groups of four waves, one wave of each group per SIMD: group X owns rows [128 X, +128) of
-// "its" 256x256 tile (wave tile 128 x 64 as in 256p, 128 accumulators per lane).  Both groups walk the SAME tile list, but
-// group 1 runs H = (nk + E) / 2 K-steps behind group 0 (nk = K / 64 steps of MFMAs per tile, E = the epilogue cut into E
-// barrier-to-barrier steps).  While one group is in its epilogue the other is in the middle of a tile and has the matrix
-// pipe to itself (a lone wave issues an MFMA every ~39 cycles against 2 x 37.5 shared), so the pipe idles only when BOTH
-// groups are out of MFMAs: never in steady state (E <= nk).
-//   * One operand stream, one barrier per step for all 8 waves (gfx950 has no sub-workgroup barrier): stage g holds the
-//     64-deep K slice (g mod nk) of the weight panel in the B ring and, in the A ring, that slice of the rows of whichever
-//     tile each group is on.  Both groups therefore always sit at the same K slice and a group starts its tile at
-//     whatever slice the stream is at: a tile's K sum is a ROTATION of 0 .. nk-1 (fp32 accumulation order differs from
-//     256p's; results agree to fp32 rounding of the sum).  The workgroup keeps its weight panel as long as it can (tile
-//     order below); when the panel changes group 0 waits the H - E steps group 1 still needs the old one.
-//   * Operand requests are made by whoever is NOT in MFMAs: both groups computing -> the 256p split roles (group 1 all
-//     of B right after the barrier, group 0 all of A at the end of its step); one group computing -> the other one
-//     requests everything right after the barrier and the computing group issues nothing but MFMAs and fragment reads.
-//   * Epilogue staging (wave-private LDS transpose -> full-line stores) lives in the A-ring half of the group that is in
-//     its epilogue: that half is not requested for steps in which its group does not compute.
-//   * LDS 160 KiB as in 256p: A ring 3 x 32 KiB (two steps ahead), B ring 2 x 32 KiB (one step ahead).
+// Structure.  A workgroup is two groups of four waves, one wave of each group per SIMD; group X owns rows [128 X, +128) of
+// every 256x256 tile of the workgroup's list (wave tile 128 x 64 as in 256p, 128 accumulators per lane).  Time is cut
+// into steps of one 64-deep K slice, one s_barrier per step for all 8 waves.  In every step exactly ONE group issues
+// MFMAs: group 0 runs its half of tile i for nk = K / 64 steps, then group 1 runs its half of tile i for nk steps,
+// and so on.  The group that is not in MFMAs
+//   * requests the operands of the stage two steps ahead (B: the 256 weight rows, A: the 128 rows of the computing
+//     group) - the computing group issues nothing but MFMAs and LDS fragment reads, so no wave of the matrix pipe's
+//     feeder ever waits in the CU's texture queue, and
+//   * runs the epilogue of the half tile it has just finished, cut into E steps (bias, activation pair / x act' /
+//     fp32 residual, wave-private LDS transpose, full-line stores), then idles (requests only) until its next turn.
+// A lone wave issues an MFMA every ~39 cycles (profiles/r02_gemm_timeline_split_fine.log), two sharing a SIMD one every
+// 37.5: the pipe is fed at the same rate, and the epilogue no longer costs pipe time.  The price: the weight panel is
+// fetched once per HALF tile (operand bytes per FLOP x 1.5; they come from L2, the panel is shared by the XCD's
+// workgroups), and 4 waves instead of 8 hide MFMA / LDS latency.
+//   * LDS 160 KiB: 3 stages x (A 16 KiB + B 32 KiB), i.e. BOTH operands two steps ahead (the first form of this kernel kept
+//     256p's rings - B one step ahead - and shared the stream between the groups: a request then had to land inside a
+//     ~1 300-cycle step and every step took 2 700-3 100 cycles, profiles/r03_gemm_pingpong_v1_shared_stream.log) + 16 KiB of
+//     epilogue staging (only one group is in its epilogue at a time).
+//   * The K order of a tile is 0 .. nk-1 as in 256p and the MFMA order inside a slice is the same: results are
+//     bit-identical to gemm_bf16_nt_256p_kernel.
 //
-// Requirements (else the dispatcher keeps 256p): N % 256 == 0, K % 128 == 0, K >= 512, (M / 256) % (32 / nb) == 0 and
-// tiles % 256 == 0 (every workgroup gets the same number of tiles, every XCD whole 32-tile blocks), no batched form.
+// Requirements (else the dispatcher keeps 256p): N % 256 == 0, K % 128 == 0, K >= 512, no batched form.
 #include "kernels.h"
 #include "gemm_persist.h"
 #include "gemm_strip.h"
@@ -34,16 +34,19 @@
 
 namespace rvlm {
 
-constexpr int X_HALF = P_OPER_BYTES / 2;   // one group's 128 rows of an A stage
+constexpr int X_A_BYTES = 128 * 128;                 // one stage of A: the computing group's 128 rows x 64 k
+constexpr int X_STAGE = X_A_BYTES + P_OPER_BYTES;    // + 256 weight rows x 64 k = 48 KiB
+constexpr int X_STAGING = 3 * X_STAGE;               // 4 waves x 4 KiB behind the ring
 
 template <int EPI, int ACT, bool HAS_PRE>
 __global__ void __launch_bounds__(512)
-gemm_bf16_nt_256x_kernel(GemmBf16 p, int nb, int mblocks, int blocks_per_xcd, int m_total) {
+gemm_bf16_nt_256x_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     constexpr bool OUT_F32 = (EPI == EPI_F32_RESID || EPI == EPI_F32);
     // epilogue steps: one 32 x 64 bf16 block (4 full-line stores) or one 32 x 32 fp32 sub-tile per step; the activation
     // pair (two outputs, VALU-bound) per 32 x 32 sub-tile
     constexpr int E = (OUT_F32 || (EPI == EPI_BF16_ACT && HAS_PRE)) ? 8 : 4;
+    const int ntiles = tiles_m * tiles_n;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -60,61 +63,22 @@ gemm_bf16_nt_256x_kernel(GemmBf16 p, int nb, int mblocks, int blocks_per_xcd, in
     const auto bias_rs = make_rsrc(p.bias ? (const void*)p.bias : (const void*)p.out, p.bias ? (unsigned)p.N * 4u : 0u);
     const auto r_rs = make_rsrc(EPI == EPI_F32_RESID ? (const void*)p.residual : (const void*)p.out, out_elems * 4u);
 
-    // ---- tile list of this workgroup: XCD x (= blockIdx & 7) owns blocks [x * bpx, (x + 1) * bpx) of 32 tiles (mb m-tiles
-    // x nb n-tiles, the L2 working set of 256p's grouped order), numbered m-fastest inside an n-set so that the weight
-    // panel of a workgroup changes as rarely as possible; workgroup l of the XCD keeps position (l % mb, l / mb) in
-    // every block.
-    const int T = blocks_per_xcd;
-    const int mb = 32 / nb;
-    const int xl = (int)blockIdx.x >> 3, li = xl % mb, lj = xl / mb;
-    const int blk0 = ((int)blockIdx.x & 7) * blocks_per_xcd;
-    auto tile_m0 = [&](int t) { return (((blk0 + t) % mblocks) * mb + li) * P_M; };
-    auto tile_n0 = [&](int t) { return (((blk0 + t) / mblocks) * nb + lj) * P_N; };
-
+    // tile -> (m, n): 256p's XCD-aware grouped order
+    auto tile_origin = [&](int tile, int& m0, int& n0) __attribute__((always_inline)) {
+        const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = tile & 7, loc = tile >> 3;
+        const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+        const int group_size = p.group_m * tiles_n;
+        const int first_m = (t / group_size) * p.group_m;
+        const int gm = min(tiles_m - first_m, p.group_m);
+        m0 = __builtin_amdgcn_readfirstlane((first_m + (t % group_size) % gm) * P_M);
+        n0 = __builtin_amdgcn_readfirstlane(((t % group_size) / gm) * P_N);
+    };
     const int nk = p.K / P_K;
-    const int P = nk + E, H = P >> 1;      // period of a group's tile, lag of group 1 (nk and E even)
-    const int stall_len = H - E;           // extra idle steps of a group behind a tile whose successor has another panel
+    const int ntw = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // tiles of this workgroup
 
-    // ---- schedule state, identical in every wave (scalar): for each group Z its mode at steps g, g+1, g+2 and the
-    // tile rows / panel of the frontier.  cur* is the cursor of group Z at time g + 2.
-    // (every field is a separate scalar: a runtime-indexed array of flags would live in vector registers)
-    struct Cur { int tile, ph, per, m0, n0; };
-    Cur cur0, cur1;
-    bool c0_0, c0_1, c1_0, c1_1, c2_0, c2_1;   // cK_Z: group Z computes at step g + K
-    int n1_0, n1_1, n2_0, n2_1, m2_0, m2_1;    // panel at g+1 / g+2, tile rows at g+2
-    auto cur_load = [&](Cur& c) __attribute__((always_inline)) {
-        if (c.tile < T) {
-            c.m0 = tile_m0(c.tile);
-            c.n0 = tile_n0(c.tile);
-            const int nn = c.tile + 1 < T ? tile_n0(c.tile + 1) : c.n0;
-            c.per = P + (nn != c.n0 ? stall_len : 0);
-        } else {
-            c.per = 1 << 30;
-        }
-    };
-    auto cur_computes = [&](const Cur& c) __attribute__((always_inline)) { return c.tile < T && c.ph >= 0 && c.ph < nk; };
-    auto cur_step = [&](Cur& c) __attribute__((always_inline)) {
-        if (++c.ph == c.per) { ++c.tile; c.ph = 0; cur_load(c); }
-    };
-    cur0.tile = 0; cur0.ph = 0; cur0.m0 = 0; cur0.n0 = 0; cur_load(cur0);
-    cur1.tile = 0; cur1.ph = -H; cur1.m0 = 0; cur1.n0 = 0; cur_load(cur1);
-    c0_0 = cur_computes(cur0); c0_1 = cur_computes(cur1);
-    cur_step(cur0); cur_step(cur1);
-    c1_0 = cur_computes(cur0); c1_1 = cur_computes(cur1); n1_0 = cur0.n0; n1_1 = cur1.n0;
-    cur_step(cur0); cur_step(cur1);
-    c2_0 = cur_computes(cur0); c2_1 = cur_computes(cur1); n2_0 = cur0.n0; n2_1 = cur1.n0; m2_0 = cur0.m0; m2_1 = cur1.m0;
-    int kb1 = 1 % nk, kb2 = 2 % nk;         // K slice of stages g+1, g+2 (g = global step, between barrier g-1 and barrier g)
-    int sa0 = 0, sa2 = 2, sb0 = 0, sb1 = 1; // ring slots: A of stage g / g+2, B of stage g / g+1
-    auto advance = [&]() __attribute__((always_inline)) {   // g -> g + 1 (called right after a barrier)
-        c0_0 = c1_0; c0_1 = c1_1; c1_0 = c2_0; c1_1 = c2_1; n1_0 = n2_0; n1_1 = n2_1;
-        cur_step(cur0); cur_step(cur1);
-        c2_0 = cur_computes(cur0); c2_1 = cur_computes(cur1); n2_0 = cur0.n0; n2_1 = cur1.n0; m2_0 = cur0.m0; m2_1 = cur1.m0;
-        kb1 = kb2; kb2 = (kb2 + 1 == nk) ? 0 : kb2 + 1;
-        sa0 = (sa0 == 2) ? 0 : sa0 + 1; sa2 = (sa2 == 2) ? 0 : sa2 + 1;
-        sb0 ^= 1; sb1 ^= 1;
-    };
-
-    // ---- operand requests.  One DMA instruction moves 8 rows x 128 B; row r of a stage lives at r * 128 B of its slot,
+    // ---- the operand stream.  Stage t (t = 0, 1, ...) is K slice (t mod nk) of half tile (t div nk): group
+    // (t div nk) & 1 of tile (t div 2 nk).  It lives in ring slot t mod 3 and is requested during step t - 2 by the
+    // group that is not in MFMAs then.  One DMA instruction moves 8 rows x 128 B; row r of an operand lives at r * 128 B,
     // its 16-B chunk c holds logical chunk c ^ ((r >> 1) & 7) (first rows below are multiples of 16, so the swizzle of
     // piece j only depends on the parity of j).
     int a_loff[2], b_loff[2];
@@ -124,65 +88,52 @@ gemm_bf16_nt_256x_kernel(GemmBf16 p, int nb, int mblocks, int blocks_per_xcd, in
         a_loff[jp] = ((lane >> 3) * lda + clog * 8) * 2;
         b_loff[jp] = ((lane >> 3) * ldb + clog * 8) * 2;
     }
-    // NP pieces = rows [row0, row0 + 8 NP) of an A stage (row0 in 0..255: the group halves are stacked) from tile rows m0
-    auto req_a = [&](int slot, int row0, int m0, int kb, auto np_c) __attribute__((always_inline)) {
-        constexpr int NP = decltype(np_c)::value;
-        __attribute__((address_space(3))) char* dst = (__attribute__((address_space(3))) char*)lds + (slot * PA_SLOT + row0 * 128);
-        const int so = __builtin_amdgcn_readfirstlane(((m0 + row0) * lda + kb * P_K) * 2);
-#pragma unroll
-        for (int j = 0; j < NP; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_ptr_t)(dst + j * 1024), 16, a_loff[j & 1], so + j * 16 * lda, 0, 0);
+    // frontier = the next stage to request: its K slice, group, tile and that tile's origin; its ring slot
+    int f_k = 0, f_grp = 0, f_tile = 0, f_m0 = 0, f_n0 = 0, f_slot = 0;
+    if (ntw > 0) tile_origin(blockIdx.x, f_m0, f_n0);
+    auto frontier_step = [&]() __attribute__((always_inline)) {
+        f_slot = (f_slot == 2) ? 0 : f_slot + 1;
+        if (++f_k == nk) {
+            f_k = 0;
+            f_grp ^= 1;
+            if (f_grp == 0 && ++f_tile < ntw) tile_origin(blockIdx.x + f_tile * gridDim.x, f_m0, f_n0);
+        }
     };
-    auto req_b = [&](int slot, int row0, int n0, int kb, auto np_c) __attribute__((always_inline)) {
-        constexpr int NP = decltype(np_c)::value;
-        __attribute__((address_space(3))) char* dst = (__attribute__((address_space(3))) char*)lds + (PB_BASE + slot * PB_SLOT + row0 * 128);
-        const int so = __builtin_amdgcn_readfirstlane(((n0 + row0) * ldb + kb * P_K) * 2);
+    // NPA / NPB pieces of the frontier stage: rows [arow, +8 NPA) of its A half, rows [brow, +8 NPB) of the weight panel
+    auto request = [&](int arow, int brow, auto npa_c, auto npb_c) __attribute__((always_inline)) -> bool {
+        constexpr int NPA = decltype(npa_c)::value, NPB = decltype(npb_c)::value;
+        if (f_tile >= ntw) return false;
+        __attribute__((address_space(3))) char* dst = (__attribute__((address_space(3))) char*)lds + f_slot * X_STAGE;
+        const int sob = __builtin_amdgcn_readfirstlane(((f_n0 + brow) * ldb + f_k * P_K) * 2);
 #pragma unroll
-        for (int j = 0; j < NP; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, (lds_ptr_t)(dst + j * 1024), 16, b_loff[j & 1], so + j * 16 * ldb, 0, 0);
+        for (int j = 0; j < NPB; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, (lds_ptr_t)(dst + X_A_BYTES + brow * 128 + j * 1024), 16, b_loff[j & 1],
+                                                     sob + j * 16 * ldb, 0, 0);
+        const int soa = __builtin_amdgcn_readfirstlane(((f_m0 + f_grp * 128 + arow) * lda + f_k * P_K) * 2);
+#pragma unroll
+        for (int j = 0; j < NPA; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_ptr_t)(dst + arow * 128 + j * 1024), 16, a_loff[j & 1],
+                                                     soa + j * 16 * lda, 0, 0);
+        return true;
     };
     const std::integral_constant<int, 2> np2;
     const std::integral_constant<int, 4> np4;
     const std::integral_constant<int, 8> np8;
-    // Right after barrier g-1 (state = step g).  Both groups in MFMAs: group 1 requests B of stage g+1.  Otherwise the
-    // group that is not in MFMAs (group 0 when neither is) requests B of stage g+1 and, for every group that computes at
-    // g+2, its half of A of stage g+2 (4 pieces per wave and half).
-    auto duties_after_barrier = [&]() __attribute__((always_inline)) {
-        const bool cc = c0_0 && c0_1;
-        const bool need_b = c1_0 || c1_1;
-        const int nb1 = c1_0 ? n1_0 : n1_1;
-        if (cc) {
-            if (X == 1 && need_b) req_b(sb1, wi * 64, nb1, kb1, np8);
-        } else if (X == (c0_0 ? 1 : 0)) {
-            if (need_b) req_b(sb1, wi * 64, nb1, kb1, np8);
-            if (c2_0) req_a(sa2, wi * 32, m2_0, kb2, np4);
-            if (c2_1) req_a(sa2, 128 + wi * 32, m2_1, kb2, np4);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    // End of step g in a both-compute step: group 0 requests A of stage g+2 (wave wi: rows [64 wi, +64) of the stacked
-    // stage, i.e. the half of group wi >> 1).  Returns whether this wave issued (its 8 pieces may stay in flight).
-    auto duties_end_of_step = [&]() __attribute__((always_inline)) -> bool {
-        if (!(c0_0 && c0_1) || X != 0) return false;
-        const bool upper = (wi >> 1) != 0;
-        if (!(upper ? c2_1 : c2_0)) return false;
-        req_a(sa2, wi * 64, upper ? m2_1 : m2_0, kb2, np8);
-        return true;
-    };
 
-    // ---- fragments (as in 256p): per-lane part by k-slice + ring slot offsets kept opaque to the optimiser
+    // ---- fragments: per-lane part by k-slice + ring slot offset kept opaque to the optimiser (as in 256p)
     const int swz = (l31 >> 1) & 7;
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
     unsigned fa[4];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) fa[kk] = lds_base + (X * 128 + l31) * 128 + (((kk * 2 + hi) ^ swz) << 4);
-    const int ab_delta = PB_BASE + (wi * 64 - X * 128) * 128;
+    for (int kk = 0; kk < 4; ++kk) fa[kk] = lds_base + l31 * 128 + (((kk * 2 + hi) ^ swz) << 4);
+    const int ab_delta = X_A_BYTES + wi * 64 * 128;
+    int c_slot = 0;                                      // ring slot of the stage of the current step
     f32x16 acc[4][2];
     i32x4 a0[4], b0[2], a1[4], b1[2];
-    auto load_frags = [&](int sa, int sb, int kk, i32x4 (&a)[4], i32x4 (&b)[2]) __attribute__((always_inline)) {
-        int oa = sa * PA_SLOT, ob = sb * PB_SLOT + ab_delta;
-        asm volatile("" : "+s"(oa), "+s"(ob));
-        const unsigned aa = fa[kk] + oa, bb = fa[kk] + ob;
+    auto load_frags = [&](int slot, int kk, i32x4 (&a)[4], i32x4 (&b)[2]) __attribute__((always_inline)) {
+        int oa = slot * X_STAGE;
+        asm volatile("" : "+s"(oa));
+        const unsigned aa = fa[kk] + oa, bb = aa + ab_delta;
         asm volatile("ds_read_b128 %0, %1" : "=v"(a[0]) : "v"(aa));
         asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(a[1]) : "v"(aa));
         asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(a[2]) : "v"(aa));
@@ -198,12 +149,12 @@ gemm_bf16_nt_256x_kernel(GemmBf16 p, int nb, int mblocks, int blocks_per_xcd, in
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b[j]),
                                                                     __builtin_bit_cast(bf16x8, a[i]), acc[i][j], 0, 0, 0);
     };
-    // 8 MFMAs of one k-slice with the 6 fragment reads of slice kk of stage (sa, sb) issued between them
-    auto mma_lf = [&](const i32x4 (&a)[4], const i32x4 (&b)[2], int sa, int sb, int kk, i32x4 (&na)[4], i32x4 (&nb_)[2])
+    // 8 MFMAs of one k-slice with the 6 fragment reads of slice kk of the stage in `slot` issued between them
+    auto mma_lf = [&](const i32x4 (&a)[4], const i32x4 (&b)[2], int slot, int kk, i32x4 (&na)[4], i32x4 (&nb_)[2])
                       __attribute__((always_inline)) {
-        int oa = sa * PA_SLOT, ob = sb * PB_SLOT + ab_delta;
-        asm volatile("" : "+s"(oa), "+s"(ob));
-        const unsigned aa = fa[kk] + oa, bb = fa[kk] + ob;
+        int oa = slot * X_STAGE;
+        asm volatile("" : "+s"(oa));
+        const unsigned aa = fa[kk] + oa, bb = aa + ab_delta;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -231,7 +182,7 @@ gemm_bf16_nt_256x_kernel(GemmBf16 p, int nb, int mblocks, int blocks_per_xcd, in
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) { init_acc(mi, 0); init_acc(mi, 1); }
 
-    // optional timeline (test hook rvlm_k_gemm_set_trace): per wave, s_memtime at kernel start / end and at the start of
+    // optional timeline (test hook rvlm_k_gemm_x_set_trace): per wave, s_memtime at kernel start / end and at the start of
     // the MFMAs, the end of the MFMAs and the end of the epilogue of each of its first 8 tiles: [wg][wave][2 + 3 * 8]
     auto stamp = [&](int k) {
         if (p.trace) {
@@ -241,10 +192,11 @@ gemm_bf16_nt_256x_kernel(GemmBf16 p, int nb, int mblocks, int blocks_per_xcd, in
     };
     stamp(0);
 
-    // ---- prologue: B of stage 0, group 0's half of A of stages 0 and 1 (steps 0 and 1 are group 0's: H >= 6) ----
-    req_b(0, w * 32, tile_n0(0), 0, np4);
-    req_a(0, w * 16, tile_m0(0), 0, np2);
-    req_a(1, w * 16, tile_m0(0), 1 % nk, np2);
+    // ---- prologue: stages 0 and 1, requested by all 8 waves (2 + 4 pieces each per stage) ----
+    request(w * 16, w * 32, np2, np4);
+    frontier_step();
+    request(w * 16, w * 32, np2, np4);
+    frontier_step();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -254,81 +206,99 @@ gemm_bf16_nt_256x_kernel(GemmBf16 p, int nb, int mblocks, int blocks_per_xcd, in
     const int st32_loff = ((lane >> 3) * ldo + (lane & 7) * 4) * 4;   // fp32: 8 rows x 128 B (32 columns)
     const int h16_loff = ((lane >> 2) * ldo + (lane & 3) * 8) * 2;    // bf16 32-column sub-tile: 16 rows x 64 B
     const int r0 = lane >> 3;
+    const unsigned ebuf = lds_base + X_STAGING + wi * P_EPI_WAVE;
+    const unsigned w16_pre = ebuf + l31 * 128 + ((hi ^ (l31 & 15)) << 3);
+    const unsigned w32_pre = ebuf + l31 * 128 + ((hi ^ (l31 & 7)) << 4);
+    const unsigned r16_a = ebuf + r0 * 128 + (((lane & 7) ^ (r0 >> 1)) << 4);
+    const unsigned r16_b = ebuf + r0 * 128 + (((lane & 7) ^ (r0 >> 1) ^ 4) << 4);
+    const unsigned r32 = ebuf + r0 * 128 + (((lane & 7) ^ r0) << 4);
 
-    // a step in which this group neither computes nor stores: operand requests (if it is the requesting group), barrier
-    auto idle_step = [&]() __attribute__((always_inline)) {
-        duties_after_barrier();
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // end of a step (every wave): advance the step bookkeeping behind the barrier
+    auto step_end = [&]() __attribute__((always_inline)) {
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        advance();
+        c_slot = (c_slot == 2) ? 0 : c_slot + 1;
+        frontier_step();
+    };
+    // a step of the group that is NOT in MFMAs, without epilogue work: request the frontier stage (12 pieces per wave),
+    // make sure the previous step's requests have landed, barrier
+    auto idle_step = [&]() __attribute__((always_inline)) {
+        if (request(wi * 32, wi * 64, np4, np8)) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        step_end();
     };
 
-    for (int s = 0; s < (X ? H : 0); ++s) idle_step();      // group 1 starts H steps late
+    for (int s = 0; s < (X ? nk : 0); ++s) idle_step();      // group 1's first turn comes after group 0's first half tile
 
-    for (int ti = 0; ti < T; ++ti) {
-        const int m0 = tile_m0(ti), n0 = tile_n0(ti);
-        const int stall = (ti + 1 < T && tile_n0(ti + 1) != n0) ? stall_len : 0;
+    for (int ti = 0; ti < ntw; ++ti) {
+        int m0, n0;
+        tile_origin(blockIdx.x + ti * gridDim.x, m0, n0);
         if (ti < 8) stamp(2 + 3 * ti);
-        // ---- nk steps of MFMAs.  Entering: barrier g-1 passed, stage g landed, nothing of this step done yet.
-        duties_after_barrier();
-        load_frags(sa0, sb0, 0, a0, b0);
+        // ---- nk steps of MFMAs: nothing but MFMAs and fragment reads (vmcnt(0): requests this wave made in its last idle
+        // steps must have landed before the barrier that publishes them)
+        load_frags(c_slot, 0, a0, b0);
         for (int kt = 0; kt < nk; ++kt) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
-            mma_lf(a0, b0, sa0, sb0, 1, a1, b1);
+            mma_lf(a0, b0, c_slot, 1, a1, b1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
-            mma_lf(a1, b1, sa0, sb0, 2, a0, b0);
+            mma_lf(a1, b1, c_slot, 2, a0, b0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
-            mma_lf(a0, b0, sa0, sb0, 3, a1, b1);
+            mma_lf(a0, b0, c_slot, 3, a1, b1);
             __builtin_amdgcn_sched_barrier(0);
-            if (duties_end_of_step()) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            advance();
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            step_end();
             if (kt + 1 < nk) {       // the last k-slice's MFMAs with the next stage's first fragments (its barrier is behind us)
-                duties_after_barrier();
-                mma_lf(a1, b1, sa0, sb0, 0, a0, b0);
+                mma_lf(a1, b1, c_slot, 0, a0, b0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // ---- E epilogue steps.  The first one opens with the requests (time-critical: B of the next stage has one step
-        // to land), then the tile's last 8 MFMAs.
-        duties_after_barrier();
-        float4 bv[2][4];
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq)   // (a null bias has a zero-length descriptor: out-of-range loads return 0)
-                bv[ni][gq] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
-                    bias_rs, hi * 16, __builtin_amdgcn_readfirstlane((n0 + wi * 64 + ni * 32 + 8 * gq) * 4), 0));
-        __builtin_amdgcn_sched_barrier(0);
-        mma(a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (ti < 8) stamp(3 + 3 * ti);
+        // ---- the other group's turn: E epilogue steps (the first one opens with the requests, then the tile's last 8
+        // MFMAs), then request-only steps.  The last half tile of the workgroup (group 1) has only its epilogue left.
+        const int off_steps = (X == 1 && ti + 1 == ntw) ? E : nk;
         const int m_base = m0 + X * 128, n_base = n0 + wi * 64;
+        float4 bv[2][4];
+        // side input of the epilogue (fp32 residual / stored act'(h)) of chunk cc, read in the store pattern.  VMEM returns
+        // in order, so these loads are issued IN FRONT of the step's operand requests (behind them they would not return
+        // before the whole stage has landed) and one step ahead of their use: side[cc & 1]
+        u32x4 side[2][4];
+        auto load_side = [&](int cc) __attribute__((always_inline)) {
+            if (EPI == EPI_BF16_DACT) {
+                const int so = __builtin_amdgcn_readfirstlane(((m_base + cc * 32) * ldo + n_base) * 2);
+#pragma unroll
+                for (int it = 0; it < 4; ++it) side[cc & 1][it] = __builtin_amdgcn_raw_buffer_load_b128(h_rs, st16_loff, so + it * 16 * ldo, 0);
+            } else if (EPI == EPI_F32_RESID) {
+                const int so = __builtin_amdgcn_readfirstlane(((m_base + (cc >> 1) * 32) * ldo + n_base + (cc & 1) * 32) * 4);
+#pragma unroll
+                for (int it = 0; it < 4; ++it) side[cc & 1][it] = __builtin_amdgcn_raw_buffer_load_b128(r_rs, st32_loff, so + it * 32 * ldo, 0);
+            }
+        };
 #pragma unroll
         for (int c = 0; c < E; ++c) {
-            if (c > 0) duties_after_barrier();
-            // staging: this group's half of the A slot of the current stage (not requested: the group is not computing)
-            const unsigned ebuf = lds_base + sa0 * PA_SLOT + X * X_HALF + wi * P_EPI_WAVE;
-            const unsigned w16_pre = ebuf + l31 * 128 + ((hi ^ (l31 & 15)) << 3);
-            const unsigned w32_pre = ebuf + l31 * 128 + ((hi ^ (l31 & 7)) << 4);
-            const unsigned r16_a = ebuf + r0 * 128 + (((lane & 7) ^ (r0 >> 1)) << 4);
-            const unsigned r16_b = ebuf + r0 * 128 + (((lane & 7) ^ (r0 >> 1) ^ 4) << 4);
-            const unsigned r32 = ebuf + r0 * 128 + (((lane & 7) ^ r0) << 4);
+            if (c == 0) {
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq)   // (a null bias has a zero-length descriptor: out-of-range loads return 0)
+                        bv[ni][gq] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                            bias_rs, hi * 16, __builtin_amdgcn_readfirstlane((n0 + wi * 64 + ni * 32 + 8 * gq) * 4), 0));
+                load_side(0);
+            }
+            if (c + 1 < E) load_side(c + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const bool issued = request(wi * 32, wi * 64, np4, np8);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c == 0) {
+                mma(a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ti < 8) stamp(3 + 3 * ti);
+            }
             if (E == 4) {
                 // one 32 x 64 bf16 block: bias, (x act'(h) of the forward), LDS transpose, 4 stores of 8 full lines
                 const int mi = c;
-                u32x4 side[4];
                 const int so = __builtin_amdgcn_readfirstlane(((m_base + mi * 32) * ldo + n_base) * 2);
-                if (EPI == EPI_BF16_DACT) {
-#pragma unroll
-                    for (int it = 0; it < 4; ++it) side[it] = __builtin_amdgcn_raw_buffer_load_b128(h_rs, st16_loff, so + it * 16 * ldo, 0);
-                }
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -361,7 +331,7 @@ gemm_bf16_nt_256x_kernel(GemmBf16 p, int nb, int mblocks, int blocks_per_xcd, in
                         for (int e = 0; e < 8; ++e) o[e] = (bf16_t)((float)a[e] * (float)b[e]);
                         t = __builtin_bit_cast(u32x4, o);
                     };
-                    mul8(t0, side[0]); mul8(t1, side[1]); mul8(t2, side[2]); mul8(t3, side[3]);
+                    mul8(t0, side[c & 1][0]); mul8(t1, side[c & 1][1]); mul8(t2, side[c & 1][2]); mul8(t3, side[c & 1][3]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 store16(t0, o_rs, st16_loff, so);
@@ -414,11 +384,6 @@ gemm_bf16_nt_256x_kernel(GemmBf16 p, int nb, int mblocks, int blocks_per_xcd, in
                 // fp32 output, one 32 x 32 sub-tile: (+ fp32 residual read in the store pattern), 4 stores of 8 full lines
                 const int mi = c >> 1, ni = c & 1;
                 const int so = __builtin_amdgcn_readfirstlane(((m_base + mi * 32) * ldo + n_base + ni * 32) * 4);
-                u32x4 side[4];
-                if (EPI == EPI_F32_RESID) {
-#pragma unroll
-                    for (int it = 0; it < 4; ++it) side[it] = __builtin_amdgcn_raw_buffer_load_b128(r_rs, st32_loff, so + it * 32 * ldo, 0);
-                }
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
                     const float4 v = make_float4(acc[mi][ni][gq * 4 + 0] + bv[ni][gq].x, acc[mi][ni][gq * 4 + 1] + bv[ni][gq].y,
@@ -432,7 +397,7 @@ gemm_bf16_nt_256x_kernel(GemmBf16 p, int nb, int mblocks, int blocks_per_xcd, in
 #pragma unroll
                     for (int it = 0; it < 4; ++it) {
                         const float4 x = __builtin_bit_cast(float4, t[it]);
-                        const float4 r = __builtin_bit_cast(float4, side[it]);
+                        const float4 r = __builtin_bit_cast(float4, side[c & 1][it]);
                         t[it] = __builtin_bit_cast(u32x4, make_float4(x.x + r.x, x.y + r.y, x.z + r.z, x.w + r.w));
                     }
                 }
@@ -441,16 +406,16 @@ gemm_bf16_nt_256x_kernel(GemmBf16 p, int nb, int mblocks, int blocks_per_xcd, in
                 for (int it = 0; it < 4; ++it) store16(t[it], o_rs, st32_loff, so + it * 32 * ldo);
             }
             __builtin_amdgcn_sched_barrier(0);
-            // the step's 4 stores may stay in flight; everything older (the requests of this step, side loads) has landed
-            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            advance();
+            // in flight behind this wait at most: this step's 12 requests + its 4 stores - the previous step's requests (the
+            // stage of the NEXT step) and stores are complete
+            if (issued) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            step_end();
         }
         if (ti < 8) stamp(4 + 3 * ti);
-        for (int s = 0; s < stall; ++s) idle_step();
+        for (int s = E; s < off_steps; ++s) idle_step();
     }
-    for (int s = 0; s < (X ? 0 : H); ++s) idle_step();      // group 0 keeps requesting operands for group 1's last half tile
+    for (int s = 0; s < (X ? 0 : E); ++s) idle_step();       // group 0 waits out the epilogue of group 1's last half tile
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (m_total > p.M) strip_tail<EPI, ACT>(p, p.M, m_total, lds, w, lane);
     stamp(1);
@@ -460,9 +425,9 @@ unsigned long long* g_x_trace = nullptr;    // [256 workgroups][8 waves][26 stam
 void gemm_x_set_trace(unsigned long long* ptr) { g_x_trace = ptr; }
 
 template <int EPI, int ACT, bool HAS_PRE>
-static int launch_256x(const GemmBf16& p, int nb, int mblocks, int bpx, int m_total, hipStream_t s) {
+static int launch_256x(const GemmBf16& p, int tiles_m, int tiles_n, int m_total, hipStream_t s) {
     static bool attr_set = false;
-    const int lds_bytes = 3 * PA_SLOT + 2 * PB_SLOT;
+    const int lds_bytes = X_STAGING + 4 * P_EPI_WAVE;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_nt_256x_kernel<EPI, ACT, HAS_PRE>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -471,7 +436,8 @@ static int launch_256x(const GemmBf16& p, int nb, int mblocks, int bpx, int m_to
     }
     GemmBf16 q = p;
     q.trace = g_x_trace;
-    hipLaunchKernelGGL((gemm_bf16_nt_256x_kernel<EPI, ACT, HAS_PRE>), dim3(256), dim3(512), lds_bytes, s, q, nb, mblocks, bpx, m_total);
+    const int grid = std::min(tiles_m * tiles_n, 256);
+    hipLaunchKernelGGL((gemm_bf16_nt_256x_kernel<EPI, ACT, HAS_PRE>), dim3(grid), dim3(512), lds_bytes, s, q, tiles_m, tiles_n, m_total);
     RVLM_CHECK_LAUNCH();
     return RVLM_OK;
 }
@@ -484,29 +450,27 @@ int gemm_bf16_nt_256x(const GemmBf16& p, int* rows_done, hipStream_t s) {
     const long lim = 1L << 31;
     if ((long)p.M * p.lda * 2 >= lim || (long)p.N * p.ldb * 2 >= lim || (long)p.M * p.ldo * 4 >= lim) return RVLM_OK;
     const int tiles_m = p.M / P_M, tiles_n = p.N / P_N;
-    const int nb = tiles_n % 4 == 0 ? 4 : tiles_n % 2 == 0 ? 2 : 1, mb = 32 / nb;
-    if (tiles_m % mb != 0) return RVLM_OK;
-    const int mblocks = tiles_m / mb, blocks = mblocks * (tiles_n / nb);
-    if (blocks % 8 != 0) return RVLM_OK;
     GemmBf16 q = p;
     q.M = tiles_m * P_M;
     if (q.epi == EPI_F32_RESID && !q.residual) q.epi = EPI_F32;
     static int tail_on = -1;
     if (tail_on < 0) { const char* e = getenv("RVLM_GEMM_TAIL"); tail_on = e ? atoi(e) : 1; }
     const int m_total = (tail_on && p.M > q.M) ? p.M : q.M;
-    const int bpx = blocks / 8;
+    static int group_m = -1;
+    if (group_m < 0) { const char* e = getenv("RVLM_GEMM_GROUP_M"); group_m = e ? std::max(1, atoi(e)) : 8; }
+    q.group_m = group_m;
     const bool gelu = p.act != RVLM_ACT_QUICK_GELU;
     int rc;
     switch (q.epi) {
-        case EPI_BF16: rc = launch_256x<EPI_BF16, RVLM_ACT_QUICK_GELU, false>(q, nb, mblocks, bpx, m_total, s); break;
-        case EPI_F32_RESID: rc = launch_256x<EPI_F32_RESID, RVLM_ACT_QUICK_GELU, false>(q, nb, mblocks, bpx, m_total, s); break;
-        case EPI_F32: rc = launch_256x<EPI_F32, RVLM_ACT_QUICK_GELU, false>(q, nb, mblocks, bpx, m_total, s); break;
-        case EPI_BF16_DACT: rc = launch_256x<EPI_BF16_DACT, RVLM_ACT_QUICK_GELU, false>(q, nb, mblocks, bpx, m_total, s); break;
+        case EPI_BF16: rc = launch_256x<EPI_BF16, RVLM_ACT_QUICK_GELU, false>(q, tiles_m, tiles_n, m_total, s); break;
+        case EPI_F32_RESID: rc = launch_256x<EPI_F32_RESID, RVLM_ACT_QUICK_GELU, false>(q, tiles_m, tiles_n, m_total, s); break;
+        case EPI_F32: rc = launch_256x<EPI_F32, RVLM_ACT_QUICK_GELU, false>(q, tiles_m, tiles_n, m_total, s); break;
+        case EPI_BF16_DACT: rc = launch_256x<EPI_BF16_DACT, RVLM_ACT_QUICK_GELU, false>(q, tiles_m, tiles_n, m_total, s); break;
         case EPI_BF16_ACT:
-            if (q.out_pre) rc = gelu ? launch_256x<EPI_BF16_ACT, RVLM_ACT_GELU, true>(q, nb, mblocks, bpx, m_total, s)
-                                     : launch_256x<EPI_BF16_ACT, RVLM_ACT_QUICK_GELU, true>(q, nb, mblocks, bpx, m_total, s);
-            else rc = gelu ? launch_256x<EPI_BF16_ACT, RVLM_ACT_GELU, false>(q, nb, mblocks, bpx, m_total, s)
-                           : launch_256x<EPI_BF16_ACT, RVLM_ACT_QUICK_GELU, false>(q, nb, mblocks, bpx, m_total, s);
+            if (q.out_pre) rc = gelu ? launch_256x<EPI_BF16_ACT, RVLM_ACT_GELU, true>(q, tiles_m, tiles_n, m_total, s)
+                                     : launch_256x<EPI_BF16_ACT, RVLM_ACT_QUICK_GELU, true>(q, tiles_m, tiles_n, m_total, s);
+            else rc = gelu ? launch_256x<EPI_BF16_ACT, RVLM_ACT_GELU, false>(q, tiles_m, tiles_n, m_total, s)
+                           : launch_256x<EPI_BF16_ACT, RVLM_ACT_QUICK_GELU, false>(q, tiles_m, tiles_n, m_total, s);
             break;
         default: return fail(RVLM_ERR_ARG, "gemm_bf16_nt_256x: unknown epilogue");
     }
