@@ -6,8 +6,8 @@
 // walks the LDS-resident operand in 32-row tiles with an online (running max / sum) softmax.
 //
 // Layout tricks
-//  * LDS tiles are [rows][64] bf16 (128-B rows), 16-B chunk index XOR ((row>>1)&7): ds_read_b128
-//    fragment reads are bank-conflict free.
+//  * LDS tiles are [rows][64] bf16 (128-B rows), 16-B chunk index XOR swz_key(row) (a permutation of row bits 1-3):
+//    ds_read_b128 fragment reads AND the ds_read_b64_tr_b16 transposing reads are bank-conflict free.
 //  * "Swapped" products: S^T = K.Q^T puts one query per lane (lane&31), so softmax row statistics are
 //    per-lane scalars and P^T / dS^T are already in the B-operand register layout of the next MFMA
 //    (the k index is permuted identically on both operands, so no cross-lane exchange is needed).
@@ -27,8 +27,23 @@ struct AttnLayout { long qkv_b, qkv_h, o_b, o_h; };
 
 typedef __attribute__((address_space(3))) char lds_char;
 
+// Swizzle key of a tile row: row bits (1, 3, 2) -> chunk bits (2, 1, 0).  Any bijection of those three row bits keeps the
+// row-major ds_read_b128 fragments conflict-free (the 8 same-parity rows of a 16-lane group get 8 different keys); the
+// TRANSPOSING reads (ds_read_b64_tr_b16: a 32-lane half reads 4 consecutive rows x one 64-B half row) additionally need
+// rows r and r + 2 - same bank parity - to land in DIFFERENT 64-B halves, i.e. row bit 1 on chunk bit 2.  Round 2 used
+// (row >> 1) & 7: every transposing read was a 2-way bank conflict (scripts/lds_bank_model.py: 16 of 40 extra LDS cycles
+// per query tile and wave; PMC: 32.5 % of the backward's LDS-active cycles in conflicts, profiles/r02_pmc_attention.json).
+#ifdef RVLM_ATTN_SWZ_R2     // A/B build with the round-2 swizzles (scripts/trip_attn_swz.sh)
+__device__ __forceinline__ int swz_key(int row) { return (row >> 1) & 7; }
+constexpr int DS_KEY_SHIFT = 2;
+#else
+__device__ __forceinline__ int swz_key(int row) {
+    return (((row >> 1) & 1) << 2) | (((row >> 3) & 1) << 1) | ((row >> 2) & 1);
+}
+constexpr int DS_KEY_SHIFT = 1;
+#endif
 __device__ __forceinline__ int swz_off(int row, int chunk) {  // byte offset inside a [rows][64] bf16 tile
-    return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+    return row * 128 + ((chunk ^ swz_key(row)) << 4);
 }
 
 // cooperative stage of rows [0,Sp) x 64 bf16 from global (row stride ld elements) into a swizzled tile
@@ -39,7 +54,7 @@ __device__ __forceinline__ void stage_tile(char* tile, const bf16_t* src, long l
                                            int w, int nw, int lane) {
     for (int blk = w; blk < (Sp >> 3); blk += nw) {
         const int row = blk * 8 + (lane >> 3);
-        const int lc = (lane & 7) ^ ((row >> 1) & 7);
+        const int lc = (lane & 7) ^ swz_key(row);
         const int rs = min(row, S - 1);
         __builtin_amdgcn_global_load_lds(
             (const __attribute__((address_space(1))) void*)(src + (long)rs * ld + lc * 8),
@@ -85,7 +100,7 @@ __device__ __forceinline__ bf16x8 frag_transposed(const char* tile, int rowbase,
 }
 
 // Per-lane byte offsets that do not depend on the tile index (32-row tiles start at multiples of 16
-// rows, which leaves the (row>>1)&7 swizzle term unchanged): address = tile + row0*128 + offset.
+// rows, which leaves the swz_key(row) swizzle term unchanged): address = tile + row0*128 + offset.
 struct FragOffs {
     int rm[4];      // row-major fragment, k-chunk kk:      row0 = first row of the 32-row tile
     int tr[2][2];   // transposed fragment [dt][r]:          row0 = first row of the 16-row k-slice
@@ -257,7 +272,7 @@ attn_fwd_odd_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict_
 
     const FragOffs fo = make_offs(lane);
     constexpr float RESCALE_THR = 6.0f;
-    // row S-1 = 32 NK of a tile: ((row >> 1) & 7) == 0, i.e. its chunks are not swizzled
+    // row S-1 = 32 NK of a tile: swz_key(row) == 0, i.e. its chunks are not swizzled
     const char* kl = Kt + (S - 1) * 128;
     const char* vl = Vt + (S - 1) * 128;
 
@@ -814,16 +829,19 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
     // The dS tiles are double-buffered by tile parity: a wave that writes tile qt + 1 has passed barrier qt, which
     // every wave reaches only after its reads of tile qt - 1 - one barrier per tile is enough.
     lds_char* dsb = (lds_char*)area;                          // [2][NK] tiles of FB2_TILE bytes: [32 keys][32 q] bf16
-    // write: this lane's key row (64-B rows), 8-B chunk (4 consecutive q) index XOR ((key >> 2) & 7)
+    // write: this lane's key row (64-B rows), 8-B chunk (4 consecutive q) index XOR ((key >> 1) & 7): the 8 same-parity
+    // rows of a 16-lane ds_write_b64 group get 8 different keys, and the two rows r, r + 8 that share a bank phase in
+    // the transposing read below differ in key bit 2 = the other 32-B half of the row (round 2 XORed (key >> 2) & 7: 2-way
+    // conflicts on every write and every read, 24 extra LDS cycles per query tile and wave in scripts/lds_bank_model.py)
     const int st_w = w * FB2_TILE + l31 * 64;
-    const int st_sw = (l31 >> 2) & 7;
+    const int st_sw = (l31 >> DS_KEY_SHIFT) & 7;
     // read (B operand of the 16x16x32 MFMA, lane <-> q = 16 qb + (lane & 15), k <-> key = 8 G + 0..7): transposing read of
     // the 4 (keys) x 16 (q) block; lane i of a 16-lane group addresses key row 8 G + 4 r + (i >> 2), 8-B chunk 4 qb + (i & 3)
     int rd[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int row = 8 * G + 4 * r + (i16 >> 2);
-        rd[r] = row * 64 + (((4 * qb + (i16 & 3)) ^ ((row >> 2) & 7)) << 3);
+        rd[r] = row * 64 + (((4 * qb + (i16 & 3)) ^ ((row >> DS_KEY_SHIFT) & 7)) << 3);
     }
     const float4 ke4 = *(const float4*)(Ke + 16 * db + 4 * G);        // k[odd key][d], d = 16 db + 4 G + 0..3
     bf16_t* dq_out = dqkv + (long)b * lay.qkv_b + (long)h * lay.qkv_h + 16 * db + 4 * G;
@@ -834,7 +852,7 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
     // otherwise spend waiting at that barrier
     auto prefetch_tile = [&](int t) {
         const int blk = 4 * t + (w & 3), row = blk * 8 + (lane >> 3);
-        const bf16_t* gp = nsrc + (long)min(row, S - 1) * nld + ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+        const bf16_t* gp = nsrc + (long)min(row, S - 1) * nld + ((lane & 7) ^ swz_key(row)) * 8;
         const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_char*)((w < 4 ? Qt : Dt) + blk * 1024));
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gp), "s"(dst) : "memory", "m0");
     };

@@ -60,8 +60,13 @@ __device__ __forceinline__ void lds_wait() {
 // 16-byte buffer store with the whole offset in the VGPR operand and soffset = 0.  With an SGPR soffset hipcc's hazard
 // recogniser assumes that a >8-byte store's data registers may be overwritten by the next VALU instruction; on gfx950
 // that corrupted the upper dwords of stores that were followed by dense VALU code (measured: EPI_BF16_ACT / _DACT).
+// RVLM_STORE_AUX: cache-policy bits of the epilogue stores (experiment: 2 = nt, the output streams past L2 and leaves it to
+// the operand panels; default 0)
+#ifndef RVLM_STORE_AUX
+#define RVLM_STORE_AUX 0
+#endif
 __device__ __forceinline__ void store16(u32x4 v, __amdgpu_buffer_rsrc_t rs, int lane_off, int scalar_off) {
-    __builtin_amdgcn_raw_buffer_store_b128(v, rs, lane_off + scalar_off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, lane_off + scalar_off, 0, RVLM_STORE_AUX);
 }
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* ptr, unsigned bytes) {
