@@ -190,6 +190,51 @@ def bench_train(args, R, cfg, sd, dev, dist, world, rank):
         dist.destroy_process_group()
 
 
+class ClockSampler:
+    """Shader clock / socket power of one GPU while the timed region runs: `rocm-smi --showclocks --showpower` polled from
+    a thread (~10 Hz; each call costs the HOST ~60 ms, nothing on the GPU).  The 2.5 PFLOP/s peak assumes 2.4 GHz; under the
+    ~1.4 kW socket cap a dense MFMA loop holds 1.7-1.9 GHz, so `roofline.frac` is also reported against
+    the peak at the clock the chip actually held."""
+
+    def __init__(self, device_index: int):
+        import threading
+        self.dev, self.samples, self.stop, self.thread = device_index, [], False, None
+        self._threading = threading
+
+    def _run(self):
+        import re
+        import subprocess
+        while not self.stop:
+            try:
+                o = subprocess.run(["rocm-smi", "-d", str(self.dev), "--showpower", "--showclocks"], capture_output=True,
+                                   text=True, timeout=5).stdout
+                p = re.search(r"Power \(W\):\s*([\d.]+)", o)
+                c = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", o)
+                if c:
+                    self.samples.append((float(p.group(1)) if p else -1.0, int(c.group(1))))
+            except Exception:
+                pass
+            time.sleep(0.03)
+
+    def __enter__(self):
+        self.thread = self._threading.Thread(target=self._run, daemon=True)
+        self.thread.start()
+        return self
+
+    def __exit__(self, *a):
+        self.stop = True
+        self.thread.join(timeout=10)
+
+    def summary(self):
+        cs = [c for _, c in self.samples if c > 0]
+        ps = [p for p, _ in self.samples if p > 0]
+        if not cs:
+            return None
+        return {"sclk_mhz_mean": sum(cs) / len(cs), "sclk_mhz_min": min(cs), "sclk_mhz_max": max(cs), "samples": len(cs),
+                "socket_power_w_mean": (sum(ps) / len(ps)) if ps else None,
+                "source": "rocm-smi --showclocks --showpower polled during the timed region"}
+
+
 def bind_rank_to_numa(local_rank: int, local_world: int):
     """One process per GPU on a 2-socket host: keep each rank's host threads (launch loop, RCCL proxy) on the cores of
     its GPU's NUMA node - sysfs numa_node of the GPU's PCI function when readable, else an even split of the cores.
@@ -300,11 +345,16 @@ def main():
     for _ in range(args.warmup):
         out = step()
     barrier()
+    sampler = ClockSampler(local_rank) if rank == 0 and not args.no_roofline else None
+    if sampler is not None:
+        sampler.__enter__()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    if sampler is not None:
+        sampler.__exit__()
     per_rank_s = [el]
     if dist is not None:
         t = torch.tensor([el], device=dev, dtype=torch.float64)
@@ -369,14 +419,28 @@ def main():
         achieved = gflops / (gms * 1e-3) / 1e12 if gms > 0 else 0.0
         # HBM-side traffic comes from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE cannot be
         # read from inside this process); the committed measurement of this same command is reported.
-        traffic, traffic_src = None, None
-        tj = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")
-        if os.path.exists(tj) and args.model == "ViT-L-14" and args.batch == 128 and args.precision == "bf16":
+        traffic, traffic_src, pmc = None, None, None
+        headline = args.model == "ViT-L-14" and args.batch == 128 and args.precision == "bf16" and args.attack == "pgd"
+        for tag in ("r03", "r02"):
+            tj = os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_traffic.json")
+            if traffic is None and os.path.exists(tj) and headline:
+                try:
+                    traffic = json.load(open(tj))["gemm_bytes_per_logical_launch"]
+                    traffic_src = f"profiles/{tag}_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+                except Exception:
+                    traffic = None
+        # matrix-pipe utilisation INSIDE this pipeline (not of a cube): rocprofv3 --pmc passes over this same command,
+        # summarised per kernel by scripts/pmc_pipeline.sh (counters cannot be read from inside this process either)
+        pj = os.path.join(ROOT, "profiles", "r03_pmc_pipeline.json")
+        if os.path.exists(pj) and headline:
             try:
-                traffic = json.load(open(tj))["gemm_bytes_per_logical_launch"]
-                traffic_src = "profiles/r02_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+                kd = json.load(open(pj))["kernels"]
+                pmc = {"source": "profiles/r03_pmc_pipeline.json (scripts/pmc_pipeline.sh: rocprofv3 --pmc passes over bench.py --steps 1)",
+                       "mfma_busy": {k: v.get("mfma_busy") for k, v in kd.items() if v.get("mfma_busy") is not None},
+                       "lds_conflict_share": {k: v.get("lds_conflict_share") for k, v in kd.items()
+                                              if v.get("lds_conflict_share") is not None}}
             except Exception:
-                traffic = None
+                pmc = None
         res["roofline"] = {
             "bound": "mfma", "kernel": "gemm_bf16_nt_256p_kernel (QKV/out-proj/fc1/fc2, fwd + dgrad; the 128 remainder rows ride in the same launch)",
             "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
@@ -384,6 +448,7 @@ def main():
             "traffic_source": traffic_src,
             "flops_per_launch": gflops / max(glaunch, 1), "avg_launch_ms": gms / max(glaunch, 1),
             "launches": glaunch,
+            "pmc_in_pipeline": pmc,
             "attention_gemm_subset": {
                 "tflops": sum(v["flops"] for v in attn_gemm.values()) / max(sum(v["ms"] for v in attn_gemm.values()), 1e-9) / 1e9,
                 "frac": sum(v["flops"] for v in attn_gemm.values()) / max(sum(v["ms"] for v in attn_gemm.values()), 1e-9) / 1e9 / PEAK_BF16_TFLOPS},
@@ -392,6 +457,14 @@ def main():
                               "gbps": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 and v["bytes"] > 0 else None}
                           for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
         }
+    if rank == 0 and sampler is not None and "roofline" in res:
+        clk = sampler.summary()
+        res["roofline"]["clock"] = clk
+        if clk:
+            # the dense peak = 256 CUs x 2.4 GHz x (bf16 FLOP per CU and cycle): it scales linearly with the shader clock
+            peak_at_clock = PEAK_BF16_TFLOPS * clk["sclk_mhz_mean"] / 2400.0
+            res["roofline"]["frac_at_measured_clock"] = res["roofline"]["achieved"] / peak_at_clock
+            res["roofline"]["peak_at_measured_clock"] = peak_at_clock
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(args.iterations)
     if rank == 0:

@@ -537,10 +537,17 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
                         mul8(t0, side[mi % SIDE_DEPTH][0]); mul8(t1, side[mi % SIDE_DEPTH][1]);
                         mul8(t2, side[mi % SIDE_DEPTH][2]); mul8(t3, side[mi % SIDE_DEPTH][3]);
                     }
-                    store16(t0, rs, st16_loff, so);
-                    store16(t1, rs, st16_loff, so + 16 * ldo);
-                    store16(t2, rs, st16_loff, so + 32 * ldo);
-                    store16(t3, rs, st16_loff, so + 48 * ldo);
+                    if (what == 2) {     // act'(h): next read by the backward pass - streamed past the L2
+                        store16<2>(t0, rs, st16_loff, so);
+                        store16<2>(t1, rs, st16_loff, so + 16 * ldo);
+                        store16<2>(t2, rs, st16_loff, so + 32 * ldo);
+                        store16<2>(t3, rs, st16_loff, so + 48 * ldo);
+                    } else {
+                        store16(t0, rs, st16_loff, so);
+                        store16(t1, rs, st16_loff, so + 16 * ldo);
+                        store16(t2, rs, st16_loff, so + 32 * ldo);
+                        store16(t3, rs, st16_loff, so + 48 * ldo);
+                    }
                 };
                 // forward-only callers (no backward to come) pass out_pre = null: act'(h) is then not written
                 if (EPI != EPI_BF16_ACT || p.out_pre)
@@ -572,7 +579,8 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
                                 const float4 r = __builtin_bit_cast(float4, side[sub % SIDE_DEPTH][it]);
                                 t[it] = __builtin_bit_cast(u32x4, make_float4(x.x + r.x, x.y + r.y, x.z + r.z, x.w + r.w));
                             }
-                            store16(t[it], o_rs, st32_loff, so + it * 32 * ldo);
+                            if (ABL & 4096) store16<2>(t[it], o_rs, st32_loff, so + it * 32 * ldo);   // K >= 2048: large operand set
+                            else store16(t[it], o_rs, st32_loff, so + it * 32 * ldo);
                         }
                     }
                     if (EPI == EPI_F32_RESID && sub + SIDE_DEPTH < 8) load_side(sub + SIDE_DEPTH);
@@ -657,6 +665,9 @@ static int launch_256p_act(const GemmBf16& p, int tiles_m, int tiles_n, int m_to
     }
     if constexpr (EPI == EPI_F32_RESID) {   // evidence for DESIGN.md: the fp32 + residual epilogue with the MFMAs removed
         if (g_persist_ablate == 2) return launch_256p_abl<EPI, ACT, 2>(p, tiles_m, tiles_n, m_total, s);
+        static int nt_k = -1;               // fp32 output stored nt from this K on (RVLM_GEMM_NT_K, 0 = never)
+        if (nt_k < 0) { const char* e = getenv("RVLM_GEMM_NT_K"); nt_k = e ? atoi(e) : 2048; }
+        if (nt_k > 0 && p.K >= nt_k && g_persist_ablate == 0) return launch_256p_abl<EPI, ACT, 4096>(p, tiles_m, tiles_n, m_total, s);
     }
     return launch_256p_abl<EPI, ACT, 0>(p, tiles_m, tiles_n, m_total, s);
 }

@@ -376,8 +376,8 @@ gemm_bf16_nt_256x_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
                 const u32x4 p0 = join(rq[0], rq[1]), p1 = join(rq[2], rq[3]), q0 = join(rq[4], rq[5]), q1 = join(rq[6], rq[7]);
                 const int so = __builtin_amdgcn_readfirstlane(((m_base + mi * 32) * ldo + n_base + ni * 32) * 2);
                 __builtin_amdgcn_sched_barrier(0);
-                store16(p0, pre_rs, h16_loff, so);
-                store16(p1, pre_rs, h16_loff, so + 32 * ldo);
+                store16<2>(p0, pre_rs, h16_loff, so);
+                store16<2>(p1, pre_rs, h16_loff, so + 32 * ldo);
                 store16(q0, o_rs, h16_loff, so);
                 store16(q1, o_rs, h16_loff, so + 32 * ldo);
             } else {

@@ -60,13 +60,13 @@ __device__ __forceinline__ void lds_wait() {
 // 16-byte buffer store with the whole offset in the VGPR operand and soffset = 0.  With an SGPR soffset hipcc's hazard
 // recogniser assumes that a >8-byte store's data registers may be overwritten by the next VALU instruction; on gfx950
 // that corrupted the upper dwords of stores that were followed by dense VALU code (measured: EPI_BF16_ACT / _DACT).
-// RVLM_STORE_AUX: cache-policy bits of the epilogue stores (experiment: 2 = nt, the output streams past L2 and leaves it to
-// the operand panels; default 0)
-#ifndef RVLM_STORE_AUX
-#define RVLM_STORE_AUX 0
-#endif
+// AUX = cache-policy bits of the store: 2 = nt (the output streams past the L2 and leaves it to the operand panels).  Used
+// where the consumer is far away in time (act'(h): read by the backward) or the launch's operand set is large (fp32 outputs
+// at K >= 2048); an output the NEXT kernel reads (qkv -> attention, out-proj -> LayerNorm) is slower to re-read when it was
+// stored nt (profiles/r03_ab_attn_swizzle_nt_stores.log: all-nt build qkv forward +1.3 ms, attention forward +1.0 ms per step)
+template <int AUX = 0>
 __device__ __forceinline__ void store16(u32x4 v, __amdgpu_buffer_rsrc_t rs, int lane_off, int scalar_off) {
-    __builtin_amdgcn_raw_buffer_store_b128(v, rs, lane_off + scalar_off, 0, RVLM_STORE_AUX);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, lane_off + scalar_off, 0, AUX);
 }
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* ptr, unsigned bytes) {
