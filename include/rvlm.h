@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RVLM_VERSION 103
+#define RVLM_VERSION 104
 
 typedef void* rvlm_stream_t; /* hipStream_t */
 typedef struct rvlm_vit rvlm_vit;
@@ -302,6 +302,12 @@ typedef struct rvlm_preproc rvlm_preproc;
 int rvlm_preproc_create(int size, int max_input_dim, rvlm_preproc** out);
 int rvlm_preproc_destroy(rvlm_preproc* p);
 int rvlm_preproc_run(rvlm_preproc* p, const uint8_t* img_hwc, int H, int W, float* out_chw, rvlm_stream_t stream);
+/* A batch of n decoded images of any mix of shapes in ONE kernel launch (the reference's DataLoader hands over batches of
+ * 128, train/adversarial_training_clip.py:119-148): imgs_hwc / H / W are HOST arrays of n device pointers / heights /
+ * widths; out: device float32 [n, 3, size, size].  Tables are staged through pinned memory and copied on `stream`; the call
+ * does not synchronise the stream.  Same arithmetic as rvlm_preproc_run (bit-identical outputs). */
+int rvlm_preproc_run_batch(rvlm_preproc* p, const uint8_t* const* imgs_hwc, const int* H, const int* W, int n, float* out,
+                           rvlm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Measurement support: per-kernel-class HIP-event timing on the engine's stream.
@@ -323,7 +329,8 @@ int rvlm_version(void);   /* = RVLM_VERSION.  101: rvlm_loss_spec.y_target, rvlm
                            * 102: square-attack kernels; 103: rvlm_vit_fwd_inputgrad, rvlm_vit_backward_params_stages,
                            * rvlm_ce_logits, rvlm_head_logits(_bwd), double hyper-parameters in rvlm_adamw_step,
                            * rvlm_pgd_l2_update, rvlm_pgd_run_norm, rvlm_apgd_l2_step, rvlm_apgd_run_norm,
-                           * rvlm_project_perturbation, rvlm_normalize_grad */
+                           * rvlm_project_perturbation, rvlm_normalize_grad; 104: rvlm_preproc_run_batch, rvlm_ce_logits takes B = 1,
+                           * rvlm_vit_backward_params_stages refuses out-of-order stages */
 
 #ifdef __cplusplus
 }

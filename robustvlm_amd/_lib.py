@@ -136,6 +136,8 @@ _SIGS = {
     "rvlm_preproc_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "rvlm_preproc_destroy": (C.c_int, [C.c_void_p]),
     "rvlm_preproc_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, c_f32p, c_stream]),
+    "rvlm_preproc_run_batch": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int,
+                                         c_f32p, c_stream]),
     "rvlm_vit_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "rvlm_vit_get_profile": (C.c_int, [C.c_void_p, C.POINTER(ProfileEntryC), C.POINTER(C.c_int)]),
     "rvlm_vit_reset_profile": (C.c_int, [C.c_void_p]),

@@ -317,7 +317,6 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
     // lane offsets of the epilogue's coalesced accesses (bytes); one instruction = 8 rows (16 for the 64-B rows)
     const int st16_loff = ((lane >> 3) * ldo + (lane & 7) * 8) * 2;   // bf16: 128 B (64 columns) per row
     const int st32_loff = ((lane >> 3) * ldo + (lane & 7) * 4) * 4;   // fp32: 128 B (32 columns) per row
-    const int h16_loff = ((lane >> 2) * ldo + (lane & 3) * 8) * 2;    // bf16 next to a 32-column sub-tile: 64 B per row
     const int r0 = lane >> 3;                                         // flush: row r0 + 8*it, 16-B slot lane & 7
 
     auto stamp = [&](int ti, int k) {   // optional per-tile timeline (test hook rvlm_k_gemm_set_trace), wave 0 only

@@ -64,7 +64,10 @@ __device__ __forceinline__ void lds_wait() {
 // where the consumer is far away in time (act'(h): read by the backward) or the launch's operand set is large (fp32 outputs
 // at K >= 2048); an output the NEXT kernel reads (qkv -> attention, out-proj -> LayerNorm) is slower to re-read when it was
 // stored nt (profiles/r03_ab_attn_swizzle_nt_stores.log: all-nt build qkv forward +1.3 ms, attention forward +1.0 ms per step)
-template <int AUX = 0>
+#ifndef RVLM_STORE_AUX          // A/B builds: default cache policy of the epilogue stores (16 = sc1 write-through, 17 = sc0 sc1)
+#define RVLM_STORE_AUX 0
+#endif
+template <int AUX = RVLM_STORE_AUX>
 __device__ __forceinline__ void store16(u32x4 v, __amdgpu_buffer_rsrc_t rs, int lane_off, int scalar_off) {
     __builtin_amdgcn_raw_buffer_store_b128(v, rs, lane_off + scalar_off, 0, AUX);
 }

@@ -34,11 +34,28 @@ class ResizeCenterCropToTensor:
                                               L.stream_ptr()), "rvlm_preproc_run")
         return out
 
-    def batch(self, images) -> torch.Tensor:
-        """List of decoded images (any sizes) -> [B, 3, size, size]; same-shaped neighbours share their tap tables."""
-        out = torch.empty(len(images), 3, self.size, self.size, dtype=torch.float32, device=images[0].device)
-        for i, im in enumerate(images):
-            self(im, out[i])
+    def batch(self, images, out: torch.Tensor | None = None) -> torch.Tensor:
+        """List of decoded images (uint8 [H, W, 3] CUDA tensors of any mix of shapes) -> [B, 3, size, size] in ONE kernel
+        launch (rvlm_preproc_run_batch): what the reference's DataLoader collates from its 8 workers
+        (train/adversarial_training_clip.py:119-148)."""
+        n = len(images)
+        if n == 0:
+            raise ValueError("empty batch")
+        dev = images[0].device
+        keep = []
+        for im in images:
+            if not (isinstance(im, torch.Tensor) and im.is_cuda and im.dtype == torch.uint8 and im.dim() == 3
+                    and im.shape[2] == 3 and im.device == dev):
+                raise ValueError("expected uint8 CUDA tensors of shape [H, W, 3] on one device")
+            keep.append(im.contiguous())
+        if out is None:
+            out = torch.empty(n, 3, self.size, self.size, dtype=torch.float32, device=dev)
+        ptrs = (C.c_void_p * n)(*[im.data_ptr() for im in keep])
+        hs = (C.c_int * n)(*[im.shape[0] for im in keep])
+        ws = (C.c_int * n)(*[im.shape[1] for im in keep])
+        with torch.cuda.device(dev):
+            L.check(self.lib.rvlm_preproc_run_batch(self._h, ptrs, hs, ws, n, out.data_ptr(), L.stream_ptr()),
+                    "rvlm_preproc_run_batch")
         return out
 
     def close(self):

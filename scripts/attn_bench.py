@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
-"""Micro-benchmark of the bf16 attention kernels at ViT-L/14 B=128 (2048 (image, head) pairs, S=257)."""
+"""Micro-benchmark of the bf16 attention kernels: python scripts/attn_bench.py [S=257] [B=128] [H=16]
+(ViT-L/14: S=257, H=16; ViT-L/14@336: S=577, H=16; ViT-B/32: S=50, H=12)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from robustvlm_amd import _lib as L
 lib = L.load(); dev = torch.device("cuda:0")
-B, H = 128, 16
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 257
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+H = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 W = H * 64; Sp = (S + 31) // 32 * 32
 g = torch.Generator(device=dev).manual_seed(0)
 qkv = torch.randn(B * S, 3 * W, generator=g, device=dev).bfloat16()
@@ -19,7 +21,9 @@ _wa = torch.randn(8192, 8192, device=dev).bfloat16()
 for _ in range(300):
     torch.matmul(_wa, _wa)     # clock warm-up (the GPU leaves idle at a low clock)
 torch.cuda.synchronize()
-for name, fn, flops in (("fwd", fwd, 4.0 * B * H * S * S * 64), ("bwd", bwd, 8.0 * B * H * S * S * 64)):
+# algorithmic HBM bytes: forward reads q, k, v and writes o; backward reads q, k, v, o, dO and writes dq, dk, dv
+for name, fn, flops, nbytes in (("fwd", fwd, 4.0 * B * H * S * S * 64, 4.0 * B * H * S * 64 * 2),
+                                ("bwd", bwd, 8.0 * B * H * S * S * 64, 8.0 * B * H * S * 64 * 2)):
     for _ in range(3): fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -27,7 +31,7 @@ for name, fn, flops in (("fwd", fwd, 4.0 * B * H * S * S * 64), ("bwd", bwd, 8.0
     for _ in range(20): fn()
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 20
-    print(f"S={S} attn {name}: {ms*1e3:8.1f} us  {flops/ms/1e9:7.1f} TFLOP/s (algorithmic)", flush=True)
+    print(f"S={S} B={B} H={H} attn {name}: {ms*1e3:8.1f} us  {flops/ms/1e9:7.1f} TFLOP/s (algorithmic)  {nbytes/ms/1e9:6.2f} TB/s (algorithmic bytes)", flush=True)
 
 if os.environ.get("RVLM_ATTN_TRACE") and S == 257:
     t = dsum.view(torch.int64)[: B * H * 8].view(B * H, 8).cpu().double()

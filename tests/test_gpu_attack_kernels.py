@@ -242,11 +242,24 @@ def test_preprocess_kernel_bit_exact_vs_pillow_golden():
     batch = t224.batch([torch.from_numpy(a).cuda() for a in imgs]).cpu().numpy()
     for a, b in zip(imgs, batch):
         assert np.array_equal(b, P.preprocess_ref(a, 224)), a.shape
+    # the batch is ONE launch (rvlm_preproc_run_batch: blockIdx.z = image, every image its own shape / tables / tile
+    # height); it must equal the one-image calls bit for bit, also when the staging buffers are reused and regrown
+    dimgs = [torch.from_numpy(a).cuda() for a in imgs]
+    single = torch.stack([t224(d) for d in dimgs])
+    assert torch.equal(torch.from_numpy(batch).cuda(), single)
+    big = dimgs * 19                                             # 133 images, 6 distinct shapes
+    again = t224.batch(big)
+    assert torch.equal(again[:7], single) and torch.equal(again[-7:], single)
+    assert torch.equal(t224.batch(dimgs[:2]), single[:2])
+    with pytest.raises(ValueError):
+        t224.batch([])
     with pytest.raises(ValueError):
         t224(torch.zeros(4, 4, 3).cuda())
     small = R.ResizeCenterCropToTensor(32, max_input_dim=64)
     with pytest.raises(NotImplementedError):
         small(torch.zeros(1000, 1000, 3, dtype=torch.uint8).cuda())   # 31x down-scaling needs more taps than provisioned
+    with pytest.raises(NotImplementedError):
+        small.batch([torch.zeros(40, 40, 3, dtype=torch.uint8).cuda(), torch.zeros(1000, 1000, 3, dtype=torch.uint8).cuda()])
 
 
 # ---- L2-norm branch of pgd as a device kernel (rvlm_pgd_l2_update), against the reference's own outputs
