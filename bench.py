@@ -410,6 +410,25 @@ def main():
         step()
         prof = eng.get_profile()
         eng.set_profiling(False)
+        # effective shader clock INSIDE the GEMM launches of one more step: the persistent kernel's trace hook makes wave 0
+        # of every workgroup stamp s_memtime (shader clock) and s_memrealtime (constant 100 MHz) at its start and end
+        eff_clock = None
+        try:
+            from robustvlm_amd import _lib as L
+            tr = torch.zeros(256 * 8 * 4, dtype=torch.int64, device=dev)
+            L.load().rvlm_k_gemm_set_trace(tr.data_ptr())
+            step()
+            torch.cuda.synchronize()
+            L.load().rvlm_k_gemm_set_trace(None)
+            t = tr.view(256, 8, 4)[:, 7, :].double()          # [wg][memtime0, realtime0, memtime1, realtime1] of the LAST launch
+            ok = (t[:, 3] > t[:, 1]) & (t[:, 2] > t[:, 0])
+            if bool(ok.any()):
+                mhz = ((t[ok, 2] - t[ok, 0]) / (t[ok, 3] - t[ok, 1]) * 100.0)
+                eff_clock = {"sclk_mhz_effective": float(mhz.mean()), "workgroups": int(ok.sum()),
+                             "source": "s_memtime / s_memrealtime stamps of the last persistent-GEMM launch of a pgd() call "
+                                       "(rvlm_k_gemm_set_trace)"}
+        except Exception as e:                     # measurement aid only
+            eff_clock = {"error": f"{type(e).__name__}: {e}"}
         gemm = {k: v for k, v in prof.items() if k.startswith("gemm_") and "patch" not in k}
         gflops = sum(v["flops"] for v in gemm.values())
         gms = sum(v["ms"] for v in gemm.values())
@@ -449,6 +468,7 @@ def main():
             "flops_per_launch": gflops / max(glaunch, 1), "avg_launch_ms": gms / max(glaunch, 1),
             "launches": glaunch,
             "pmc_in_pipeline": pmc,
+            "clock_in_kernel": eff_clock,
             "attention_gemm_subset": {
                 "tflops": sum(v["flops"] for v in attn_gemm.values()) / max(sum(v["ms"] for v in attn_gemm.values()), 1e-9) / 1e9,
                 "frac": sum(v["flops"] for v in attn_gemm.values()) / max(sum(v["ms"] for v in attn_gemm.values()), 1e-9) / 1e9 / PEAK_BF16_TFLOPS},
@@ -460,9 +480,11 @@ def main():
     if rank == 0 and sampler is not None and "roofline" in res:
         clk = sampler.summary()
         res["roofline"]["clock"] = clk
-        if clk:
-            # the dense peak = 256 CUs x 2.4 GHz x (bf16 FLOP per CU and cycle): it scales linearly with the shader clock
-            peak_at_clock = PEAK_BF16_TFLOPS * clk["sclk_mhz_mean"] / 2400.0
+        eff = (res["roofline"].get("clock_in_kernel") or {}).get("sclk_mhz_effective")
+        if clk or eff:
+            # the dense peak = 256 CUs x 2.4 GHz x (bf16 FLOP per CU and cycle): it scales linearly with the shader clock;
+            # the in-kernel measurement (cycles the waves actually got) is preferred over rocm-smi's reading
+            peak_at_clock = PEAK_BF16_TFLOPS * (eff if eff else clk["sclk_mhz_mean"]) / 2400.0
             res["roofline"]["frac_at_measured_clock"] = res["roofline"]["achieved"] / peak_at_clock
             res["roofline"]["peak_at_measured_clock"] = peak_at_clock
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
