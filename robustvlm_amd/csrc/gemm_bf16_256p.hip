@@ -75,6 +75,16 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w >> 2, wn = w & 3;
+    // experiment (RVLM_GEMM_STRIP_FIRST=m, default off): every m-th workgroup of an XCD computes its remainder-row unit
+    // BEFORE its tiles instead of after them - no extra work, but those workgroups then run a strip-time late for the whole
+    // launch, so the chip-wide store bursts (every workgroup's epilogue at the same moment) and the final drain fall
+    // into two groups
+    const int sf_mod = (p.stagger >> 16) & 255;
+    const bool strip_first = sf_mod >= 2 && (((int)blockIdx.x >> 3) % sf_mod) == sf_mod - 1 && (ABL & 15) == 0 && m_total > p.M;
+    if (strip_first) {
+        strip_tail<EPI, ACT>(p, p.M, m_total, lds, w, lane);
+        __syncthreads();      // the reduce buffer overlaps the first ring slots
+    }
     const int l31 = lane & 31, hi = lane >> 5;
     // experiment (MI355X_MICROARCH.md, two waves per SIMD, item 4): static priority for the second-dispatched half
     if (p.wave_prio > 0 && w >= 4) __builtin_amdgcn_s_setprio(1);
@@ -317,6 +327,7 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
     // lane offsets of the epilogue's coalesced accesses (bytes); one instruction = 8 rows (16 for the 64-B rows)
     const int st16_loff = ((lane >> 3) * ldo + (lane & 7) * 8) * 2;   // bf16: 128 B (64 columns) per row
     const int st32_loff = ((lane >> 3) * ldo + (lane & 7) * 4) * 4;   // fp32: 128 B (32 columns) per row
+    const int h16_loff = ((lane >> 2) * ldo + (lane & 3) * 8) * 2;    // bf16 32-column sub-tile: 16 rows x 64 B per instruction
     const int r0 = lane >> 3;                                         // flush: row r0 + 8*it, 16-B slot lane & 7
 
     auto stamp = [&](int ti, int k) {   // optional per-tile timeline (test hook rvlm_k_gemm_set_trace), wave 0 only
@@ -548,12 +559,57 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
                         store16(t3, rs, st16_loff, so + 48 * ldo);
                     }
                 };
-                // forward-only callers (no backward to come) pass out_pre = null: act'(h) is then not written
-                if (EPI != EPI_BF16_ACT || p.out_pre)
-                    stage_flush(EPI == EPI_BF16_ACT ? pre_rs : o_rs, EPI == EPI_BF16_ACT ? 2 : EPI == EPI_BF16_DACT ? 3 : 0);
-                if (EPI == EPI_BF16_ACT) stage_flush(o_rs, 1);
-                init_acc(mi, 0);
-                init_acc(mi, 1);
+                if (EPI == EPI_BF16_ACT && p.out_pre) {
+                    // Activation PAIR: act(h) and act'(h) of one 32 x 32 sub-tile at a time, both staged at once (act'(h) in
+                    // the left 64 B of the staged rows, act(h) in the right) and flushed as 16 rows x 64 B per store.  The
+                    // round-2 form flushed the 32 x 64 block twice (act' then act): hipcc kept the first pass's act values live
+                    // across the LDS round trip and the stores of the second, ran out of registers (20 spilled dwords) and
+                    // reloaded them from scratch BEHIND the four stores it had just issued - VMEM returns in order, so every
+                    // reload waited for those stores to be acknowledged, six times per tile.
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            bf16x4 oa, od;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float av, dv;
+                                actp_pair<ACT>(acc[mi][ni][g * 4 + e], av, dv);
+                                oa[e] = (bf16_t)av; od[e] = (bf16_t)dv;
+                            }
+                            // 8-B chunk index within the 128-B row: (which * 8 + 2 g + hi) ^ (row & 15); which = 0 act', 1 act
+                            lds_w64(w16_pre ^ ((2 * g) << 3), __builtin_bit_cast(u32x2, od));
+                            lds_w64(w16_pre ^ ((8 + 2 * g) << 3), __builtin_bit_cast(u32x2, oa));
+                        }
+                        init_acc(mi, ni);
+                        // read back: 16 rows per instruction, 4 lanes x 16 B per row and output; lane -> row rr (+ 16), 16-B
+                        // slot q of output `which`: 8-B chunks (which * 8 + 2 q, + 1) ^ (row & 15)
+                        const int rr = lane >> 2, q = lane & 3;
+                        u32x2 rq[8];
+#pragma unroll
+                        for (int which = 0; which < 2; ++which)
+#pragma unroll
+                            for (int half = 0; half < 2; ++half) {
+                                const int row = rr + 16 * half;
+                                const unsigned rbase = ebuf + row * 128;
+                                const int c8 = (which * 8 + 2 * q) ^ (row & 15);
+                                asm volatile("ds_read_b64 %0, %1" : "=v"(rq[(which * 2 + half) * 2]) : "v"(rbase + (c8 << 3)) : "memory");
+                                asm volatile("ds_read_b64 %0, %1" : "=v"(rq[(which * 2 + half) * 2 + 1]) : "v"(rbase + ((c8 ^ 1) << 3)) : "memory");
+                            }
+                        lds_wait();
+                        auto join = [](u32x2 lo, u32x2 hi2) { u32x4 t; t.x = lo.x; t.y = lo.y; t.z = hi2.x; t.w = hi2.y; return t; };
+                        const int so2 = __builtin_amdgcn_readfirstlane(((m_base + mi * 32) * ldo + n_base + ni * 32) * 2);
+                        store16<2>(join(rq[0], rq[1]), pre_rs, h16_loff, so2);              // act'(h): next read by the backward pass
+                        store16<2>(join(rq[2], rq[3]), pre_rs, h16_loff, so2 + 32 * ldo);
+                        store16(join(rq[4], rq[5]), o_rs, h16_loff, so2);
+                        store16(join(rq[6], rq[7]), o_rs, h16_loff, so2 + 32 * ldo);
+                    }
+                } else {
+                    // (forward-only callers - no backward to come - pass out_pre = null: act'(h) is then not written)
+                    stage_flush(o_rs, EPI == EPI_BF16_ACT ? 1 : EPI == EPI_BF16_DACT ? 3 : 0);
+                    init_acc(mi, 0);
+                    init_acc(mi, 1);
+                }
             } else {
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
@@ -603,7 +659,7 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
     if (!SPLIT) run(std::integral_constant<int, 0>{});
     else if ((w < 4) != SWAP) run(std::integral_constant<int, 2>{});
     else run(std::integral_constant<int, 1>{});
-    if ((ABL & 15) == 0 && m_total > p.M) strip_tail<EPI, ACT>(p, p.M, m_total, lds, w, lane);
+    if ((ABL & 15) == 0 && m_total > p.M && !strip_first) strip_tail<EPI, ACT>(p, p.M, m_total, lds, w, lane);
     if (!(ABL & (128 | 2048)) && p.trace && w == 0 && lane == 0) {
         p.trace[((long)blockIdx.x * 8 + 7) * 4 + 2] = __builtin_amdgcn_s_memtime();
         p.trace[((long)blockIdx.x * 8 + 7) * 4 + 3] = __builtin_amdgcn_s_memrealtime();
@@ -706,6 +762,9 @@ int gemm_bf16_nt_256p(const GemmBf16& p, int* rows_done, hipStream_t s) {
     static int stagger_ph = -1;     // phase mask: 3 = 4 phases
     if (stagger_ph < 0) { const char* e = getenv("RVLM_GEMM_STAGGER_PH"); stagger_ph = e ? atoi(e) : 3; }
     if (((stagger_mask >> q.epi) & 1) && stagger > 0) q.stagger = (stagger & 255) | (stagger_ph << 8);
+    static int strip_first = -1;
+    if (strip_first < 0) { const char* e = getenv("RVLM_GEMM_STRIP_FIRST"); strip_first = e ? atoi(e) : 0; }
+    q.stagger |= (strip_first & 255) << 16;
     static int group_m = -1, wave_prio = -1;
     if (group_m < 0) { const char* e = getenv("RVLM_GEMM_GROUP_M"); group_m = e ? std::max(1, atoi(e)) : 8; }
     if (wave_prio < 0) { const char* e = getenv("RVLM_GEMM_PRIO"); wave_prio = e ? atoi(e) : 0; }

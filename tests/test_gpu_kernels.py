@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 def test_library_is_the_in_tree_hip_build():
     l = lib()
-    assert l.rvlm_version() == 103
+    assert l.rvlm_version() == 104
     assert L.LIB_PATH.endswith("robustvlm_amd/librvlm.so")
 
 
