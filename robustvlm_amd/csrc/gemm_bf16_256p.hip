@@ -75,12 +75,15 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w >> 2, wn = w & 3;
-    // experiment (RVLM_GEMM_STRIP_FIRST=m, default off): every m-th workgroup of an XCD computes its remainder-row unit
-    // BEFORE its tiles instead of after them - no extra work, but those workgroups then run a strip-time late for the whole
-    // launch, so the chip-wide store bursts (every workgroup's epilogue at the same moment) and the final drain fall
-    // into two groups
-    const int sf_mod = (p.stagger >> 16) & 255;
-    const bool strip_first = sf_mod >= 2 && (((int)blockIdx.x >> 3) % sf_mod) == sf_mod - 1 && (ABL & 15) == 0 && m_total > p.M;
+    // Desynchronised halves (RVLM_GEMM_STRIP_FIRST, default 130 = the workgroups of every second XCD; 0 = off): those
+    // workgroups compute their remainder-row unit BEFORE their tiles instead of after them.  No extra work, but they then
+    // run a strip-time (4-14 us) behind the others for the whole launch, so the chip-wide store bursts - every workgroup's
+    // epilogue at the same moment, 67-134 MB at once - and the final drain fall into two groups.  Same-box A/B, four
+    // alternations (profiles/r03_ab_strip_first_4reps.log): 259.7 -> 264.5 img/s, all-GEMM 1 043 -> 1 075 TFLOP/s; fc2 dgrad
+    // 65.7 -> 60.7 ms, fc2 forward 60.2 -> 57.2; every second workgroup of an XCD instead: 262.5; one XCD of eight: 261.4
+    const int sf_mod = (p.stagger >> 16) & 127;
+    const int sf_id = ((p.stagger >> 16) & 128) ? ((int)blockIdx.x & 7) : ((int)blockIdx.x >> 3);   // +128: whole XCDs instead
+    const bool strip_first = sf_mod >= 2 && (sf_id % sf_mod) == sf_mod - 1 && (ABL & 15) == 0 && m_total > p.M;
     if (strip_first) {
         strip_tail<EPI, ACT>(p, p.M, m_total, lds, w, lane);
         __syncthreads();      // the reduce buffer overlaps the first ring slots
@@ -763,7 +766,7 @@ int gemm_bf16_nt_256p(const GemmBf16& p, int* rows_done, hipStream_t s) {
     if (stagger_ph < 0) { const char* e = getenv("RVLM_GEMM_STAGGER_PH"); stagger_ph = e ? atoi(e) : 3; }
     if (((stagger_mask >> q.epi) & 1) && stagger > 0) q.stagger = (stagger & 255) | (stagger_ph << 8);
     static int strip_first = -1;
-    if (strip_first < 0) { const char* e = getenv("RVLM_GEMM_STRIP_FIRST"); strip_first = e ? atoi(e) : 0; }
+    if (strip_first < 0) { const char* e = getenv("RVLM_GEMM_STRIP_FIRST"); strip_first = e ? atoi(e) : 130; }
     q.stagger |= (strip_first & 255) << 16;
     static int group_m = -1, wave_prio = -1;
     if (group_m < 0) { const char* e = getenv("RVLM_GEMM_GROUP_M"); group_m = e ? std::max(1, atoi(e)) : 8; }
