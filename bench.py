@@ -9,8 +9,14 @@ HBM before the timed region.  One process per GPU; the attack is per-sample, so 
 with NO data-path collective (weak scaling) - torch.distributed (RCCL) only provides the barrier and
 the max-over-ranks time.
 
+`python bench.py --gpus N` started WITHOUT a launcher creates its N ranks itself (robustvlm_amd/launch.py: re-exec under
+torch.distributed.run on 127.0.0.1, exit code of the ranks); started under one (WORLD_SIZE set) it is a rank, and --gpus has
+to equal WORLD_SIZE.  More GPUs than the node shows is an error, never a silently smaller job.
+
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     - bf16 MFMA GEMM kernel: algorithmic FLOPs / HIP-event launch time, vs 2.5 PFLOP/s
+  roofline     - bf16 MFMA GEMM kernel: algorithmic FLOPs / HIP-event launch time, vs 2.5 PFLOP/s; the shader clock held
+                 during the timed region (rocm-smi) and inside the GEMM launches (the kernel's own cycle / real-time stamps),
+                 the fraction against the peak at that clock, per-class times, the committed in-pipeline PMC summary
   cpu_baseline - the oracle (PyTorch-CPU restatement of the reference path) timed on this host
 """
 import argparse
