@@ -506,6 +506,7 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
         const unsigned ebuf = lds_base + PB_BASE + stage_slot * PB_SLOT + w * P_EPI_WAVE;
         // staging write addresses: row l31 (128-B rows); chunk index = (constant per register group) ^ (lane part)
         const unsigned w16_pre = ebuf + l31 * 128 + ((hi ^ (l31 & 15)) << 3);   // bf16: 8-B chunk (ni*8 + 2g + hi) ^ (row & 15)
+        const unsigned wp_pre = ebuf + l31 * 128 + ((hi ^ pair_key(l31)) << 3);     // activation pair: see pair_key()
         const unsigned w32_pre = ebuf + l31 * 128 + ((hi ^ (l31 & 7)) << 4);    // fp32: 16-B chunk (2g + hi) ^ (row & 7)
         const unsigned r16_a = ebuf + r0 * 128 + (((lane & 7) ^ (r0 >> 1)) << 4);       // bf16, it even
         const unsigned r16_b = ebuf + r0 * 128 + (((lane & 7) ^ (r0 >> 1) ^ 4) << 4);   // bf16, it odd ((row & 15) >> 1 flips bit 2)
@@ -580,9 +581,9 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
                                 actp_pair<ACT>(acc[mi][ni][g * 4 + e], av, dv);
                                 oa[e] = (bf16_t)av; od[e] = (bf16_t)dv;
                             }
-                            // 8-B chunk index within the 128-B row: (which * 8 + 2 g + hi) ^ (row & 15); which = 0 act', 1 act
-                            lds_w64(w16_pre ^ ((2 * g) << 3), __builtin_bit_cast(u32x2, od));
-                            lds_w64(w16_pre ^ ((8 + 2 * g) << 3), __builtin_bit_cast(u32x2, oa));
+                            // 8-B chunk index within the 128-B row: (which * 8 + 2 g + hi) ^ pair_key(row); which = 0 act', 1 act
+                            lds_w64(wp_pre ^ ((2 * g) << 3), __builtin_bit_cast(u32x2, od));
+                            lds_w64(wp_pre ^ ((8 + 2 * g) << 3), __builtin_bit_cast(u32x2, oa));
                         }
                         init_acc(mi, ni);
                         // read back: 16 rows per instruction, 4 lanes x 16 B per row and output; lane -> row rr (+ 16), 16-B
@@ -595,7 +596,7 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
                             for (int half = 0; half < 2; ++half) {
                                 const int row = rr + 16 * half;
                                 const unsigned rbase = ebuf + row * 128;
-                                const int c8 = (which * 8 + 2 * q) ^ (row & 15);
+                                const int c8 = (which * 8 + 2 * q) ^ pair_key(row);
                                 asm volatile("ds_read_b64 %0, %1" : "=v"(rq[(which * 2 + half) * 2]) : "v"(rbase + (c8 << 3)) : "memory");
                                 asm volatile("ds_read_b64 %0, %1" : "=v"(rq[(which * 2 + half) * 2 + 1]) : "v"(rbase + ((c8 ^ 1) << 3)) : "memory");
                             }

@@ -208,6 +208,7 @@ gemm_bf16_nt_256x_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
     const int r0 = lane >> 3;
     const unsigned ebuf = lds_base + X_STAGING + wi * P_EPI_WAVE;
     const unsigned w16_pre = ebuf + l31 * 128 + ((hi ^ (l31 & 15)) << 3);
+    const unsigned wp_pre = ebuf + l31 * 128 + ((hi ^ pair_key(l31)) << 3);
     const unsigned w32_pre = ebuf + l31 * 128 + ((hi ^ (l31 & 7)) << 4);
     const unsigned r16_a = ebuf + r0 * 128 + (((lane & 7) ^ (r0 >> 1)) << 4);
     const unsigned r16_b = ebuf + r0 * 128 + (((lane & 7) ^ (r0 >> 1) ^ 4) << 4);
@@ -352,9 +353,9 @@ gemm_bf16_nt_256x_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
                         actp_pair<ACT>(v[e], av, dv);
                         oa[e] = (bf16_t)av; od[e] = (bf16_t)dv;
                     }
-                    // 8-B chunk index within the 128-B row: (which * 8 + 2 gq + hi) ^ (row & 15); which = 0 act', 1 act
-                    lds_w64(w16_pre ^ ((2 * gq) << 3), __builtin_bit_cast(u32x2, od));
-                    lds_w64(w16_pre ^ ((8 + 2 * gq) << 3), __builtin_bit_cast(u32x2, oa));
+                    // 8-B chunk index within the 128-B row: (which * 8 + 2 gq + hi) ^ pair_key(row); which = 0 act', 1 act
+                    lds_w64(wp_pre ^ ((2 * gq) << 3), __builtin_bit_cast(u32x2, od));
+                    lds_w64(wp_pre ^ ((8 + 2 * gq) << 3), __builtin_bit_cast(u32x2, oa));
                 }
                 init_acc(mi, ni);
                 // read back: 16 rows per instruction, 4 lanes x 16 B per row and output; lane -> row rr = lane >> 2 (+16),
@@ -367,7 +368,7 @@ gemm_bf16_nt_256x_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
                     for (int half = 0; half < 2; ++half) {
                         const int row = rr + 16 * half;
                         const unsigned base = ebuf + row * 128;
-                        const int c8 = (which * 8 + 2 * q) ^ (row & 15);      // first 8-B chunk; its pair is c8 ^ 1
+                        const int c8 = (which * 8 + 2 * q) ^ pair_key(row);      // first 8-B chunk; its pair is c8 ^ 1
                         asm volatile("ds_read_b64 %0, %1" : "=v"(rq[(which * 2 + half) * 2]) : "v"(base + (c8 << 3)) : "memory");
                         asm volatile("ds_read_b64 %0, %1" : "=v"(rq[(which * 2 + half) * 2 + 1]) : "v"(base + ((c8 ^ 1) << 3)) : "memory");
                     }

@@ -57,6 +57,15 @@ __device__ __forceinline__ void lds_wait() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// Swizzle key of the activation-pair staging ([32 rows][act' 64 B | act 64 B], 8-B chunks): a permutation of the row's low
+// four bits - row bits (1, 0, 3, 2) -> key bits (0, 1, 2, 3).  Any bijection keeps the 16-lane ds_write_b64 groups (16
+// consecutive rows, one chunk) conflict-free; the read-back (ds_read_b64, 32 lanes = 8 rows x four 16-B slots of one output)
+// needs the four same-parity rows of a half wave to differ in key bits 0 and 3, the bits the slot index 2 q does not
+// touch (with key = row & 15 the read-back was a 4-way conflict: 18 % of the kernel's LDS-active cycles, PMC).
+__device__ __forceinline__ int pair_key(int row) {
+    return ((row >> 1) & 1) | ((row & 1) << 1) | (((row >> 3) & 1) << 2) | (((row >> 2) & 1) << 3);
+}
+
 // 16-byte buffer store with the whole offset in the VGPR operand and soffset = 0.  With an SGPR soffset hipcc's hazard
 // recogniser assumes that a >8-byte store's data registers may be overwritten by the next VALU instruction; on gfx950
 // that corrupted the upper dwords of stores that were followed by dense VALU code (measured: EPI_BF16_ACT / _DACT).

@@ -224,13 +224,28 @@ class AdversarialTrainer:
                                             L.stream_ptr()), "rvlm_argmax_eq")
         return (pred.sum() / B).item() * 100
 
-    def train_step(self, data, targets, data_adv=None, global_batch=None):
+    def _global_means(self, out: dict, n_local: int) -> dict:
+        """Logging values over the GLOBAL batch, as the reference's single-process DataParallel reports them (…clip.py:
+        368-387 on gathered outputs): every rank contributes n_local x its shard mean, one small all-reduce."""
+        keys = [k for k in ("loss", "loss_clean", "loss_total", "cos_sim_clean", "cos_sim", "acc", "racc") if out.get(k) is not None]
+        vec = torch.tensor([float(out[k]) * n_local for k in keys] + [float(n_local)], dtype=torch.float64)
+        if self._device_collectives:
+            vec = vec.to(self.device)
+        dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=self.pg)
+        vec = vec.cpu()
+        res = dict(out)
+        for i, k in enumerate(keys):
+            res[k] = float(vec[i] / vec[-1])
+        return res
+
+    def train_step(self, data, targets, data_adv=None, global_batch=None, global_metrics=False):
         """One optimizer step on this rank's shard.  Returns dict(loss, loss_clean, loss_total, lr) and, with
         ``metrics`` on, the reference's logging values cos_sim_clean, cos_sim, acc, racc (acc / racc None unless
         ``targets`` are labels and a text head was given).  ``data_adv`` (optional) bypasses the attack with
         precomputed adversarial images (tests).  ``global_batch`` (optional): the number of images all ranks hold in
         this step, when the caller knows it (equal shards: world * len(data)) - skips the size all-reduce.  The
-        returned loss / metrics are this rank's SHARD values (the reference's DataParallel logs global-batch values)."""
+        returned loss / metrics are this rank's SHARD values; ``global_metrics=True`` (one extra 8-number all-reduce and
+        a host sync, for logging steps) returns them over the global batch like the reference's DataParallel logs."""
         with torch.no_grad():
             e0 = self.model_orig(data, self.output_normalize)                   # …clip.py:296-297
         if data_adv is None:
@@ -268,6 +283,8 @@ class AdversarialTrainer:
             is_cls = isinstance(targets, torch.Tensor) and self.T is not None
             out["racc"] = self._acc(emb_adv, targets, normalize=False) if is_cls else None   # logits_adv: NOT normalised
             out["acc"] = self._acc(emb_clean, targets, normalize=True) if is_cls else None
+        if global_metrics and self.world > 1:
+            out = self._global_means(out, data.shape[0])
         return out
 
     def eval_step(self, data_eval, targets_eval):

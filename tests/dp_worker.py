@@ -44,11 +44,10 @@ def main(out):
     assert tr.world == 2 and len(tr.buckets) == 3
     losses = []
     for _ in range(2):
-        o = tr.train_step(x[lo:hi], None, data_adv=xa_fix[lo:hi])
-        losses.append(float(o["loss"]) * (hi - lo))
-    t = torch.tensor([losses[-1]], dtype=torch.float64)
-    dist.all_reduce(t)
-    torch.save(dict(x_adv=attack(x[lo:hi], d0[lo:hi]), params={k: v.cpu() for k, v in tr.state_dict().items()}, loss_global=float(t) / B),
+        o = tr.train_step(x[lo:hi], None, data_adv=xa_fix[lo:hi], global_metrics=True)
+        losses.append(float(o["loss"]))
+    torch.save(dict(x_adv=attack(x[lo:hi], d0[lo:hi]), params={k: v.cpu() for k, v in tr.state_dict().items()}, loss_global=losses[-1],
+                    cos_global=float(o["cos_sim"]), cos_clean_global=float(o["cos_sim_clean"])),
                os.path.join(out, f"rank{rank}.pt"))
     tr.close()
     dist.barrier()
@@ -59,7 +58,8 @@ def main(out):
         p0 = {k: v.cpu() for k, v in tr1.state_dict().items()}
         for _ in range(2):
             o = tr1.train_step(x, None, data_adv=xa_fix)
-        torch.save(dict(x_adv=attack(x, d0), params={k: v.cpu() for k, v in tr1.state_dict().items()}, params0=p0, loss=float(o["loss"])),
+        torch.save(dict(x_adv=attack(x, d0), params={k: v.cpu() for k, v in tr1.state_dict().items()}, params0=p0, loss=float(o["loss"]),
+                        cos=float(o["cos_sim"]), cos_clean=float(o["cos_sim_clean"])),
                    os.path.join(out, "single.pt"))
         tr1.close()
 
