@@ -166,7 +166,7 @@ __device__ __forceinline__ f32x16 zero16() {
 // forward
 // =============================================================================================
 template <bool USE_TR, int MINW>
-__global__ void __launch_bounds__(576, MINW)
+__global__ void __launch_bounds__(640, MINW)
 attn_fwd_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict__ o, long ldo,
                 float* __restrict__ lse2, int H, int S, int Sp, int W, float scale_log2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -448,7 +448,7 @@ attn_bwd_prep_kernel(const bf16_t* __restrict__ o, long ldo, const bf16_t* __res
 // backward dQ: wave owns a query tile, K and V LDS-resident
 // =============================================================================================
 template <bool USE_TR>
-__global__ void __launch_bounds__(576)
+__global__ void __launch_bounds__(640)
 attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __restrict__ o, long ldo,
                    const bf16_t* __restrict__ d_o, long lddo, const float* __restrict__ lse2,
                    float* __restrict__ dsum, bf16_t* __restrict__ dqkv, long lddq, int H, int S, int Sp, int W,
@@ -529,7 +529,7 @@ attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __rest
 // backward dK, dV: wave owns a key tile, Q and dO LDS-resident
 // =============================================================================================
 template <bool USE_TR, bool KV_LDS>
-__global__ void __launch_bounds__(576)
+__global__ void __launch_bounds__(640)
 attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __restrict__ d_o, long lddo,
                     const float* __restrict__ lse2, const float* __restrict__ dsum,
                     bf16_t* __restrict__ dqkv, long lddq, int H, int S, int Sp, int W, float scale,
@@ -987,8 +987,11 @@ static bool g_use_tr = true;
 void attn_set_use_tr(int on) { g_use_tr = on != 0; }
 
 static int attn_block_threads(int ntiles) {
-    // one 32-row tile per wave, up to 9 waves (S = 257 -> 9 tiles -> 576 threads, perfectly balanced)
-    return (ntiles < 9 ? ntiles : 9) * 64;
+    // one 32-row tile per wave and round, up to 10 waves: the fewest rounds, then the fewest waves that give them
+    // (S = 257 -> 9 tiles -> 9 waves; S = 577 -> 19 tiles -> 2 rounds of 10 waves - with 9 waves it took 3 rounds, 27 wave
+    // slots for 19 tiles of work; 10 waves still are at most 3 per SIMD, the register budget of 9)
+    const int rounds = (ntiles + 9) / 10;
+    return ((ntiles + rounds - 1) / rounds) * 64;
 }
 
 template <typename K>
@@ -1035,7 +1038,8 @@ int attn_fwd_bf16(const bf16_t* qkv, long ldqkv, bf16_t* o, long ldo, float* lse
         hipLaunchKernelGGL((attn_fwd_kernel<TR, MW>), dim3(B * H), dim3(nt), lds_bytes, s, qkv, ldqkv, o,    \
                            ldo, lse, H, S, Sp, W, sl2);                                                      \
     } while (0)
-    if (g_use_tr) { if (occ == 5) LAUNCH_FWD(true, 5); else LAUNCH_FWD(true, 1); }
+    // (two workgroups share a CU only if their K / V tiles fit twice: at S = 577 the 96-register cap would buy nothing)
+    if (g_use_tr) { if (occ == 5 && 2 * lds_bytes <= 160 * 1024) LAUNCH_FWD(true, 5); else LAUNCH_FWD(true, 1); }
     else LAUNCH_FWD(false, 1);
 #undef LAUNCH_FWD
     RVLM_CHECK_LAUNCH();
