@@ -770,7 +770,7 @@ int gemm_bf16_nt_256p(const GemmBf16& p, int* rows_done, hipStream_t s) {
     if (strip_first < 0) { const char* e = getenv("RVLM_GEMM_STRIP_FIRST"); strip_first = e ? atoi(e) : 130; }
     q.stagger |= (strip_first & 255) << 16;
     static int group_m = -1, wave_prio = -1;
-    if (group_m < 0) { const char* e = getenv("RVLM_GEMM_GROUP_M"); group_m = e ? std::max(1, atoi(e)) : 8; }
+    if (group_m < 0) { const char* e = getenv("RVLM_GEMM_GROUP_M"); group_m = e ? std::max(1, atoi(e)) : 4; }
     if (wave_prio < 0) { const char* e = getenv("RVLM_GEMM_PRIO"); wave_prio = e ? atoi(e) : 0; }
     static int krot = -999;
     if (krot == -999) { const char* e = getenv("RVLM_GEMM_KROT"); krot = e ? atoi(e) : 0; }

@@ -458,7 +458,7 @@ int gemm_bf16_nt_256x(const GemmBf16& p, int* rows_done, hipStream_t s) {
     if (tail_on < 0) { const char* e = getenv("RVLM_GEMM_TAIL"); tail_on = e ? atoi(e) : 1; }
     const int m_total = (tail_on && p.M > q.M) ? p.M : q.M;
     static int group_m = -1;
-    if (group_m < 0) { const char* e = getenv("RVLM_GEMM_GROUP_M"); group_m = e ? std::max(1, atoi(e)) : 8; }
+    if (group_m < 0) { const char* e = getenv("RVLM_GEMM_GROUP_M"); group_m = e ? std::max(1, atoi(e)) : 4; }
     q.group_m = group_m;
     const bool gelu = p.act != RVLM_ACT_QUICK_GELU;
     int rc;

@@ -53,7 +53,7 @@ struct GemmBf16 {
     float* splitk = nullptr;            // fp32 slab scratch for the split-K paths (few-row GEMMs); null: no split-K
     size_t splitk_bytes = 0;
     int stagger = 0;                    // persistent kernel only: odd workgroup groups start stagger x ~4 us late
-    int group_m = 8;                    // persistent kernel only: m-tiles per tile-order group (RVLM_GEMM_GROUP_M experiment)
+    int group_m = 4;                    // persistent kernel only: m-tiles per tile-order group (RVLM_GEMM_GROUP_M)
     int wave_prio = 0;                  // persistent kernel only: s_setprio for waves 4-7 (RVLM_GEMM_PRIO experiment)
     int krot = 0;                       // persistent kernel only: K-step rotation per workgroup (RVLM_GEMM_KROT experiment)
     int batch_m_rows = 0;               // persistent kernel only, > 0: batched form - rows [b*batch_m_rows, ...) of A meet

@@ -15,7 +15,7 @@ Run: python scripts/pingpong_model.py      Used by tests/test_pingpong_model.py.
 from __future__ import annotations
 
 
-def tile_list(wg, grid, tiles_m, tiles_n, group_m=8):
+def tile_list(wg, grid, tiles_m, tiles_n, group_m=4):
     """tile list of workgroup `wg` as tile_origin() of the persistent kernels lays it out: (m0, n0) in rows / columns"""
     ntiles = tiles_m * tiles_n
     out = []
