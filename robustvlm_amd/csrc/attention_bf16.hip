@@ -663,7 +663,10 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
                       unsigned long long* __restrict__ trace, int desync, AttnLayout lay, int nbh) {
     // Phase offset: every CU would otherwise stage its head at the same moment (6 TB/s-bound, 22 % of the kernel spent
     // waiting for HBM) and compute at the same moment (HBM idle).  The first workgroup of each CU starts up to 7 x desync
-    // kilo-cycles late; the stagger then persists, one CU's staging hides under the others' compute.
+    // kilo-cycles late; the stagger then persists, one CU's staging hides under the others' compute.  (RVLM_ATTN_DESYNC,
+    // default 0 since round 3: worth 5 % on the one-head-per-workgroup kernel of round 1, but the persistent kernel requests
+    // the next head's Q / dO under its tile loop and then the late start only costs its tail - in-pipeline attention
+    // backward 46.5 ms per step at 5, 44.9 at 0, 49.3 at 9; profiles/r03_ab_attn_desync.log)
     if (desync > 0 && blockIdx.x < 256) {
         for (int i = 0; i < (int)((blockIdx.x >> 3) & 7) * desync; ++i) __builtin_amdgcn_s_sleep(16);   // 16 x 64 cycles
     }
@@ -1064,7 +1067,7 @@ int attn_bwd_bf16(const bf16_t* qkv, long ldqkv, const bf16_t* o, long ldo, cons
         if ((rc = set_lds(attn_bwd_fused_kernel<NK>, lds_f))) return rc;
         static int trace = -1, desync = -1;
         if (trace < 0) { const char* e = getenv("RVLM_ATTN_TRACE"); trace = e ? atoi(e) : 0; }
-        if (desync < 0) { const char* e = getenv("RVLM_ATTN_DESYNC"); desync = e ? atoi(e) : 5; }
+        if (desync < 0) { const char* e = getenv("RVLM_ATTN_DESYNC"); desync = e ? atoi(e) : 0; }
         static int hm = -1, persist = -1;
         if (hm < 0) { const char* e = getenv("RVLM_ATTN_HM"); hm = e ? atoi(e) : 0; }
         if (persist < 0) { const char* e = getenv("RVLM_ATTN_PERSIST"); persist = e ? atoi(e) : 1; }
