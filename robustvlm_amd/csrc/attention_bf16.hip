@@ -666,7 +666,10 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
     // kilo-cycles late; the stagger then persists, one CU's staging hides under the others' compute.  (RVLM_ATTN_DESYNC,
     // default 0 since round 3: worth 5 % on the one-head-per-workgroup kernel of round 1, but the persistent kernel requests
     // the next head's Q / dO under its tile loop and then the late start only costs its tail - in-pipeline attention
-    // backward 46.5 ms per step at 5, 44.9 at 0, 49.3 at 9; profiles/r03_ab_attn_desync.log)
+    // backward 46.5 ms per step at 5, 44.9 at 0, 49.3 at 9; two phases 4-8 k cycles apart: 195 vs 202 us in the micro-benchmark,
+    // 44.5 vs 44.7 ms in the pipeline; profiles/r03_ab_attn_desync.log)
+    const int trace_mode = desync >> 8;       // (RVLM_ATTN_TRACE=2: per-wave duration of phase 1 instead of the phase stamps)
+    desync &= 255;
     if (desync > 0 && blockIdx.x < 256) {
         for (int i = 0; i < (int)((blockIdx.x >> 3) & 7) * desync; ++i) __builtin_amdgcn_s_sleep(16);   // 16 x 64 cycles
     }
@@ -698,7 +701,7 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
     const int l31 = lane & 31, hi = lane >> 5;
     // optional phase timeline (RVLM_ATTN_TRACE=1: 5 s_memtime stamps per head into the dsum scratch buffer)
     auto stamp = [&](int k) {
-        if (trace && threadIdx.x == 0) trace[(long)bh * 8 + k] = __builtin_amdgcn_s_memtime();
+        if (trace && trace_mode < 2 && threadIdx.x == 0) trace[(long)bh * 8 + k] = __builtin_amdgcn_s_memtime();
     };
     stamp(0);
     const int b = bh / H, h = bh % H;
@@ -726,16 +729,20 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
     bf16x8 ofr[4];   // O rows of this wave's query tile (for D = rowsum(dO * O)): requested under the staging
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) ofr[kk] = frag_global(ob, ldo, w * 32 + (lane & 31), kk, lane);
-    // the odd query's rows as 64-wide vectors (last wave only), requested under the staging as well: fetched in phase 1
-    // they put an HBM round trip on the path to the phase's barrier
+    // the odd query's rows as 64-wide vectors (ONE wave), requested under the staging as well: fetched in phase 1 they put
+    // an HBM round trip on the path to the phase's barrier.  That wave is wave 0: per-wave stamps (RVLM_ATTN_TRACE=2) put
+    // the first-dispatched waves 0-3 at the phase's barrier after 4.3 k cycles, waves 4-6 after 5.6 k, and the wave that
+    // carries these 1.7 k cycles of serial shuffles on top - it used to be the last one - after 7.3 k
+    constexpr int ODD_Q_WAVE = 0;
     float odd_do = 0.0f, odd_o = 0.0f, odd_q = 0.0f, odd_v = 0.0f;
-    if (w == NK - 1) {
+    if (w == ODD_Q_WAVE) {
         odd_do = (float)dob[(long)SE * lddo + lane]; odd_o = (float)ob[(long)SE * ldo + lane];
         odd_q = (float)base[(long)SE * ld + lane]; odd_v = (float)base[(long)SE * ld + 2 * W + lane];
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the inline-asm requests of the previous head's loop)
     __syncthreads();
     stamp(1);
+    const unsigned long long t_p1 = (trace && trace_mode == 2) ? __builtin_amdgcn_s_memtime() : 0ull;
 
     const FragOffs fo = make_offs(lane);
     // ---- phase 1: this wave's key tile in registers; D for its query tile(s); the odd key -------------------
@@ -756,6 +763,7 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
                 (__attribute__((address_space(3))) bf16x4*)((lds_char*)Kt + swz_off(row, 2 * db + ((i16 & 3) >> 1)) + (i16 & 1) * 8));
             kq[j][4 * r + 0] = v[0]; kq[j][4 * r + 1] = v[1]; kq[j][4 * r + 2] = v[2]; kq[j][4 * r + 3] = v[3];
         }
+    if (trace) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamp(5); }     // K / V / K^T fragments in registers
     {
         f32x16 dke[2] = {zero16(), zero16()}, dve[2] = {zero16(), zero16()};
         {
@@ -781,6 +789,7 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
             }
             const float pe = EXP2(fmaf(sT[0], scale_log2, -Ls[q]));
             if (hi == 0) { Ds[q] = dsum; Pe[q] = pe; De[q] = pe * (dpT[0] - dsum); }
+            if (trace) stamp(6);                                                       // D, p and dS of the odd key
             // dV, dK of the odd key: B operand with the single column n = 0 (lanes 0 and 32), k <-> the 32 queries
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -814,7 +823,7 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
                 }
         }
     }
-    if (w == NK - 1) {
+    if (w == ODD_Q_WAVE) {
         // the odd QUERY (row SE) against the odd key, as 64-wide vectors (lane <-> d): D, p, dS, and its dK / dV terms
         const float dov = odd_do, ov = odd_o, qv = odd_q, kv = Ke[lane], vv = odd_v;
         const float dsum = wave_sum(dov * ov), sc = wave_sum(qv * kv), dpe = wave_sum(dov * vv);
@@ -823,6 +832,11 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
         if (lane < 32) { Ds[SE + lane] = (lane == 0) ? dsum : 0.0f; Pe[SE + lane] = (lane == 0) ? pe : 0.0f; De[SE + lane] = (lane == 0) ? de : 0.0f; }
         KVe[(NK * 2 + 0) * 64 + lane] = de * qv;
         KVe[(NK * 2 + 1) * 64 + lane] = pe * dov;
+    }
+    if (trace) stamp(7);                                                               // this wave's part of phase 1 done
+    if (trace && trace_mode == 2 && (threadIdx.x & 63) == 0) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        trace[(long)bh * 8 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memtime() - t_p1;
     }
     __syncthreads();   // K / V tiles are dead: the area becomes the partial slots; Ds / Pe / De are complete
     stamp(2);
@@ -1076,12 +1090,12 @@ int attn_bwd_bf16(const bf16_t* qkv, long ldqkv, const bf16_t* o, long ldo, cons
             const AttnLayout lay = {(long)H * S * 64, (long)S * 64, (long)H * S * 64, (long)S * 64};
             hipLaunchKernelGGL((attn_bwd_fused_kernel<NK>), dim3(grid), dim3(NK * 64), lds_f, s, qkv, 64L, o, 64L, d_o, 64L,
                                lse, dqkv, 64L, H, S, (long)B * H * S * 64, scale, sl2,
-                               trace ? (unsigned long long*)dsum_scratch : nullptr, desync, lay, nbh);
+                               trace ? (unsigned long long*)dsum_scratch : nullptr, desync | (trace << 8), lay, nbh);
         } else {
             const AttnLayout lay = {(long)S * ldqkv, 64L, (long)S * ldo, 64L};
             hipLaunchKernelGGL((attn_bwd_fused_kernel<NK>), dim3(grid), dim3(NK * 64), lds_f, s, qkv, ldqkv, o, ldo, d_o, lddo,
                                lse, dqkv, lddqkv, H, S, (long)W, scale, sl2,
-                               trace ? (unsigned long long*)dsum_scratch : nullptr, desync, lay, nbh);
+                               trace ? (unsigned long long*)dsum_scratch : nullptr, desync | (trace << 8), lay, nbh);
         }
         RVLM_CHECK_LAUNCH();
         return RVLM_OK;

@@ -33,10 +33,17 @@ for name, fn, flops, nbytes in (("fwd", fwd, 4.0 * B * H * S * S * 64, 4.0 * B *
     ms = e0.elapsed_time(e1) / 20
     print(f"S={S} B={B} H={H} attn {name}: {ms*1e3:8.1f} us  {flops/ms/1e9:7.1f} TFLOP/s (algorithmic)  {nbytes/ms/1e9:6.2f} TB/s (algorithmic bytes)", flush=True)
 
-if os.environ.get("RVLM_ATTN_TRACE") and S == 257:
+if os.environ.get("RVLM_ATTN_TRACE") == "2" and S == 257:
+    t = dsum.view(torch.int64)[: B * H * 8].view(B * H, 8).cpu().double()
+    print("   phase 1 of the fused backward, cycles from its barrier to the end of each wave's own work (mean over heads):")
+    print("   " + "  ".join(f"w{w}: {float(t[:, w].mean()):6.0f}" for w in range(8)))
+elif os.environ.get("RVLM_ATTN_TRACE") and S == 257:
     t = dsum.view(torch.int64)[: B * H * 8].view(B * H, 8).cpu().double()
     names = ["stage Q,dO,K,V", "fragments + D + odd key", "9 query-tile steps", "dK/dV stores"]
     tot = (t[:, 4] - t[:, 0]).mean()
     for i, nm in enumerate(names):
         print(f"   fused bwd phase {nm:26s}: {float((t[:, i + 1] - t[:, i]).mean()):9.0f} cycles ({100 * float((t[:, i + 1] - t[:, i]).mean() / tot):4.1f} %)")
     print(f"   per workgroup: {float(tot):.0f} cycles")
+    for i, nm in ((5, "fragments of K, V, K^T read"), (6, "D, odd-key p / dS"), (7, "odd-key dK / dV (thread 0's wave)"), (2, "barrier")):
+        prev = {5: 1, 6: 5, 7: 6, 2: 7}[i]
+        print(f"      phase 1: {nm:36s} {float((t[:, i] - t[:, prev]).mean()):8.0f} cycles")
