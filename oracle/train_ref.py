@@ -3,10 +3,16 @@
 Restates the part of ``train_one_epoch`` after the attack (train/adversarial_training_clip.py:338-387):
 clean / adversarial forward, ``compute_loss`` (``--loss_clean`` with T=None for the clean term, ``--trades``),
 ``loss_total.backward()``, ``torch.optim.AdamW`` (:196-197), the third-party open_clip ``cosine_lr`` (:211) and the
-logging metrics cos-sim-clean / cos-sim / acc / racc (:368-387).  The reference module cannot be imported here
-(torchvision / open_clip / wandb missing), so this file is pinned by construction only: it is plain torch
-autograd + torch.optim.AdamW over oracle/vit_ref.py (itself pinned against HF transformers) - "parity
-unpinned" by reference outputs for this row.
+logging metrics cos-sim-clean / cos-sim / acc / racc (:368-387); ``eval_ref`` restates the periodic validation
+(:389-424).
+
+PINNED: the reference module cannot be imported here (torchvision / open_clip / wandb missing), but its
+``train_one_epoch`` takes model, optimizer, scheduler, dataloader and ``args`` as parameters, so
+tests/golden/make_golden_train.py AST-extracts it and RUNS it on a tiny seeded ViT (4 recipes x 5 steps);
+tests/test_oracle_golden.py::test_train_step_oracle_vs_reference_train_one_epoch holds this file to the recorded
+losses, metrics, learning rates and post-step parameters bit for bit.  What the fixture caught: the reference never
+calls ``scheduler`` before the first optimizer step (:211-219 build it, :366 is its only call site, AFTER
+``step_total += 1``), so step 1 runs at the BASE learning rate and step s >= 2 at ``cosine_lr(s - 1)``.
 """
 from __future__ import annotations
 
@@ -36,7 +42,7 @@ class TrainStepRef:
         self.loss_clean, self.trades = loss_clean, trades
         self.last_metrics = {}
         self.step_total = 0
-        self._set_lr(cosine_lr_ref(0, lr, warmup, steps))
+        # no scheduler call before the first step (…clip.py:211-219): AdamW starts at the base LR it was built with
 
     def _set_lr(self, lr):
         for g in self.opt.param_groups:
@@ -72,3 +78,20 @@ class TrainStepRef:
                 m["acc"] = acc(F.normalize(emb_clean, dim=1) @ self.T)
             self.last_metrics = m
         return float(loss.detach()), grads
+
+
+def eval_ref(cfg, weights, x_eval, y_eval, T, eps, clean_weight, norm="linf"):
+    """The periodic validation of train_one_epoch (…clip.py:389-424): 50-step supervised APGD (CE on the zero-shot
+    head; ``initial_stepsize = 0.05 * eps`` iff clean_weight > 0), then acc / racc of the NORMALISED embeddings and the
+    clean-vs-adversarial cosine similarity.  Returns (acc, racc, cos_sim, x_adv)."""
+    from . import attacks_ref as A
+    from .losses_ref import ComputeLossWrapperRef, compute_acc_ref
+    model = V.ClipVisionModelRef(cfg, weights).eval()
+    wrap = ComputeLossWrapperRef(None, T, "none", "ce", 100.)
+    adv = A.apgd_train_ref(model, x_eval, y_eval, norm, eps, n_iter=50, loss_fn=wrap,
+                           initial_stepsize=0.05 * eps if clean_weight > 0 else None)
+    with torch.no_grad():
+        ea, ec = model(adv, True), model(x_eval, True)
+        racc, acc = compute_acc_ref(ea @ T, y_eval), compute_acc_ref(ec @ T, y_eval)
+        cs = float(torch.nn.functional.cosine_similarity(ea, ec, dim=1).mean())
+    return acc, racc, cs, adv

@@ -8,7 +8,8 @@ Mirrors the step semantics of ``train_one_epoch`` (train/adversarial_training_cl
     loss_clean = compute_loss(loss_clean, emb_clean, e0, T=None)  if cw > 0     :341-347
     loss = compute_loss(loss, emb_adv, e0 | emb_clean.detach() (trades), T)     :352-359
     loss_total = cw * loss_clean + (1 - cw) * loss                              :360
-    loss_total.backward(); optimizer.step(); zero_grad(); scheduler(step)       :361-366
+    loss_total.backward(); optimizer.step(); zero_grad();                       :361-364
+    step_total += 1; scheduler(step_total)   (sets the NEXT step's LR)          :365-366
     cos-sim-clean / cos-sim / acc / racc                (logging, no grad)      :368-387
     every eval_freq steps: acc / racc / cos-sim under a 50-step supervised APGD :389-424
 
@@ -129,7 +130,10 @@ class AdversarialTrainer:
         self.T = embedding_text_labels_norm
         self.metrics = bool(metrics)
         self.step_total = 0
-        self.cur_lr = cosine_lr_value(0, lr, warmup, steps)      # scheduler(start_step), …clip.py:219
+        # The reference builds the scheduler (…clip.py:211) but calls it only AFTER each optimizer step (:366, its one
+        # call site): the first step of a fresh run uses the BASE learning rate AdamW was built with (:197), step s >= 2
+        # uses cosine_lr(s - 1).  Pinned by tests/golden/train_step_tiny.npz (the reference's own train_one_epoch).
+        self.cur_lr = float(lr)
         self.pg = process_group
         self.world = dist.get_world_size(self.pg) if (dist.is_available() and dist.is_initialized()) else 1
         # always_reduce: run the bucketed all-reduce path even in a one-rank group (exercises the RCCL calls, the work
@@ -346,13 +350,18 @@ class AdversarialTrainer:
                 self.exp_avg[o:o + c].copy_(st["exp_avg"].reshape(-1).to(self.device))
                 self.exp_avg_sq[o:o + c].copy_(st["exp_avg_sq"].reshape(-1).to(self.device))
                 step = int(float(st["step"]))
+            file_lr = sd["param_groups"][0].get("lr") if sd["param_groups"] else None
         else:
             for k, (o, c) in self.params.offsets.items():
                 self.exp_avg[o:o + c].copy_(sd["exp_avg"][k].reshape(-1).to(self.device))
                 self.exp_avg_sq[o:o + c].copy_(sd["exp_avg_sq"][k].reshape(-1).to(self.device))
             step = int(sd["step"])
+            file_lr = None
         self.step_total = int(step if start_step is None else start_step)
-        self.cur_lr = cosine_lr_value(self.step_total, self.lr, self.warmup, self.steps)
+        # optimizer.load_state_dict restores the param group's lr (…clip.py:207-208) = what the scheduler left behind
+        # when the file was written; the next scheduler call comes after the first resumed step
+        self.cur_lr = float(file_lr) if file_lr is not None else cosine_lr_value(self.step_total, self.lr, self.warmup,
+                                                                                 self.steps)
 
     def load_state_dict(self, state_dict):
         """Resume the model weights (…clip.py:98-103): both engines' GEMM copies are refreshed; ``model_orig`` keeps the

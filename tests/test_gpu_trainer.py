@@ -408,3 +408,57 @@ def test_train_step_vit_l14_vs_oracle(precision):
     assert agree / total > (0.999 if precision == "fp32" else 0.98), agree / total
     tr.engine.close(); tr.engine_orig.close()
     torch.set_num_threads(8)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# round 4: the product's train_step / eval_step against the reference's OWN train_one_epoch
+# (tests/golden/train_step_tiny.npz, written by tests/golden/make_golden_train.py in the build container)
+# --------------------------------------------------------------------------------------------------------------------
+TRAIN_CASES = {
+    "fare_pgd": dict(attack="pgd", loss="l2", inner_loss="l2", clean_weight=0.0, trades=False, output_normalize=False),
+    "tecoa_pgd": dict(attack="pgd", loss="ce", inner_loss="ce", clean_weight=0.0, trades=False, output_normalize=True),
+    "none_cw": dict(attack="none", loss="ce", inner_loss="ce", clean_weight=0.5, trades=False, output_normalize=True),
+    "apgd_trades_cw": dict(attack="apgd", loss="l2", inner_loss="l2", clean_weight=0.3, trades=True,
+                           output_normalize=True),
+}
+
+
+@pytest.mark.parametrize("name", sorted(TRAIN_CASES))
+def test_train_step_vs_reference_train_one_epoch(name):
+    """AdversarialTrainer.train_step (fp32 mode) on the batches the reference's train_one_epoch (…clip.py:276-486) was
+    run on, with the adversarial batches that run produced: the learning rate of every step EXACTLY (step 1 at the
+    base LR - the reference calls its scheduler only after a step), losses / cos-sims to fp32 rounding, acc / racc
+    equal, parameters after the steps within what Adam's normalised step allows for rounding-noise gradients."""
+    from tests.helpers import load_golden, cfg_from_array, weights_from_golden
+    z = load_golden("train_step_tiny.npz")
+    cfg, w, c = cfg_from_array(z["cfg"]), weights_from_golden(z), TRAIN_CASES[name]
+    B = z["x"].shape[1]
+    tr = AdversarialTrainer(to_cfg(cfg), {k: v.to(dev()) for k, v in w.items()}, batch_size=6, precision="fp32",
+                            lr=float(z["lr"]), wd=float(z["wd"]), warmup=int(z["warmup"]), steps=int(z["steps"]),
+                            embedding_text_labels_norm=torch.from_numpy(z["T"]).to(dev()), loss_clean="l2",
+                            eps=float(z["eps"]), **c)
+    keys, W = list(w), cfg.width
+    for s in range(z["x"].shape[0]):
+        x, y = torch.from_numpy(z["x"][s]).to(dev()), torch.from_numpy(z["y"][s]).to(dev())
+        xa = torch.from_numpy(z[f"{name}::x_adv"][s]).to(dev()) if f"{name}::x_adv" in z.files else x
+        out = tr.train_step(x, y, data_adv=xa)
+        assert out["lr"] == float(z[f"{name}::lr_used"][s]), (s, out["lr"])
+        assert tr.cur_lr == float(z[f"{name}::lr_after"][s])
+        for key in ("loss", "loss_total", "cos_sim_clean", "cos_sim"):
+            got, want = float(out[key]), float(z[f"{name}::{key}"][s])
+            assert abs(got - want) <= 2e-3 * abs(want) + 2e-5, (s, key, got, want)
+        assert out["acc"] == float(z[f"{name}::acc"][s]) and out["racc"] == float(z[f"{name}::racc"][s]), s
+        if s == 0:
+            logs = tr.eval_step(torch.from_numpy(z["x_eval"]).to(dev()), torch.from_numpy(z["y_eval"]).to(dev()))
+            want = z[f"{name}::eval"]
+            assert logs["eval/acc"] == want[0], (logs, want)
+            assert abs(logs["eval/racc"] - want[1]) <= 100 / 6 + 1e-6         # at most one borderline sample differs
+            assert abs(logs["eval/cos-sim"] - want[2]) < 0.02
+        if f"{name}::w{s + 1}::{keys[0]}" in z.files:
+            sd = tr.state_dict()
+            for k in keys:
+                got, want = sd[k].cpu(), torch.from_numpy(z[f"{name}::w{s + 1}::{k}"])
+                if k.endswith("attn.in_proj_bias"):        # key bias: true gradient 0, Adam steps on rounding noise
+                    got = torch.cat([got[:W], got[2 * W:]]); want = torch.cat([want[:W], want[2 * W:]])
+                assert rel_max(got, want) < 1e-2, (s, k, rel_max(got, want))
+    tr.close()

@@ -304,3 +304,81 @@ def test_apgd_train_l2norm_tiny_vit_bit_exact(loss_name, n_iter):
     out = A.apgd_train_ref(model, x, y, "l2", 1.0, n_iter=n_iter, loss_fn=wrap)
     assert np.array_equal(out.numpy(), g[f"apgd_{loss_name}_{n_iter}_xadv"])
     assert float((out - x).flatten(1).norm(dim=1).max()) <= 1.0 + 1e-5
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# round 4: the optimizer step against the reference's OWN train_one_epoch (tests/golden/make_golden_train.py)
+# --------------------------------------------------------------------------------------------------------------------
+TRAIN_CASES = {   # the args fields of each recorded run (same table as make_golden_train.py::CASES)
+    "fare_pgd": dict(loss="l2", loss_clean="l2", clean_weight=0.0, trades=False, output_normalize=False),
+    "tecoa_pgd": dict(loss="ce", loss_clean="l2", clean_weight=0.0, trades=False, output_normalize=True),
+    "none_cw": dict(loss="ce", loss_clean="l2", clean_weight=0.5, trades=False, output_normalize=True),
+    "apgd_trades_cw": dict(loss="l2", loss_clean="l2", clean_weight=0.3, trades=True, output_normalize=True),
+}
+
+
+@pytest.mark.parametrize("name", sorted(TRAIN_CASES))
+def test_train_step_oracle_vs_reference_train_one_epoch(name):
+    """oracle/train_ref.py against what the reference's train_one_epoch (…clip.py:276-486) did on the same batches:
+    learning rate USED by every optimizer step, loss / loss-total / cos-sim-clean / cos-sim / acc / racc, and every
+    parameter after the step, bit for bit (same torch, same ops in the same order)."""
+    from oracle.train_ref import TrainStepRef
+    z = load_golden("train_step_tiny.npz")
+    assert sorted(TRAIN_CASES) == [str(c) for c in z["cases"]]
+    cfg = cfg_from_array(z["cfg"])
+    w = weights_from_golden(z)
+    c = TRAIN_CASES[name]
+    T = torch.from_numpy(z["T"])
+    ref = TrainStepRef(cfg, w, lr=float(z["lr"]), wd=float(z["wd"]), warmup=int(z["warmup"]), steps=int(z["steps"]),
+                       T=T, **c)
+    model_orig = V.ClipVisionModelRef(cfg, w)
+    keys = list(w)
+    n_steps = z["x"].shape[0]
+    for s in range(n_steps):
+        x, y = torch.from_numpy(z["x"][s]), torch.from_numpy(z["y"][s])
+        xa = torch.from_numpy(z[f"{name}::x_adv"][s]) if f"{name}::x_adv" in z.files else x
+        with torch.no_grad():
+            e0 = model_orig(x, c["output_normalize"])
+        lr_used = ref.opt.param_groups[0]["lr"]
+        loss, _ = ref.step(x, xa, y, e0)
+        m = ref.last_metrics
+        assert lr_used == float(z[f"{name}::lr_used"][s]), (s, lr_used)
+        assert ref.opt.param_groups[0]["lr"] == float(z[f"{name}::lr_after"][s])
+        for key, got in (("loss", loss), ("loss_total", m["loss_total"]), ("cos_sim_clean", m["cos_sim_clean"]),
+                         ("cos_sim", m["cos_sim"]), ("acc", m["acc"]), ("racc", m["racc"])):
+            assert got == float(z[f"{name}::{key}"][s]), (s, key, got, float(z[f"{name}::{key}"][s]))
+        wsum = np.array([float(ref.w[k].detach().double().sum()) for k in keys])
+        wsq = np.array([float((ref.w[k].detach().double() ** 2).sum()) for k in keys])
+        assert np.array_equal(wsum, z[f"{name}::wsum"][s]) and np.array_equal(wsq, z[f"{name}::wsq"][s]), s
+        if f"{name}::w{s + 1}::{keys[0]}" in z.files:
+            for k in keys:
+                assert np.array_equal(ref.w[k].detach().numpy(), z[f"{name}::w{s + 1}::{k}"]), (s, k)
+
+
+@pytest.mark.parametrize("name", ["fare_pgd", "none_cw"])
+def test_eval_oracle_vs_reference_train_one_epoch(name):
+    """The validation the reference runs after its first optimizer step (…clip.py:389-424) on the weights of that step:
+    the 50-step supervised APGD batch bit for bit, acc / racc / cos-sim equal."""
+    from oracle.train_ref import eval_ref
+    z = load_golden("train_step_tiny.npz")
+    cfg = cfg_from_array(z["cfg"])
+    c = TRAIN_CASES[name]
+    if f"{name}::w1::class_embedding" in z.files:
+        w1 = {k[len(f"{name}::w1::"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(f"{name}::w1::")}
+    else:                              # only the last step's parameters are stored in full: replay step 1 with the oracle
+        from oracle.train_ref import TrainStepRef
+        w = weights_from_golden(z)
+        T = torch.from_numpy(z["T"])
+        ref = TrainStepRef(cfg, w, lr=float(z["lr"]), wd=float(z["wd"]), warmup=int(z["warmup"]),
+                           steps=int(z["steps"]), T=T, **c)
+        x, y = torch.from_numpy(z["x"][0]), torch.from_numpy(z["y"][0])
+        xa = torch.from_numpy(z[f"{name}::x_adv"][0]) if f"{name}::x_adv" in z.files else x
+        with torch.no_grad():
+            e0 = V.ClipVisionModelRef(cfg, w)(x, c["output_normalize"])
+        ref.step(x, xa, y, e0)
+        w1 = {k: v.detach() for k, v in ref.w.items()}
+    acc, racc, cs, adv = eval_ref(cfg, w1, torch.from_numpy(z["x_eval"]), torch.from_numpy(z["y_eval"]),
+                                  torch.from_numpy(z["T"]), float(z["eps"]), c["clean_weight"])
+    assert np.array_equal(adv.numpy(), z[f"{name}::x_adv_eval"])
+    want = z[f"{name}::eval"]
+    assert acc == want[0] and racc == want[1] and cs == want[2], (acc, racc, cs, want)
