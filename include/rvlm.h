@@ -219,6 +219,14 @@ int rvlm_apgd_controller(int i, int B, int n_iter, int k, int do_check, const fl
                          float* loss_best_last_check, float* reduced_last_check, float* step,
                          uint8_t* acc, uint8_t* f_notpred, uint8_t* f_improved,
                          uint8_t* f_reduced, rvlm_stream_t stream);
+/* The same with the oscillation threshold as a parameter: `rho` of APGDAttack (autoattack/autopgd_base.py:111,137;
+ * check_oscillation's k3, :170-175,415-416); rvlm_apgd_controller is rho = 0.75, the value apgd_train hard-codes
+ * (train/apgd_train.py:117,334). */
+int rvlm_apgd_controller_rho(int i, int B, int n_iter, int k, int do_check, double rho, const float* loss_i,
+                             const uint8_t* pred, float* loss_steps, float* loss_best,
+                             float* loss_best_last_check, float* reduced_last_check, float* step,
+                             uint8_t* acc, uint8_t* f_notpred, uint8_t* f_improved,
+                             uint8_t* f_reduced, rvlm_stream_t stream);
 /* The index assignments of the same lines as one pass over the image tensors. */
 int rvlm_apgd_select(float* x_adv, float* grad, float* x_best, float* grad_best,
                      float* x_best_adv, const uint8_t* f_notpred, const uint8_t* f_improved,
@@ -276,6 +284,10 @@ int rvlm_apgd_run(rvlm_vit* h, const float* x, const float* x_init, int B,
                   const rvlm_loss_spec* loss, float eps, int n_iter, float alpha,
                   int train_variant, int logits_from_head, float* x_best_adv, float* x_best,
                   float* loss_best, uint8_t* acc, rvlm_stream_t stream);
+
+/* `rho` of APGDAttack for the following rvlm_apgd_run* calls on this handle (default 0.75; train/apgd_train.py has no
+ * such parameter).  Returns RVLM_ERR_ARG for NaN. */
+int rvlm_vit_set_apgd_rho(rvlm_vit* h, double rho);
 
 /* SURVEY.md section 8(b) `rvlm_vit_fwd_inputgrad`: ONE iteration's model work in one call - forward of x (+ delta,
  * may be NULL) with the activations kept, the bound FARE / TeCoA loss, and grad_x = d loss / d (x + delta)

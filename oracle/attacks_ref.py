@@ -126,8 +126,9 @@ class ApgdController:
     (same arithmetic as autopgd_base.py:402-446), Appendix A.3.  Host-side state machine over
     numpy arrays; mirrors what the device controller kernel does."""
 
-    def __init__(self, n_iter, loss0, step0):
+    def __init__(self, n_iter, loss0, step0, rho=0.75):
         self.n_iter = n_iter
+        self.rho = rho                                  # APGDAttack's thr_decr (autopgd_base.py:137,415-416)
         self.n_iter_2, self.n_iter_min, self.size_decr = apgd_schedule(n_iter)
         self.k = self.n_iter_2
         self.counter3 = 0
@@ -149,7 +150,7 @@ class ApgdController:
         self.counter3 += 1
         red = None
         if self.counter3 == self.k:
-            osc = check_oscillation_ref(self.loss_steps, i, self.k, 0.75)
+            osc = check_oscillation_ref(self.loss_steps, i, self.k, self.rho)
             no_impr = (F32(1.0) - self.reduced_last_check) * \
                 (self.loss_best_last_check >= self.loss_best).astype(F32)
             red = np.maximum(osc, no_impr)
@@ -309,7 +310,7 @@ class APGDAttackRef:
         grad_best = grad.copy()
         acc = (logits.max(1)[1] == y).numpy()
         alpha = 2.0 if self.alpha is None else self.alpha                         # :296-299
-        ctl = ApgdController(self.n_iter, loss_indiv, np.full((B,), F32(alpha * self.eps), F32))
+        ctl = ApgdController(self.n_iter, loss_indiv, np.full((B,), F32(alpha * self.eps), F32), rho=self.thr_decr)
         x_adv_old = x_adv.copy()
         for i in range(self.n_iter):
             a = 0.75 if i > 0 else 1.0

@@ -123,6 +123,10 @@ _SIGS = {
     "rvlm_apgd_controller": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p,
                                        C.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, c_stream]),
+    "rvlm_apgd_controller_rho": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, c_f32p,
+                                           C.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, c_stream]),
+    "rvlm_vit_set_apgd_rho": (C.c_int, [C.c_void_p, C.c_double]),
     "rvlm_apgd_select": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_size_t, C.c_int, c_stream]),
     "rvlm_linf_random_start": (C.c_int, [c_f32p, c_f32p, C.c_float, C.c_size_t, C.c_int, c_f32p,

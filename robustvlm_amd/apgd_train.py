@@ -21,8 +21,10 @@ def apgd_schedule(n_iter: int):
     return max(int(0.22 * n_iter), 1), max(int(0.06 * n_iter), 1), max(int(0.03 * n_iter), 1)
 
 
-def _apgd_linf_generic(model_call, loss_call, x, y, eps, n_iter, step0, train_variant, x_init=None, norm_kind=0):
-    """Shared host loop of apgd_train / APGDAttack.attack_single_run for arbitrary callables.
+def _apgd_linf_generic(model_call, loss_call, x, y, eps, n_iter, step0, train_variant, x_init=None, norm_kind=0,
+                       rho=0.75):
+    """Shared host loop of apgd_train / APGDAttack.attack_single_run for arbitrary callables.  ``rho``: the oscillation
+    threshold (APGDAttack's parameter, autopgd_base.py:111,137,415-416; apgd_train.py:117,334 hard-codes 0.75).
     Returns (x_best, acc(bool), loss_best, x_best_adv)."""
     lib = L.load()
     x = _f32c(x)
@@ -75,7 +77,7 @@ def _apgd_linf_generic(model_call, loss_call, x, y, eps, n_iter, step0, train_va
         counter3 += 1
         do_check = int(counter3 == k)
         with torch.cuda.device(dev):
-            L.check(lib.rvlm_apgd_controller(i, B, n_iter, k, do_check, loss_indiv.data_ptr(), pred.data_ptr(),
+            L.check(lib.rvlm_apgd_controller_rho(i, B, n_iter, k, do_check, float(rho), loss_indiv.data_ptr(), pred.data_ptr(),
                                              loss_steps.data_ptr(), loss_best.data_ptr(), loss_best_lc.data_ptr(),
                                              reduced_lc.data_ptr(), step.data_ptr(), acc.data_ptr(),
                                              f0.data_ptr(), f1.data_ptr(), f2.data_ptr(), st()))

@@ -47,8 +47,8 @@ class APGDAttack():
         self.logger = logger
         self.alpha = alpha
         self.n_iter_2, self.n_iter_min, self.size_decr = apgd_schedule(self.n_iter)
-        if norm != 'Linf' or is_tf_model or use_largereps or eot_iter != 1 or rho != .75:
-            raise NotImplementedError("native APGDAttack covers norm='Linf', eot_iter=1, rho=0.75, torch models")
+        if norm != 'Linf' or is_tf_model or use_largereps or eot_iter != 1:
+            raise NotImplementedError("native APGDAttack covers norm='Linf', eot_iter=1, torch models")
 
     def init_hyperparam(self, x):
         if self.device is None:
@@ -108,7 +108,8 @@ class APGDAttack():
                 parts.append(m.model.apgd_run(
                     x[lo:hi], None if start is None else start[lo:hi], self.loss, m.text_embedding, y[lo:hi], True,
                     self.eps, self.n_iter, step0, train_variant=False, logits_from_head=True,
-                    logit_scale=m.logit_scale_value, want_extra=True, y_target=None if yt is None else yt[lo:hi]))
+                    logit_scale=m.logit_scale_value, want_extra=True, y_target=None if yt is None else yt[lo:hi],
+                    rho=self.thr_decr))
             x_best_adv, x_best, loss_best, acc = (torch.cat([p[i] for p in parts]) for i in range(4))
             return x_best, acc.bool(), loss_best, x_best_adv
         if self.loss == 'ce':
@@ -117,7 +118,8 @@ class APGDAttack():
             crit = lambda lg, yy: _CeLogitsFn.apply(lg, yy, L.RED_NONE)   # noqa: E731
         else:
             crit = self.dlr_loss if self.loss == 'dlr' else self.dlr_loss_targeted
-        return _apgd_linf_generic(self.model, crit, x, y, self.eps, self.n_iter, step0, False, x_init=start)
+        return _apgd_linf_generic(self.model, crit, x, y, self.eps, self.n_iter, step0, False, x_init=start,
+                                  rho=self.thr_decr)
 
     # ---- shared pieces of the two perturb() flavours --------------------------------------------------------------
     def _setup(self, x, y):

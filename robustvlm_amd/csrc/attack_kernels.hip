@@ -266,7 +266,7 @@ apgd_linf_step_kernel(const float* __restrict__ x, float* __restrict__ x_adv,
     }
 }
 
-__global__ void apgd_controller_kernel(int i, int B, int n_iter, int k, int do_check,
+__global__ void apgd_controller_kernel(int i, int B, int n_iter, int k, int do_check, double rho,
                                        const float* __restrict__ loss_i,
                                        const uint8_t* __restrict__ pred, float* loss_steps,
                                        float* loss_best, float* loss_best_last_check,
@@ -294,7 +294,7 @@ __global__ void apgd_controller_kernel(int i, int B, int n_iter, int k, int do_c
                 float l1 = loss_steps[(size_t)r1 * B + b];
                 t += (l0 > l1) ? 1.0f : 0.0f;
             }
-            float thr = (float)((double)k * 0.75);
+            float thr = (float)((double)k * rho);               // `k * k3` in double, then * ones_like(t) (fp32)
             float osc = (t <= thr) ? 1.0f : 0.0f;
             float noimp = (1.0f - reduced_last_check[b]) *
                           ((loss_best_last_check[b] >= lb) ? 1.0f : 0.0f);   // :337-338
@@ -480,22 +480,34 @@ extern "C" int rvlm_apgd_l2_step(const float* x, float* x_adv, float* x_adv_old,
     return RVLM_OK;
 }
 
+extern "C" int rvlm_apgd_controller_rho(int i, int B, int n_iter, int k, int do_check, double rho,
+                                        const float* loss_i, const uint8_t* pred, float* loss_steps,
+                                        float* loss_best, float* loss_best_last_check,
+                                        float* reduced_last_check, float* step, uint8_t* acc,
+                                        uint8_t* f_notpred, uint8_t* f_improved, uint8_t* f_reduced,
+                                        rvlm_stream_t stream) {
+    RVLM_REQUIRE(loss_i && pred && loss_steps && loss_best && loss_best_last_check &&
+                     reduced_last_check && step && acc && f_notpred && f_improved && f_reduced,
+                 "rvlm_apgd_controller: null pointer");
+    RVLM_REQUIRE(i >= 0 && i < n_iter && k >= 1 && B > 0, "rvlm_apgd_controller: bad sizes");
+    RVLM_REQUIRE(rho == rho, "rvlm_apgd_controller: rho is NaN");
+    hipLaunchKernelGGL(apgd_controller_kernel, dim3(cdiv(B, 256)), dim3(256), 0,
+                       (hipStream_t)stream, i, B, n_iter, k, do_check, rho, loss_i, pred, loss_steps,
+                       loss_best, loss_best_last_check, reduced_last_check, step, acc, f_notpred,
+                       f_improved, f_reduced);
+    RVLM_CHECK_LAUNCH();
+    return RVLM_OK;
+}
+
 extern "C" int rvlm_apgd_controller(int i, int B, int n_iter, int k, int do_check,
                                     const float* loss_i, const uint8_t* pred, float* loss_steps,
                                     float* loss_best, float* loss_best_last_check,
                                     float* reduced_last_check, float* step, uint8_t* acc,
                                     uint8_t* f_notpred, uint8_t* f_improved, uint8_t* f_reduced,
                                     rvlm_stream_t stream) {
-    RVLM_REQUIRE(loss_i && pred && loss_steps && loss_best && loss_best_last_check &&
-                     reduced_last_check && step && acc && f_notpred && f_improved && f_reduced,
-                 "rvlm_apgd_controller: null pointer");
-    RVLM_REQUIRE(i >= 0 && i < n_iter && k >= 1 && B > 0, "rvlm_apgd_controller: bad sizes");
-    hipLaunchKernelGGL(apgd_controller_kernel, dim3(cdiv(B, 256)), dim3(256), 0,
-                       (hipStream_t)stream, i, B, n_iter, k, do_check, loss_i, pred, loss_steps,
-                       loss_best, loss_best_last_check, reduced_last_check, step, acc, f_notpred,
-                       f_improved, f_reduced);
-    RVLM_CHECK_LAUNCH();
-    return RVLM_OK;
+    return rvlm_apgd_controller_rho(i, B, n_iter, k, do_check, 0.75, loss_i, pred, loss_steps, loss_best,
+                                    loss_best_last_check, reduced_last_check, step, acc, f_notpred, f_improved,
+                                    f_reduced, stream);
 }
 
 extern "C" int rvlm_apgd_select(float* x_adv, float* grad, float* x_best, float* grad_best,

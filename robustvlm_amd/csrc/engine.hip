@@ -73,6 +73,7 @@ struct rvlm_vit {
     float *emb, *d_emb, *loss_ps, *loss_scalar, *loss_scratch;
     float *ap_loss_steps, *ap_loss_best, *ap_loss_best_lc, *ap_reduced_lc, *ap_step;
     uint8_t *ap_acc, *ap_pred, *ap_f0, *ap_f1, *ap_f2;
+    double ap_rho = 0.75;      // APGDAttack's oscillation threshold (rvlm_vit_set_apgd_rho)
     size_t loss_scratch_floats;
     // bookkeeping
     std::vector<void*> allocs;
@@ -1123,7 +1124,7 @@ extern "C" int rvlm_apgd_run_norm(rvlm_vit* h, const float* x, const float* x_in
         if ((rc = eval(need_grad))) return rc;
         counter3 += 1;
         const int do_check = counter3 == k;
-        if ((rc = rvlm_apgd_controller(i, B, n_iter, k, do_check, h->loss_ps, h->ap_pred, h->ap_loss_steps,
+        if ((rc = rvlm_apgd_controller_rho(i, B, n_iter, k, do_check, h->ap_rho, h->loss_ps, h->ap_pred, h->ap_loss_steps,
                                        h->ap_loss_best, h->ap_loss_best_lc, h->ap_reduced_lc, h->ap_step,
                                        h->ap_acc, h->ap_f0, h->ap_f1, h->ap_f2, s))) return rc;
         {
@@ -1136,6 +1137,12 @@ extern "C" int rvlm_apgd_run_norm(rvlm_vit* h, const float* x, const float* x_in
     if (x_best_out) RVLM_HIP(hipMemcpyAsync(x_best_out, x_best, n * 4, hipMemcpyDeviceToDevice, s));
     if (loss_best_out) RVLM_HIP(hipMemcpyAsync(loss_best_out, h->ap_loss_best, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
     if (acc_out) RVLM_HIP(hipMemcpyAsync(acc_out, h->ap_acc, (size_t)B, hipMemcpyDeviceToDevice, s));
+    return RVLM_OK;
+}
+
+extern "C" int rvlm_vit_set_apgd_rho(rvlm_vit* h, double rho) {
+    RVLM_REQUIRE(h && rho == rho, "rvlm_vit_set_apgd_rho: null handle or NaN");
+    h->ap_rho = rho;
     return RVLM_OK;
 }
 

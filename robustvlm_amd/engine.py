@@ -40,6 +40,7 @@ class VitEngine:
             self.device = torch.device(f"cuda:{torch.cuda.current_device()}")
         self.mean, self.std = tuple(float(v) for v in mean), tuple(float(v) for v in std)
         self.generation = 0
+        self._apgd_rho = 0.75
         self._h = C.c_void_p()
         c = L.VitConfigC()
         c.image_size, c.patch, c.width, c.layers = cfg.image_size, cfg.patch, cfg.width, cfg.layers
@@ -239,9 +240,11 @@ class VitEngine:
         return out, flags, trace
 
     def apgd_run(self, x, x_init, loss_kind, ref, targets, output_normalize, eps, n_iter, step0,
-                 train_variant, logits_from_head, logit_scale=100.0, want_extra=False, y_target=None, norm_kind=0):
+                 train_variant, logits_from_head, logit_scale=100.0, want_extra=False, y_target=None, norm_kind=0,
+                 rho=0.75):
         """Whole APGD Linf loop on the device (rvlm_apgd_run).  loss_kind: 'l2' | 'ce' | 'dlr' | 'dlr-targeted'
-        (the DLR losses of AutoAttack need logits_from_head; 'dlr-targeted' needs y_target [B] int64)."""
+        (the DLR losses of AutoAttack need logits_from_head; 'dlr-targeted' needs y_target [B] int64).  ``rho``:
+        APGDAttack's oscillation threshold (rvlm_vit_set_apgd_rho)."""
         self._check_images(x)
         x = _f32c(x)
         xi = _f32c(x_init) if x_init is not None else None
@@ -256,6 +259,9 @@ class VitEngine:
         x_best = torch.empty_like(x) if want_extra else None
         loss_best = torch.empty(B, dtype=torch.float32, device=x.device) if want_extra else None
         acc = torch.empty(B, dtype=torch.uint8, device=x.device) if want_extra else None
+        if float(rho) != self._apgd_rho:
+            L.check(self.lib.rvlm_vit_set_apgd_rho(self._h, float(rho)), "rvlm_vit_set_apgd_rho")
+            self._apgd_rho = float(rho)
         with torch.cuda.device(x.device):
             L.check(self.lib.rvlm_apgd_run_norm(self._h, x.data_ptr(), L.ptr(xi), B, C.byref(ls), int(norm_kind),
                                                 float(eps), int(n_iter), float(step0), int(bool(train_variant)),

@@ -242,6 +242,20 @@ def g4_autopgd():
              first_start=seen[1].numpy(),       # seen[0] = clean pass, seen[1] = clamped random start
              n_model_calls=np.int64(len(seen)), weights_seed=np.int64(3),
              weights_sha256=np.array(weights_digest(w)))
+    # `rho` (the oscillation threshold, autopgd_base.py:111,137,415-416) away from its default: more iterations so that
+    # several checkpoints fall inside the run, two thresholds on either side of 0.75, and a radius at which the losses
+    # do oscillate (at 4/255 they rise monotonically and rho changes nothing; at 0.15: 38 % / 8 % of the pixels of the
+    # result differ from the rho = 0.75 run)
+    eps_rho = 0.15
+    for rho in (0.5, 0.9):
+        seen.clear()
+        atk = RefAPGDAttack(predict, n_iter=30, norm="Linf", n_restarts=1, eps=eps_rho, seed=0, loss="ce",
+                            device="cpu", rho=rho, use_rs=True)
+        adv = atk.perturb(x.clone(), y.clone())
+        save(f"autopgd_tiny_rho{int(rho * 100):03d}.npz", x=x.numpy(), y=y.numpy(), T=T.numpy(),
+             adv=adv.detach().numpy(), eps=np.float64(eps_rho), n_iter=np.int64(30), rho=np.float64(rho),
+             first_start=seen[1].numpy(), n_model_calls=np.int64(len(seen)), weights_seed=np.int64(3),
+             weights_sha256=np.array(weights_digest(w)))
 
 
 # ------------------------------------------------------------------ G5: ViT vs HF transformers

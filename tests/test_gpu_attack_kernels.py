@@ -405,3 +405,67 @@ def test_standalone_attack_utils_vs_torch():
         R.normalize_grad(u, "l1")
     with pytest.raises(L.RvlmError):
         R.project_perturbation(u.cpu(), eps, "linf")
+
+
+# ------------------------------------------------------------------ round 4: APGDAttack's `rho`
+@pytest.mark.parametrize("rho", [0.3, 0.5, 0.75, 0.9])
+def test_apgd_controller_rho_vs_oracle(rho):
+    """rvlm_apgd_controller_rho against the numpy controller (oracle/attacks_ref.py::ApgdController, whose rho path is
+    pinned by tests/golden/autopgd_tiny_rho*.npz): oscillation threshold `k * rho` evaluated like check_oscillation
+    (autopgd_base.py:170-175); per-sample step sizes, bests and reduce flags bit for bit over 50 iterations."""
+    from oracle.attacks_ref import ApgdController, apgd_schedule
+    l = lib()
+    rng = np.random.default_rng(7)
+    B, n_iter, npix = 96, 50, 8
+    loss0 = rng.random(B, dtype=F32)
+    ctl = ApgdController(n_iter, loss0, np.full(B, F32(0.03), F32), rho=rho)
+    d = dict(loss_steps=torch.zeros(n_iter, B, device=dev()), loss_best=_cu(loss0), loss_best_lc=_cu(loss0),
+             reduced_lc=torch.ones(B, device=dev()), step=torch.full((B,), 0.03, device=dev()),
+             acc=torch.ones(B, dtype=torch.uint8, device=dev()))
+    for f in ("f0", "f1", "f2"):
+        d[f] = torch.zeros(B, dtype=torch.uint8, device=dev())
+    pred = torch.ones(B, dtype=torch.uint8, device=dev())
+    xa = rng.random((B, npix), dtype=F32); g = xa.copy(); xb = xa.copy(); gb = xa.copy()
+    loss = loss0.copy()
+    k, n_iter_min, size_decr = apgd_schedule(n_iter)
+    counter3, n_red = 0, 0
+    for i in range(n_iter):
+        # noisy, slowly rising losses: the count of increases over a window lands on both sides of k * rho
+        loss = (loss + rng.standard_normal(B).astype(F32) * F32(0.2) + F32(0.03)).astype(F32)
+        counter3 += 1
+        do_check = int(counter3 == k)
+        red = ctl.update(i, loss, xa, g, xb, gb)
+        L.check(l.rvlm_apgd_controller_rho(i, B, n_iter, k, do_check, float(rho), _cu(loss).data_ptr(), pred.data_ptr(),
+                                           d["loss_steps"].data_ptr(), d["loss_best"].data_ptr(),
+                                           d["loss_best_lc"].data_ptr(), d["reduced_lc"].data_ptr(),
+                                           d["step"].data_ptr(), d["acc"].data_ptr(), d["f0"].data_ptr(),
+                                           d["f1"].data_ptr(), d["f2"].data_ptr(), st()))
+        torch.cuda.synchronize()
+        if do_check:
+            counter3 = 0
+            k = max(k - size_decr, n_iter_min)
+            n_red += int(d["f2"].sum())
+        assert k == ctl.k
+        for name, want in (("step", ctl.step), ("loss_best", ctl.loss_best), ("reduced_lc", ctl.reduced_last_check),
+                           ("loss_best_lc", ctl.loss_best_last_check)):
+            assert np.array_equal(d[name].cpu().numpy(), want), (i, name)
+    assert n_red > 0
+
+
+@pytest.mark.parametrize("tag", ["rho050", "rho090"])
+def test_apgdattack_rho_vs_reference_golden(tag):
+    """APGDAttack(rho != .75) through the fused device loop (rvlm_vit_set_apgd_rho) against the reference's own result."""
+    from oracle import vit_ref as V
+    from tests.test_gpu_engine import make_engine
+    z = load_golden(f"autopgd_tiny_{tag}.npz")
+    cfg = V.VIT_TINY
+    w = V.init_weights(cfg, seed=int(z["weights_seed"]))
+    eng = make_engine(cfg, w, "fp32")
+    clf = R.ClassificationModel(eng, torch.from_numpy(z["T"]).to(dev())).eval()
+    x, y = torch.from_numpy(z["x"]).to(dev()), torch.from_numpy(z["y"]).to(dev())
+    kw = dict(n_iter=int(z["n_iter"]), norm="Linf", n_restarts=1, eps=float(z["eps"]), seed=0, loss="ce", use_rs=True)
+    adv = R.APGDAttack(clf, rho=float(z["rho"]), **kw).perturb(x, y).cpu().numpy()
+    other = R.APGDAttack(clf, rho=0.75, **kw).perturb(x, y).cpu().numpy()
+    same, same_other = np.mean(adv == z["adv"]), np.mean(other == z["adv"])
+    assert same > 0.85 and same > same_other + 0.03, (same, same_other)
+    eng.close()

@@ -149,6 +149,21 @@ def test_autopgd_bit_exact(r):
     assert np.array_equal(adv.numpy()[0], z["x"][0])
 
 
+@pytest.mark.parametrize("tag", ["rho050", "rho090"])
+def test_autopgd_rho_bit_exact(tag):
+    """APGDAttack's `rho` (oscillation threshold, autopgd_base.py:111,137,415-416) away from 0.75, at a radius where
+    it changes the result."""
+    z = load_golden(f"autopgd_tiny_{tag}.npz")
+    cfg = V.VIT_TINY
+    w = V.init_weights(cfg, seed=int(z["weights_seed"]))
+    clf = V.ClassificationModelRef(cfg, w, torch.from_numpy(z["T"]), 100.0).eval()
+    kw = dict(n_iter=int(z["n_iter"]), norm="Linf", n_restarts=1, eps=float(z["eps"]), seed=0, loss="ce", use_rs=True)
+    adv = A.APGDAttackRef(clf, rho=float(z["rho"]), **kw).perturb(torch.from_numpy(z["x"]), torch.from_numpy(z["y"]))
+    assert np.array_equal(adv.numpy(), z["adv"])
+    other = A.APGDAttackRef(clf, rho=0.75, **kw).perturb(torch.from_numpy(z["x"]), torch.from_numpy(z["y"]))
+    assert not np.array_equal(other.numpy(), z["adv"])          # the parameter matters on this input
+
+
 # ------------------------------------------------------------------ section 8(f) rank 3: AutoAttack orchestration
 def test_dlr_losses_bit_exact():
     z = load_golden("dlr_losses.npz")
