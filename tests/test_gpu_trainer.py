@@ -143,8 +143,9 @@ def test_train_step_fp32_matches_oracle():
             # noise to Adam (which normalises it to +-lr steps) - compare the q and v thirds only
             got = torch.cat([got[:W], got[2 * W:]]); want = torch.cat([want[:W], want[2 * W:]])
         r = rel_max(got, want)
-        # Adam normalises the step: elements whose gradient is rounding noise move by +-lr either way
-        assert r < 1e-2, f"{k}: {r}"
+        # Adam normalises the step: elements whose gradient is rounding noise move by +-lr either way (three steps at
+        # the base LR since round 4: the reference's first step is not a warm-up step)
+        assert r < 2e-2, f"{k}: {r}"
     tr.engine.close(); tr.engine_orig.close()
 
 
@@ -460,5 +461,5 @@ def test_train_step_vs_reference_train_one_epoch(name):
                 got, want = sd[k].cpu(), torch.from_numpy(z[f"{name}::w{s + 1}::{k}"])
                 if k.endswith("attn.in_proj_bias"):        # key bias: true gradient 0, Adam steps on rounding noise
                     got = torch.cat([got[:W], got[2 * W:]]); want = torch.cat([want[:W], want[2 * W:]])
-                assert rel_max(got, want) < 1e-2, (s, k, rel_max(got, want))
+                assert rel_max(got, want) < 2e-2, (s, k, rel_max(got, want))
     tr.close()
