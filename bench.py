@@ -79,7 +79,7 @@ def host_cpu_info():
 def cpu_baseline(iterations_full=10, l14_sample=True):
     """The reference path's CPU restatement (oracle/, parity-pinned against the imported reference) on this host's
     cores, as BASELINE.md section 4 specifies: config 1 = FARE PGD 10-step eps=4/255 on ViT-B/32, batch 8, fp32,
-    torch.rand images (seed 0), delta0 ~ U(-eps, eps) (seed 1); >= 3 warm-ups, median of >= 5 full pgd_ref calls.
+    torch.rand images (seed 0), delta0 ~ U(-eps, eps) (seed 1); 3 warm-ups, median of 10 full pgd_ref calls.
     Thread count: the fastest of {physical cores, 32, 16} in a one-call probe (the 400-row matmuls of this batch do
     not scale to 128 threads); `cores` is the count actually used.  A bounded ViT-L/14 sample (the GPU workload's
     model) is reported next to it."""
@@ -118,11 +118,12 @@ def cpu_baseline(iterations_full=10, l14_sample=True):
     torch.set_num_threads(cores)
     for _ in range(3):
         call(pb, iterations_full)
-    times = sorted(call(pb, iterations_full) for _ in range(5))
-    med = times[len(times) // 2]
+    N_CALLS = 10                                     # BASELINE.md section 4 / SURVEY.md 8(d): median of >= 10
+    times = sorted(call(pb, iterations_full) for _ in range(N_CALLS))
+    med = 0.5 * (times[(N_CALLS - 1) // 2] + times[N_CALLS // 2])
     out = {"value": B1 / med, "unit": "adversarial images/sec", "cores": cores, "kind": "port",
            "sample": f"BASELINE config 1: oracle pgd_ref (torch {torch.__version__} CPU fp32), FARE PGD {iterations_full}-step "
-                     f"eps=4/255, ViT-B/32, batch {B1}; 3 warm-ups, median of 5 full calls ({med:.2f} s, min {times[0]:.2f}, "
+                     f"eps=4/255, ViT-B/32, batch {B1}; 3 warm-ups, median of {N_CALLS} full calls ({med:.2f} s, min {times[0]:.2f}, "
                      f"max {times[-1]:.2f}); {cores} threads = fastest of a probe over "
                      f"{ {k: round(v, 2) for k, v in probe.items()} } (s per 2 iterations)",
            "cpu_model": cpu_model, "physical_cores": physical, "hardware_threads": threads}
@@ -198,7 +199,7 @@ def bench_train(args, R, cfg, sd, dev, dist, world, rank):
 
 class ClockSampler:
     """Shader clock / socket power of one GPU while the timed region runs: `rocm-smi --showclocks --showpower` polled from
-    a thread (~10 Hz; each call costs the HOST ~60 ms, nothing on the GPU).  The 2.5 PFLOP/s peak assumes 2.4 GHz; under the
+    a thread (~10 Hz; each call costs the HOST ~60 ms, nothing on the GPU) - run over extra, untimed calls of the workload.  The 2.5 PFLOP/s peak assumes 2.4 GHz; under the
     ~1.4 kW socket cap a dense MFMA loop holds 1.7-1.9 GHz, so `roofline.frac` is also reported against
     the peak at the clock the chip actually held."""
 
@@ -238,7 +239,8 @@ class ClockSampler:
             return None
         return {"sclk_mhz_mean": sum(cs) / len(cs), "sclk_mhz_min": min(cs), "sclk_mhz_max": max(cs), "samples": len(cs),
                 "socket_power_w_mean": (sum(ps) / len(ps)) if ps else None,
-                "source": "rocm-smi --showclocks --showpower polled during the timed region"}
+                "source": "rocm-smi --showclocks --showpower polled during up to 3 extra pgd() calls AFTER the timed region "
+                          "(the timed region itself runs without a poller)"}
 
 
 def bind_rank_to_numa(local_rank: int, local_world: int):
@@ -351,16 +353,24 @@ def main():
     for _ in range(args.warmup):
         out = step()
     barrier()
-    sampler = ClockSampler(local_rank) if rank == 0 and not args.no_roofline else None
-    if sampler is not None:
-        sampler.__enter__()
+    # the timed region: exactly --steps calls between two barrier + synchronize pairs, nothing else running in this process
+    # (the rocm-smi clock sampler of round 3 now polls during extra UNTIMED steps below).  Device-side events between the
+    # calls give the per-call distribution (median of the K calls) without a host sync.
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         out = step()
+        marks[i + 1].record()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    if sampler is not None:
-        sampler.__exit__()
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    sampler = None
+    if rank == 0 and not args.no_roofline:
+        with ClockSampler(local_rank) as sampler:
+            for _ in range(min(args.steps, 3)):
+                step()
+            torch.cuda.synchronize()
     per_rank_s = [el]
     if dist is not None:
         t = torch.tensor([el], device=dev, dtype=torch.float64)
@@ -381,6 +391,11 @@ def main():
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            # `value` = all K calls / the bracketed wall time (the contract's definition = mean); the median call of the
+            # same K, from device events on this rank's stream, next to it (median of >= 10 timed calls)
+            "ms_per_step_median": 0.5 * (step_ms[(len(step_ms) - 1) // 2] + step_ms[len(step_ms) // 2]),
+            "ms_per_step_min": step_ms[0], "ms_per_step_max": step_ms[-1],
+            "value_median_call": B * 1e3 / (0.5 * (step_ms[(len(step_ms) - 1) // 2] + step_ms[len(step_ms) // 2])) * world,
             "config": {"workload": (f"{'FARE' if args.attack == 'pgd' else 'TeCoA-CE'} {args.attack.upper()} {args.iterations}-step eps=4/255 on {args.model} "
                                     f"{args.precision}, batch={B} per GPU, 224x224x3 synthetic, seeded random-init weights "
                                     f"({_baseline_config_name(args.attack, world, B)})")
