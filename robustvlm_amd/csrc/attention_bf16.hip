@@ -268,16 +268,6 @@ attn_fwd_odd_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict_
     const bf16_t* base = qkv + (long)b * lay.qkv_b + (long)h * lay.qkv_h;   // (W = element offset from Q to K, K to V)
     stage_tile(Kt, base + W, ld, S, Sp, w, NK, lane);
     stage_tile(Vt, base + 2 * W, ld, S, Sp, w, NK, lane);
-    // this wave's 32 query rows and the odd query's row are requested UNDER the staging (round 4): issued behind the
-    // barrier they put a second HBM round trip on every workgroup's critical path (same-box A/B: 72.0 -> 69.3 us).
-    // (A PERSISTENT form - <= 512 workgroups walking the heads - measured 79.5 us: the two workgroups of a CU then run in
-    // lockstep and stage at the same time; with one workgroup per head the dispatcher keeps them out of phase.)
-    bf16x8 qf_own[4], qf_odd[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-        qf_own[kk] = frag_global(base, ld, w * 32 + (lane & 31), kk, lane);
-        qf_odd[kk] = frag_global(base, ld, S - 1, kk, lane);
-    }
     __syncthreads();
 
     const FragOffs fo = make_offs(lane);
@@ -343,7 +333,9 @@ attn_fwd_odd_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict_
 
     {   // ---- this wave's 32 queries ----
         const int q = w * 32 + l31;
-        const bf16x8 (&qf)[4] = qf_own;
+        bf16x8 qf[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) qf[kk] = frag_global(base, ld, q, kk, lane);
         f32x16 oacc[2] = {zero16(), zero16()};
         float m = -INFINITY, l = 0.0f;
 #pragma unroll 1
@@ -380,7 +372,9 @@ attn_fwd_odd_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict_
     {   // ---- the odd query against key tile w, in the TRANSPOSED orientation: S = q K^T has the keys on the lanes and the
         // (identical) query rows on the registers, so the softmax costs one exp per lane instead of sixteen; p goes
         // through 64 B of LDS into the B-operand layout of the P.V product ----
-        const bf16x8 (&qf)[4] = qf_odd;
+        bf16x8 qf[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) qf[kk] = frag_global(base, ld, S - 1, kk, lane);
         f32x16 st = zero16();
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) st = MFMA(qf[kk], frag_rm(Kt, w * 32, fo.rm[kk]), st);
