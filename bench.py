@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--mode", default="attack", choices=["attack", "train"],
                     help="attack (default, the BASELINE metric): one pgd()/apgd call per step; train: one full "
                          "FARE/TeCoA optimizer step per step (e0 + attack + fwd + wgrad backward + grad all-reduce + AdamW)")
+    ap.add_argument("--always-reduce", action="store_true",
+                    help="train mode on ONE GPU: run the bucketed RCCL all-reduce path in a one-rank group (identity reduction) "
+                         "so that its launch / wait structure and the `allreduce` diagnostics can be exercised without a node")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -141,6 +144,26 @@ def cpu_baseline(iterations_full=10, l14_sample=True):
     return out
 
 
+PEAK_HBM_TBPS = 8.0         # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md (6.3 TB/s achievable)
+
+
+def hbm_classes(prof: dict, cfg, B: int) -> dict:
+    """Roofline objects of the HBM-bound kernel classes of one profiled pgd() call."""
+    S = (cfg.image_size // cfg.patch) ** 2 + 1
+    per_launch = {"attn_fwd": 4.0 * B * cfg.heads * S * 64 * 2, "attn_bwd": 8.0 * B * cfg.heads * S * 64 * 2}
+    out = {}
+    for k in ("attn_fwd", "attn_bwd", "layernorm_fwd", "layernorm_bwd"):
+        v = prof.get(k)
+        if not v or v["ms"] <= 0 or not v["launches"]:
+            continue
+        nbytes = per_launch[k] * v["launches"] if k in per_launch else v["bytes"]
+        tbps = nbytes / (v["ms"] * 1e-3) / 1e12
+        out[k] = {"bound": "hbm", "achieved": tbps, "peak": PEAK_HBM_TBPS, "unit": "TB/s", "frac": tbps / PEAK_HBM_TBPS,
+                  "bytes_per_launch": nbytes / v["launches"], "avg_launch_us": 1e3 * v["ms"] / v["launches"],
+                  "launches": v["launches"], "ms_per_step": round(v["ms"], 3)}
+    return out
+
+
 def _baseline_config_name(attack: str, world: int, per_gpu_batch: int) -> str:
     """Which BASELINE.json `configs` entry a run is: [1] one GPU, [3] = the same 128 images per GPU on 8 GPUs
     (global batch 1024); 2 / 4 GPUs are the intermediate points of the 1/2/4/8 curve of that same per-GPU workload."""
@@ -160,7 +183,7 @@ def bench_train(args, R, cfg, sd, dev, dist, world, rank):
     from robustvlm_amd.trainer import AdversarialTrainer
     B = args.batch
     tr = AdversarialTrainer(cfg, sd, batch_size=B, precision=args.precision, attack=args.attack if args.attack != "autopgd" else "pgd",
-                            iterations_adv=args.iterations, device=dev)
+                            iterations_adv=args.iterations, device=dev, always_reduce=args.always_reduce)
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
     x = torch.rand(B, 3, cfg.image_size, cfg.image_size, generator=g, device=dev)
 
@@ -181,8 +204,11 @@ def bench_train(args, R, cfg, sd, dev, dist, world, rank):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     barrier()
+    # with more than one rank (or --always-reduce on one): per-bucket all-reduce times and how much of them the backward hid
+    ar = tr.profile_allreduce(x) if tr._reduce else None
     if rank == 0:
         print(json.dumps({
+            "allreduce": ar,
             "metric": f"FARE training images/sec ({args.model}, {args.iterations}-step {args.attack} + optimizer step)",
             "value": world * B * args.steps / el, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak",
@@ -289,9 +315,14 @@ def main():
     dev = torch.device(f"cuda:{local_rank}")
     affinity = bind_rank_to_numa(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     dist = None
-    if world > 1:
+    if world > 1 or (args.mode == "train" and args.always_reduce):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            import socket
+            with socket.socket() as sk:                      # one-rank group (--always-reduce): any free local port
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import robustvlm_amd as R
@@ -461,21 +492,29 @@ def main():
         # read from inside this process); the committed measurement of this same command is reported.
         traffic, traffic_src, pmc = None, None, None
         headline = args.model == "ViT-L-14" and args.batch == 128 and args.precision == "bf16" and args.attack == "pgd"
-        for tag in ("r03", "r02"):
+        for tag in ("r04", "r03", "r02"):
             tj = os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_traffic.json")
             if traffic is None and os.path.exists(tj) and headline:
                 try:
-                    traffic = json.load(open(tj))["gemm_bytes_per_logical_launch"]
-                    traffic_src = f"profiles/{tag}_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+                    tjd = json.load(open(tj))
+                    traffic = tjd["gemm_bytes_per_logical_launch"]
+                    traffic_src = {"measured_in_run": False, "file": f"profiles/{tag}_pmc_hbm_traffic.json",
+                                   "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command "
+                                          "(scripts/pmc_traffic.sh) on another box of the pool, committed with the round's "
+                                          "profiles; PMC counters cannot be read from inside this process",
+                                   "collected_at_commit": tjd.get("collected_at_commit", f"round {tag[1:]} tree"),
+                                   "dram_vs_infinity_cache": tjd.get("dram_vs_infinity_cache")}
                 except Exception:
                     traffic = None
         # matrix-pipe utilisation INSIDE this pipeline (not of a cube): rocprofv3 --pmc passes over this same command,
         # summarised per kernel by scripts/pmc_pipeline.sh (counters cannot be read from inside this process either)
-        pj = os.path.join(ROOT, "profiles", "r03_pmc_pipeline.json")
-        if os.path.exists(pj) and headline:
+        pj = next((q for q in (os.path.join(ROOT, "profiles", f"{t}_pmc_pipeline.json") for t in ("r04", "r03")) if os.path.exists(q)), "")
+        if pj and headline:
             try:
                 kd = json.load(open(pj))["kernels"]
-                pmc = {"source": "profiles/r03_pmc_pipeline.json (scripts/pmc_pipeline.sh: rocprofv3 --pmc passes over bench.py --steps 1)",
+                pmc = {"measured_in_run": False,
+                       "source": f"profiles/{os.path.basename(pj)} (scripts/pmc_pipeline.sh: rocprofv3 --pmc passes over bench.py --steps 1, "
+                                 "another box of the pool, committed with that round's profiles)",
                        "mfma_busy": {k: v.get("mfma_busy") for k, v in kd.items() if v.get("mfma_busy") is not None},
                        "lds_conflict_share": {k: v.get("lds_conflict_share") for k, v in kd.items()
                                               if v.get("lds_conflict_share") is not None}}
@@ -493,6 +532,10 @@ def main():
             "attention_gemm_subset": {
                 "tflops": sum(v["flops"] for v in attn_gemm.values()) / max(sum(v["ms"] for v in attn_gemm.values()), 1e-9) / 1e9,
                 "frac": sum(v["flops"] for v in attn_gemm.values()) / max(sum(v["ms"] for v in attn_gemm.values()), 1e-9) / 1e9 / PEAK_BF16_TFLOPS},
+            # the HBM-bound quarter of the step against ITS roofline: algorithmic bytes / HIP-event time / 8 TB/s
+            # (attention: q, k, v in + o out forward; q, k, v, o, dO in + dq, dk, dv out backward, bf16; LayerNorm: the
+            # byte counts the engine's profile scopes carry - 6 B per element forward, 16 B backward)
+            "hbm_classes": hbm_classes(prof, cfg, B),
             "per_class": {k: {"ms": round(v["ms"], 3), "launches": v["launches"],
                               "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 and v["flops"] > 0 else None,
                               "gbps": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 and v["bytes"] > 0 else None}

@@ -27,9 +27,9 @@
 //     bit-identical to gemm_bf16_nt_256p_kernel.
 //
 // Requirements (else the dispatcher keeps 256p): N % 256 == 0, K % 128 == 0, K >= 512, no batched form.
-#include "kernels.h"
-#include "gemm_persist.h"
-#include "gemm_strip.h"
+#include "../kernels.h"
+#include "../gemm_persist.h"
+#include "../gemm_strip.h"
 #include <type_traits>
 
 namespace rvlm {

@@ -225,7 +225,18 @@ static int gemm_pingpong_kmax() {
     if (g_pingpong_kmax < 0) { const char* e = getenv("RVLM_GEMM_PINGPONG_KMAX"); g_pingpong_kmax = e ? atoi(e) : RVLM_PINGPONG_DEFAULT_KMAX; }
     return g_pingpong_kmax;
 }
-void gemm_set_pingpong(int mask, int kmax) { g_pingpong_mask = mask; g_pingpong_kmax = kmax; }
+// mask < 0: back to the environment / default for BOTH values (whatever kmax says)
+void gemm_set_pingpong(int mask, int kmax) {
+    if (mask < 0) { g_pingpong_mask = -1; g_pingpong_kmax = -1; }
+    else { g_pingpong_mask = mask; g_pingpong_kmax = kmax; }
+}
+bool gemm_has_pingpong() {
+#ifdef RVLM_EXPERIMENTAL_GEMM
+    return true;
+#else
+    return false;
+#endif
+}
 static int gemm_variant() {
     if (g_gemm_variant < 0) {
         const char* e = getenv("RVLM_GEMM_VARIANT");
@@ -380,13 +391,16 @@ int gemm_bf16_nt(const GemmBf16& p, hipStream_t s) {
 #endif
         {
             rc = RVLM_OK;
-            // the phase-shifted (ping-pong) form of the persistent kernel, per epilogue kind (bit e of the mask) and up
-            // to a K limit: it hides the fused epilogue under the other wave group's MFMAs, which pays where the
-            // epilogue is a large share of the tile (K = 1024 shapes, fp32 / activation epilogues)
-            if (((gemm_pingpong_mask() >> p.epi) & 1) && p.K <= gemm_pingpong_kmax()) {
+#ifdef RVLM_EXPERIMENTAL_GEMM
+            // the phase-shifted (ping-pong) form of the persistent kernel (experimental/gemm_bf16_256x.hip: bit-identical,
+            // 3-15 % slower, round 3), per epilogue kind (bit e of the mask, e = the kind the kernel will RUN: fp32 +
+            // residual without a residual is the plain fp32 kind) and up to a K limit
+            const int epi_run = (p.epi == EPI_F32_RESID && !p.residual) ? (int)EPI_F32 : (int)p.epi;
+            if (((gemm_pingpong_mask() >> epi_run) & 1) && p.K <= gemm_pingpong_kmax()) {
                 rc = gemm_bf16_nt_256x(p, &done, s);
                 if (done) g_last_kernels |= RVLM_GEMM_K_PINGPONG | (done > (p.M / 256) * 256 ? RVLM_GEMM_K_STRIP : 0);
             }
+#endif
             if (!rc && !done) {
                 rc = gemm_bf16_nt_256p(p, &done, s);
                 if (done) g_last_kernels |= RVLM_GEMM_K_PERSISTENT | (done > (p.M / 256) * 256 ? RVLM_GEMM_K_STRIP : 0);

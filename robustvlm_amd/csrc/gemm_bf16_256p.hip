@@ -31,6 +31,15 @@
 
 namespace rvlm {
 
+// Knobs that were measured neutral or worse (start stagger, K rotation, static wave priority: DESIGN.md section 3, rounds 2-3)
+// and the ablation instantiations exist in `make EXPERIMENTAL=1` builds only; in the shipped library they are
+// compile-time off - no kernel argument, branch or environment switch of theirs is live.
+#ifdef RVLM_EXPERIMENTAL_GEMM
+constexpr bool P_KNOBS = true;
+#else
+constexpr bool P_KNOBS = false;
+#endif
+
 template <int EPI, int ACT, int ABL>
 __global__ void __launch_bounds__(512)
 gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
@@ -67,7 +76,7 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
     // phase offset (performance only, RVLM_GEMM_STAGGER, default off): with every workgroup in lockstep the epilogues' HBM
     // bursts coincide chip-wide.  It gained 3 % on the fc2 dgrad under the lockstep schedule and costs it 4 % under the
     // split-role one; neutral to slightly negative for the other epilogues (profiles/r02_gemm_knobs_split.log)
-    if ((p.stagger & 255) > 0) {
+    if (P_KNOBS && (p.stagger & 255) > 0) {
         const int phase = (blockIdx.x >> 3) & ((p.stagger >> 8) & 255);   // phases per XCD (blockIdx & 7 = XCD): mask in the high bits
         for (int i = 0; i < (p.stagger & 255) * phase; ++i) __builtin_amdgcn_s_sleep(127);
     }
@@ -90,7 +99,7 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
     }
     const int l31 = lane & 31, hi = lane >> 5;
     // experiment (MI355X_MICROARCH.md, two waves per SIMD, item 4): static priority for the second-dispatched half
-    if (p.wave_prio > 0 && w >= 4) __builtin_amdgcn_s_setprio(1);
+    if (P_KNOBS && p.wave_prio > 0 && w >= 4) __builtin_amdgcn_s_setprio(1);
     const int lda = (int)p.lda, ldb = (int)p.ldb, ldo = (int)p.ldo;   // byte offsets fit 31 bits (host check)
 
     // buffer descriptors (wave-uniform, built from kernel arguments only): every global access below is
@@ -121,7 +130,8 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
     // experiment (RVLM_GEMM_KROT): the workgroups of an XCD walk K from different start offsets, so that at any moment
     // their operand requests fall on different k-columns of the panels they share (the sum order of a tile rotates with it)
     int k0 = 0;
-    if (p.krot > 0) k0 = (((int)blockIdx.x >> 3) % p.krot) * (nk >= p.krot ? nk / p.krot : 1) % nk;
+    if (!P_KNOBS) k0 = 0;
+    else if (p.krot > 0) k0 = (((int)blockIdx.x >> 3) % p.krot) * (nk >= p.krot ? nk / p.krot : 1) % nk;
     else if (p.krot < 0) k0 = (((int)blockIdx.x >> 3) % (-p.krot)) % nk;
     k0 = __builtin_amdgcn_readfirstlane(k0);
     const int ntw = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // tiles of this workgroup
@@ -676,7 +686,9 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
 }
 
 int g_persist_ablate = 0;
-void gemm_set_ablate(int v) { g_persist_ablate = v; }
+// (shipped library: the ablation kernels are not instantiated - any value other than 0 is ignored)
+void gemm_set_ablate(int v) { g_persist_ablate = P_KNOBS ? v : 0; }
+bool gemm_has_ablate() { return P_KNOBS; }
 unsigned long long* g_persist_trace = nullptr;   // [256 workgroups][8 tiles][4 stamps] or null
 void gemm_set_trace(unsigned long long* ptr) { g_persist_trace = ptr; }
 
@@ -699,6 +711,7 @@ static int launch_256p_abl(const GemmBf16& p, int tiles_m, int tiles_n, int m_to
 }
 template <int EPI, int ACT>
 static int launch_256p_act(const GemmBf16& p, int tiles_m, int tiles_n, int m_total, hipStream_t s) {
+#ifdef RVLM_EXPERIMENTAL_GEMM
     if constexpr (EPI == EPI_BF16) {   // the timing experiments exist for the plain epilogue only
         switch (g_persist_ablate) {
             case 1: return launch_256p_abl<EPI, ACT, 1>(p, tiles_m, tiles_n, m_total, s);
@@ -722,10 +735,14 @@ static int launch_256p_act(const GemmBf16& p, int tiles_m, int tiles_n, int m_to
             default: break;
         }
     }
-    if constexpr (EPI == EPI_F32_RESID) {   // evidence for DESIGN.md: the fp32 + residual epilogue with the MFMAs removed
+#endif
+    if constexpr (EPI == EPI_F32_RESID) {
+#ifdef RVLM_EXPERIMENTAL_GEMM           // evidence for DESIGN.md: the fp32 + residual epilogue with the MFMAs removed
         if (g_persist_ablate == 2) return launch_256p_abl<EPI, ACT, 2>(p, tiles_m, tiles_n, m_total, s);
-        static int nt_k = -1;               // fp32 output stored nt from this K on (RVLM_GEMM_NT_K, 0 = never)
-        if (nt_k < 0) { const char* e = getenv("RVLM_GEMM_NT_K"); nt_k = e ? atoi(e) : 2048; }
+#endif
+        // fp32 output stored nt from K = 2048 on (profiles/r03_ab_nt_threshold.log; EXPERIMENTAL builds: RVLM_GEMM_NT_K, 0 = never)
+        static int nt_k = -1;
+        if (nt_k < 0) { const char* e = P_KNOBS ? getenv("RVLM_GEMM_NT_K") : nullptr; nt_k = e ? atoi(e) : 2048; }
         if (nt_k > 0 && p.K >= nt_k && g_persist_ablate == 0) return launch_256p_abl<EPI, ACT, 4096>(p, tiles_m, tiles_n, m_total, s);
     }
     return launch_256p_abl<EPI, ACT, 0>(p, tiles_m, tiles_n, m_total, s);
@@ -757,24 +774,27 @@ int gemm_bf16_nt_256p(const GemmBf16& p, int* rows_done, hipStream_t s) {
     // the remainder rows ride along in the same launch (strip_tail) unless RVLM_GEMM_TAIL=0 / an ablation build is on
     static int tail_on = -1;
     if (tail_on < 0) { const char* e = getenv("RVLM_GEMM_TAIL"); tail_on = e ? atoi(e) : 1; }
-    static int stagger = -1;
-    // (default 0 since the split-role schedule: the late start that gained 3 % on the fc2 dgrad under the lockstep schedule
-    // now costs it 4 %, profiles/r02_gemm_knobs_split.log)
+    // the measured settings of the schedule (same-box A/Bs of round 3): the workgroups of every second
+    // XCD take their remainder-row unit first (130), tile-order groups of 4 m-tiles
+    int strip_first = 130, group_m = 4;
+    q.stagger = 0; q.wave_prio = 0; q.krot = 0;
+#ifdef RVLM_EXPERIMENTAL_GEMM
+    // experiments: start stagger (gained 3 % on the fc2 dgrad under the lockstep schedule, costs it 4 % under the split-role
+    // one, profiles/r02_gemm_knobs_split.log), static priority, K rotation, other strip-first / group sizes
+    static int stagger = -1, stagger_mask = -1, stagger_ph = -1, e_strip_first = -1, e_group_m = -1, wave_prio = -1, krot = -999;
     if (stagger < 0) { const char* e = getenv("RVLM_GEMM_STAGGER"); stagger = e ? atoi(e) : 0; }
-    static int stagger_mask = -1;   // bit e: apply to epilogue kind e
-    if (stagger_mask < 0) { const char* e = getenv("RVLM_GEMM_STAGGER_EPI"); stagger_mask = e ? atoi(e) : 8; }
-    static int stagger_ph = -1;     // phase mask: 3 = 4 phases
-    if (stagger_ph < 0) { const char* e = getenv("RVLM_GEMM_STAGGER_PH"); stagger_ph = e ? atoi(e) : 3; }
+    if (stagger_mask < 0) { const char* e = getenv("RVLM_GEMM_STAGGER_EPI"); stagger_mask = e ? atoi(e) : 8; }   // bit e: epilogue kind e
+    if (stagger_ph < 0) { const char* e = getenv("RVLM_GEMM_STAGGER_PH"); stagger_ph = e ? atoi(e) : 3; }         // phase mask: 3 = 4 phases
     if (((stagger_mask >> q.epi) & 1) && stagger > 0) q.stagger = (stagger & 255) | (stagger_ph << 8);
-    static int strip_first = -1;
-    if (strip_first < 0) { const char* e = getenv("RVLM_GEMM_STRIP_FIRST"); strip_first = e ? atoi(e) : 130; }
-    q.stagger |= (strip_first & 255) << 16;
-    static int group_m = -1, wave_prio = -1;
-    if (group_m < 0) { const char* e = getenv("RVLM_GEMM_GROUP_M"); group_m = e ? std::max(1, atoi(e)) : 4; }
+    if (e_strip_first < 0) { const char* e = getenv("RVLM_GEMM_STRIP_FIRST"); e_strip_first = e ? atoi(e) : strip_first; }
+    if (e_group_m < 0) { const char* e = getenv("RVLM_GEMM_GROUP_M"); e_group_m = e ? std::max(1, atoi(e)) : group_m; }
     if (wave_prio < 0) { const char* e = getenv("RVLM_GEMM_PRIO"); wave_prio = e ? atoi(e) : 0; }
-    static int krot = -999;
     if (krot == -999) { const char* e = getenv("RVLM_GEMM_KROT"); krot = e ? atoi(e) : 0; }
-    q.group_m = group_m; q.wave_prio = wave_prio; q.krot = krot;
+    strip_first = e_strip_first; group_m = e_group_m;
+    q.wave_prio = wave_prio; q.krot = krot;
+#endif
+    q.stagger |= (strip_first & 255) << 16;
+    q.group_m = group_m;
     const bool tail = tail_on && (g_persist_ablate & 15) == 0 && p.batch_m_rows == 0 && p.M > q.M;
     const int m_total = tail ? p.M : q.M;
     int rc;

@@ -9,7 +9,10 @@ void gemm_set_variant(int v);
 int gemm_last_kernels();
 void gemm_set_trace(unsigned long long* ptr);
 void gemm_set_pingpong(int mask, int kmax);
+bool gemm_has_pingpong();
+#ifdef RVLM_EXPERIMENTAL_GEMM
 void gemm_x_set_trace(unsigned long long* ptr);
+#endif
 void gemm_set_ablate(int v);
 int attn_occupancy(int S, int* out3);
 
@@ -274,8 +277,21 @@ extern "C" int rvlm_k_gemm_set_variant(int v) { gemm_set_variant(v); return RVLM
 extern "C" int rvlm_k_gemm_last_kernels(void) { return gemm_last_kernels(); }
 extern "C" int rvlm_k_gemm_set_ablate(int v) { gemm_set_ablate(v); return RVLM_OK; }
 extern "C" int rvlm_k_gemm_set_trace(void* ptr) { gemm_set_trace((unsigned long long*)ptr); return RVLM_OK; }
-extern "C" int rvlm_k_gemm_set_pingpong(int mask, int kmax) { gemm_set_pingpong(mask, kmax); return RVLM_OK; }
-extern "C" int rvlm_k_gemm_x_set_trace(void* ptr) { gemm_x_set_trace((unsigned long long*)ptr); return RVLM_OK; }
+// the shipped library does not contain the ping-pong kernel (make EXPERIMENTAL=1 builds it): a non-zero mask is refused
+extern "C" int rvlm_k_gemm_set_pingpong(int mask, int kmax) {
+    if (mask > 0 && !gemm_has_pingpong())
+        return fail(RVLM_ERR_UNSUPPORTED, "rvlm_k_gemm_set_pingpong: this build has no ping-pong kernel (make EXPERIMENTAL=1)");
+    gemm_set_pingpong(mask, kmax);
+    return RVLM_OK;
+}
+extern "C" int rvlm_k_gemm_x_set_trace(void* ptr) {
+#ifdef RVLM_EXPERIMENTAL_GEMM
+    gemm_x_set_trace((unsigned long long*)ptr);
+    return RVLM_OK;
+#else
+    return ptr ? fail(RVLM_ERR_UNSUPPORTED, "rvlm_k_gemm_x_set_trace: this build has no ping-pong kernel (make EXPERIMENTAL=1)") : RVLM_OK;
+#endif
+}
 extern "C" int rvlm_k_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y,
                                         float* mean, float* rstd, int M, int W, rvlm_stream_t stream) {
     return layernorm_fwd<float>(x, W, gamma, beta, y, W, mean, rstd, M, W, (hipStream_t)stream);

@@ -291,6 +291,55 @@ class AdversarialTrainer:
             out = self._global_means(out, data.shape[0])
         return out
 
+    def profile_allreduce(self, data, reps: int = 3) -> dict:
+        """Self-diagnosis of the data-parallel step (bench.py --mode train --gpus N): every gradient bucket's RCCL
+        all-reduce timed ALONE (compute stream idle), and one weight-gradient backward timed without / with the bucketed
+        reduction launched under its later stages - the exposed time is what the overlap did not hide.  Leaves the
+        parameters untouched (no optimizer step); the gradient buffer is scratch afterwards."""
+        if not self._reduce:
+            return {"note": "no gradient all-reduce in this configuration (one rank, always_reduce off)"}
+        with torch.no_grad():
+            e0 = self.model_orig(data, self.output_normalize)
+        ev = lambda: torch.cuda.Event(enable_timing=True)        # noqa: E731
+        spans = [self.params.stage_span(a, b) for a, b in self.buckets]
+        alone = []
+        for lo, hi in spans:
+            best = None
+            for _ in range(reps):
+                torch.cuda.synchronize(self.device)
+                e0_, e1_ = ev(), ev()
+                e0_.record()
+                w = self._allreduce_span(lo, hi)
+                if w is not None:
+                    w.wait()
+                e1_.record()
+                torch.cuda.synchronize(self.device)
+                t = e0_.elapsed_time(e1_)
+                best = t if best is None else min(best, t)
+            alone.append(best)
+
+        def backward_ms(reduce_grads):
+            best = None
+            for _ in range(reps):
+                torch.cuda.synchronize(self.device)
+                a, b = ev(), ev()
+                a.record()
+                self._loss_backward(data, None, e0 + 0.01, "l2", None, 1.0, False, reduce_grads)
+                b.record()
+                torch.cuda.synchronize(self.device)
+                t = a.elapsed_time(b)
+                best = t if best is None else min(best, t)
+            return best
+        t_plain, t_red = backward_ms(False), backward_ms(True)
+        total = sum(alone)
+        exposed = max(t_red - t_plain, 0.0)
+        return {"n_buckets": len(spans), "bucket_mb": [round((hi - lo) * 4 / 2 ** 20, 1) for lo, hi in spans],
+                "bucket_allreduce_ms_alone": [round(t, 3) for t in alone], "allreduce_ms_alone_total": round(total, 3),
+                "fwd_bwd_ms_without_reduce": round(t_plain, 3), "fwd_bwd_ms_with_bucketed_reduce": round(t_red, 3),
+                "exposed_ms": round(exposed, 3),
+                "overlapped_fraction": round(1.0 - exposed / total, 4) if total > 0 else None,
+                "backend": "nccl (RCCL)" if self._device_collectives else "host copy (gloo)", "world": self.world}
+
     def eval_step(self, data_eval, targets_eval):
         """The periodic validation of …clip.py:389-424: acc / racc against a supervised 50-step APGD (CE on the
         zero-shot head, ``initial_stepsize = 0.05 * eps`` when clean_weight > 0) and the clean-vs-adversarial
