@@ -40,6 +40,19 @@ int fail(int code, const std::string& msg);
     } while (0)
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+// hipFuncSetAttribute opt-ins (dynamic LDS beyond 64 KiB) are per DEVICE: a launcher remembers them in a per-kernel atomic
+// mask, bit d = done on device d - not in a process-wide bool (another device of the process would launch without the
+// opt-in; two host threads would race)
+#define RVLM_ONCE_PER_DEVICE(mask_var, stmt)                                                       \
+    do {                                                                                            \
+        int _dev = 0;                                                                               \
+        (void)hipGetDevice(&_dev);                                                                  \
+        const unsigned long long _bit = 1ull << (_dev & 63);                                        \
+        if (!(__atomic_load_n(&(mask_var), __ATOMIC_ACQUIRE) & _bit)) {                             \
+            stmt;                                                                                   \
+            __atomic_fetch_or(&(mask_var), _bit, __ATOMIC_RELEASE);                                 \
+        }                                                                                           \
+    } while (0)
 static inline long round_up(long a, long b) { return (a + b - 1) / b * b; }
 
 // ---- device helpers ----------------------------------------------------------------------------

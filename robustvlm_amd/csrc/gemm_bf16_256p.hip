@@ -694,14 +694,13 @@ void gemm_set_trace(unsigned long long* ptr) { g_persist_trace = ptr; }
 
 template <int EPI, int ACT, int ABL>
 static int launch_256p_abl(const GemmBf16& p, int tiles_m, int tiles_n, int m_total, hipStream_t s) {
-    static bool attr_set = false;
+    static unsigned long long attr_devices = 0;
     const int lds_bytes = 3 * PA_SLOT + 2 * PB_SLOT;
-    if (!attr_set) {
+    RVLM_ONCE_PER_DEVICE(attr_devices, {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_nt_256p_kernel<EPI, ACT, ABL>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return fail(RVLM_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
-        attr_set = true;
-    }
+    });
     const int grid = std::min(tiles_m * tiles_n, 256);
     GemmBf16 q = p;
     q.trace = g_persist_trace;

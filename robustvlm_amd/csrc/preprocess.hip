@@ -217,11 +217,9 @@ extern "C" int rvlm_preproc_run(rvlm_preproc* p, const uint8_t* img_hwc, int H, 
     a.hb = p->d_hb; a.hk = p->d_hk; a.hks = p->hks;
     a.vb = p->d_vb; a.vk = p->d_vk; a.vks = p->vks;
     a.th = p->th; a.out = out_chw;
-    static bool attr = false;
-    if (!attr) {
-        RVLM_HIP(hipFuncSetAttribute((const void*)resize_crop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS));
-        attr = true;
-    }
+    static unsigned long long attr_devices = 0;
+    RVLM_ONCE_PER_DEVICE(attr_devices, RVLM_HIP(hipFuncSetAttribute((const void*)resize_crop_kernel,
+                                                                    hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS)));
     hipLaunchKernelGGL(resize_crop_kernel, dim3(cdiv(size, PP_TW), cdiv(size, p->th)), dim3(256), PP_LDS, s, a);
     RVLM_CHECK_LAUNCH();
     return RVLM_OK;
@@ -277,11 +275,9 @@ extern "C" int rvlm_preproc_run_batch(rvlm_preproc* p, const uint8_t* const* img
     memcpy(p->h_stage, desc.data(), desc.size() * sizeof(PreprocImg));
     memcpy((char*)p->h_stage + desc_bytes, tables.data(), tables.size() * sizeof(int));
     RVLM_HIP(hipMemcpyAsync(p->d_stage, p->h_stage, need, hipMemcpyHostToDevice, s));
-    static bool attr = false;
-    if (!attr) {
-        RVLM_HIP(hipFuncSetAttribute((const void*)resize_crop_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS));
-        attr = true;
-    }
+    static unsigned long long attr_devices_b = 0;
+    RVLM_ONCE_PER_DEVICE(attr_devices_b, RVLM_HIP(hipFuncSetAttribute((const void*)resize_crop_batch_kernel,
+                                                                      hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS)));
     hipLaunchKernelGGL(resize_crop_batch_kernel, dim3(cdiv(size, PP_TW), cdiv(size, th_min), n), dim3(256), PP_LDS, s,
                        (const PreprocImg*)p->d_stage, (const int*)((const char*)p->d_stage + desc_bytes), size, out);
     RVLM_CHECK_LAUNCH();

@@ -29,6 +29,9 @@ class ResizeCenterCropToTensor:
         img = img.contiguous()
         if out is None:
             out = torch.empty(3, self.size, self.size, dtype=torch.float32, device=img.device)
+        elif not (isinstance(out, torch.Tensor) and out.dtype == torch.float32 and out.device == img.device
+                  and out.is_contiguous() and tuple(out.shape) == (3, self.size, self.size)):
+            raise ValueError(f"out must be a contiguous float32 tensor of shape {(3, self.size, self.size)} on {img.device}")
         with torch.cuda.device(img.device):
             L.check(self.lib.rvlm_preproc_run(self._h, img.data_ptr(), img.shape[0], img.shape[1], out.data_ptr(),
                                               L.stream_ptr()), "rvlm_preproc_run")
@@ -41,15 +44,19 @@ class ResizeCenterCropToTensor:
         n = len(images)
         if n == 0:
             raise ValueError("empty batch")
-        dev = images[0].device
-        keep = []
+        keep, dev = [], None
         for im in images:
             if not (isinstance(im, torch.Tensor) and im.is_cuda and im.dtype == torch.uint8 and im.dim() == 3
-                    and im.shape[2] == 3 and im.device == dev):
+                    and im.shape[2] == 3 and (dev is None or im.device == dev)):
                 raise ValueError("expected uint8 CUDA tensors of shape [H, W, 3] on one device")
+            dev = im.device
             keep.append(im.contiguous())
         if out is None:
             out = torch.empty(n, 3, self.size, self.size, dtype=torch.float32, device=dev)
+        elif not (isinstance(out, torch.Tensor) and out.dtype == torch.float32 and out.device == dev and out.is_contiguous()
+                  and tuple(out.shape) == (n, 3, self.size, self.size)):
+            # the kernel writes n * 3 * size * size floats through a raw pointer: anything else would be out of bounds
+            raise ValueError(f"out must be a contiguous float32 tensor of shape {(n, 3, self.size, self.size)} on {dev}")
         ptrs = (C.c_void_p * n)(*[im.data_ptr() for im in keep])
         hs = (C.c_int * n)(*[im.shape[0] for im in keep])
         ws = (C.c_int * n)(*[im.shape[1] for im in keep])

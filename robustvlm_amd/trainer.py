@@ -142,6 +142,7 @@ class AdversarialTrainer:
         self.buckets = bucket_plan(self.engine.n_stages, n_buckets if self._reduce else 1)
         # a backend without device collectives (gloo in the CPU/1-GPU tests) reduces through a pinned host copy
         self._device_collectives = self._reduce and dist.get_backend(self.pg) == "nccl"
+        self._checked_global_batch = False
 
     # -- pieces of the step ----------------------------------------------------------------------
     def _attack(self, data, targets, e0):
@@ -192,6 +193,14 @@ class AdversarialTrainer:
         if self.world == 1:
             return 1.0
         if global_batch is not None:
+            if not self._checked_global_batch:
+                # a wrong value (a last partial batch, uneven shards) would silently mis-scale every rank's gradients:
+                # the first step that is given one checks it against the all-reduced shard sizes, once
+                n = torch.tensor([float(n_local)], dtype=torch.float64, device=self.device if self._device_collectives else None)
+                dist.all_reduce(n, op=dist.ReduceOp.SUM, group=self.pg)
+                if int(n.item()) != int(global_batch):
+                    raise ValueError(f"global_batch={global_batch} but the ranks hold {int(n.item())} images in this step")
+                self._checked_global_batch = True
             return n_local * self.world / float(global_batch)
         n = torch.tensor([float(n_local)], dtype=torch.float64)
         if self._device_collectives:
@@ -232,9 +241,12 @@ class AdversarialTrainer:
         """Logging values over the GLOBAL batch, as the reference's single-process DataParallel reports them (…clip.py:
         368-387 on gathered outputs): every rank contributes n_local x its shard mean, one small all-reduce."""
         keys = [k for k in ("loss", "loss_clean", "loss_total", "cos_sim_clean", "cos_sim", "acc", "racc") if out.get(k) is not None]
-        vec = torch.tensor([float(out[k]) * n_local for k in keys] + [float(n_local)], dtype=torch.float64)
-        if self._device_collectives:
-            vec = vec.to(self.device)
+        # stacked on the device: ONE host sync (after the all-reduce) instead of one float() per metric
+        vals = [out[k].detach().to(device=self.device, dtype=torch.float64).reshape(()) if isinstance(out[k], torch.Tensor)
+                else torch.tensor(float(out[k]), dtype=torch.float64, device=self.device) for k in keys]
+        vec = torch.cat([torch.stack(vals) * n_local, torch.tensor([float(n_local)], dtype=torch.float64, device=self.device)])
+        if not self._device_collectives:
+            vec = vec.cpu()
         dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=self.pg)
         vec = vec.cpu()
         res = dict(out)
