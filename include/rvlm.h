@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RVLM_VERSION 104
+#define RVLM_VERSION 105
 
 typedef void* rvlm_stream_t; /* hipStream_t */
 typedef struct rvlm_vit rvlm_vit;
@@ -322,6 +322,26 @@ int rvlm_preproc_run_batch(rvlm_preproc* p, const uint8_t* const* imgs_hwc, cons
                            rvlm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Data-parallel trainer: gradient all-reduce over RCCL / xGMI, one process per GPU.
+ * Replaces the reduction the reference gets from torch.nn.DataParallel (train/adversarial_training_clip.py:184-191).
+ * Rendezvous: rank 0 calls rvlm_comm_unique_id and hands the 128 bytes to every rank by whatever channel the host has
+ * (launcher environment, file, socket); every rank then calls rvlm_comm_create on its own GPU (collective call).
+ * rvlm_allreduce_grads: in-place SUM of buf[0 .. count) (device pointer) over the ranks, asynchronous on `stream`; the
+ * 1 / world factor goes into rvlm_adamw_step (grad_scale).  The attack entry points need none of this: every quantity of
+ * pgd / apgd_train / APGDAttack is per sample.  librccl is loaded at the first rvlm_comm_* call (RVLM_ERR_UNSUPPORTED if
+ * the host has none).
+ * ------------------------------------------------------------------------------------------- */
+#define RVLM_COMM_ID_BYTES 128
+#define RVLM_DTYPE_F32 0
+#define RVLM_DTYPE_BF16 1
+typedef struct rvlm_comm rvlm_comm;
+int rvlm_comm_unique_id(uint8_t* out_id /* [RVLM_COMM_ID_BYTES], host memory */);
+int rvlm_comm_create(const uint8_t* id, int rank, int world, rvlm_comm** out);
+int rvlm_comm_destroy(rvlm_comm* comm);
+int rvlm_comm_info(const rvlm_comm* comm, int* rank, int* world);
+int rvlm_allreduce_grads(rvlm_comm* comm, void* buf, size_t count, int dtype, rvlm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Measurement support: per-kernel-class HIP-event timing on the engine's stream.
  * ------------------------------------------------------------------------------------------- */
 typedef struct {
@@ -342,7 +362,8 @@ int rvlm_version(void);   /* = RVLM_VERSION.  101: rvlm_loss_spec.y_target, rvlm
                            * rvlm_ce_logits, rvlm_head_logits(_bwd), double hyper-parameters in rvlm_adamw_step,
                            * rvlm_pgd_l2_update, rvlm_pgd_run_norm, rvlm_apgd_l2_step, rvlm_apgd_run_norm,
                            * rvlm_project_perturbation, rvlm_normalize_grad; 104: rvlm_preproc_run_batch, rvlm_ce_logits takes B = 1,
-                           * rvlm_vit_backward_params_stages refuses out-of-order stages */
+                           * rvlm_vit_backward_params_stages refuses out-of-order stages; 105: rvlm_apgd_controller_rho,
+                           * rvlm_vit_set_apgd_rho, rvlm_comm_* / rvlm_allreduce_grads */
 
 #ifdef __cplusplus
 }

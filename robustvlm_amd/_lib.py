@@ -179,6 +179,15 @@ _SIGS = {
                                     C.c_long, C.c_int, c_f32p, C.c_void_p, C.c_size_t, c_stream]),
 }
 
+_SIGS.update({
+    # data-parallel trainer without torch.distributed: RCCL behind the C ABI (include/rvlm.h, csrc/comm.hip)
+    "rvlm_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "rvlm_comm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "rvlm_comm_destroy": (C.c_int, [C.c_void_p]),
+    "rvlm_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "rvlm_allreduce_grads": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, c_stream]),
+})
+COMM_ID_BYTES, DTYPE_F32, DTYPE_BF16 = 128, 0, 1
 EXPORTED_SYMBOLS = tuple(_SIGS)
 
 

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     for sym in declared:
         assert hasattr(lib, sym), f"{sym} declared in include/ but not exported by librvlm.so"
     assert declared == set(L.EXPORTED_SYMBOLS), declared ^ set(L.EXPORTED_SYMBOLS)
-    assert lib.rvlm_version() == 104
+    assert lib.rvlm_version() == 105
 
 
 def test_product_path_fails_loudly_without_gpu():
@@ -294,3 +294,19 @@ def test_square_schedule_matches_oracle():
         for resc in (True, False):
             for it in list(range(0, 600)) + [999, 1000, 1001, 2000, 2001, 4000, 4001, 6000, 6001, 8000, 8001, 9999]:
                 assert p_selection(it, nq, .8, resc) == p_schedule(it, nq, .8, resc), (it, nq, resc)
+
+
+def test_comm_abi_argument_checks():
+    """rvlm_comm_* / rvlm_allreduce_grads (include/rvlm.h): argument errors are status codes, never a
+    crash; no RCCL call is made on this path (no GPU here)."""
+    lib = L.load()
+    import ctypes as C
+    assert lib.rvlm_comm_unique_id(None) == L.RVLM_ERR_ARG
+    h = C.c_void_p()
+    ident = (C.c_uint8 * L.COMM_ID_BYTES)()
+    assert lib.rvlm_comm_create(ident, 2, 2, C.byref(h)) == L.RVLM_ERR_ARG          # rank out of range
+    assert lib.rvlm_comm_create(ident, 0, 0, C.byref(h)) == L.RVLM_ERR_ARG          # empty world
+    assert lib.rvlm_comm_create(None, 0, 1, C.byref(h)) == L.RVLM_ERR_ARG
+    assert lib.rvlm_allreduce_grads(None, None, 0, L.DTYPE_F32, None) == L.RVLM_ERR_ARG
+    assert lib.rvlm_comm_info(None, None, None) == L.RVLM_ERR_ARG
+    assert lib.rvlm_comm_destroy(None) == L.RVLM_OK                                  # like free(NULL)

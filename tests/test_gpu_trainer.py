@@ -348,6 +348,23 @@ def test_bucketed_allreduce_on_rccl_single_rank(tmp_path):
     assert torch.load(out)["same"]
 
 
+def test_cabi_allreduce_grads_on_rccl(tmp_path):
+    """SURVEY.md 8(b) `rvlm_allreduce_grads`: the C ABI's own RCCL collective (csrc/comm.hip), driven through ctypes in a
+    process that never imports torch.distributed - rendezvous token, communicator, in-place fp32 / bf16 sums ordered on a side
+    stream, argument errors as status codes."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "comm.pt")
+    env = dict(os.environ, PYTHONPATH=root, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "comm_worker.py"), out], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    got = torch.load(out)
+    assert got["ok"] and got["bad_dtype_rc"] == L.RVLM_ERR_ARG, got
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_train_step_vit_l14_vs_oracle(precision):
     """VERDICT r2 missing 4 / next 4(d): the optimizer step the train bench times (train/adversarial_training_clip.py:
