@@ -55,6 +55,9 @@ def parse():
                          "so that its launch / wait structure and the `allreduce` diagnostics can be exercised without a node")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="skip the in-run rocprofv3 --pmc passes (fabric traffic, matrix-pipe busy): roofline.traffic / "
+                         "pmc_in_pipeline then come from the committed profiles/ files, flagged measured_in_run: false")
     return ap.parse_args()
 
 
@@ -162,6 +165,76 @@ def hbm_classes(prof: dict, cfg, B: int) -> dict:
                   "bytes_per_launch": nbytes / v["launches"], "avg_launch_us": 1e3 * v["ms"] / v["launches"],
                   "launches": v["launches"], "ms_per_step": round(v["ms"], 3)}
     return out
+
+
+def pmc_in_run(argv_child, timeout_s=240):
+    """`roofline.traffic` and the in-pipeline matrix-pipe figures measured IN THIS RUN, on this box and build: PMC counters cannot
+    be read from inside the process, so rank 0 runs this same script under `rocprofv3 --pmc` as a child (one counter group per
+    pass, --kernel-trace only - no sys/hip/hsa trace domains next to --pmc; the child times one pgd() call + the e0 forward,
+    --no-roofline --no-cpu-baseline --no-pmc) while the parent's stream is idle, and sums the counters per kernel like
+    scripts/pmc_traffic.sh / pmc_pipeline.sh.  FETCH_SIZE is DOUBLED (MI355X_MICROARCH.md, HBM section: gfx950 reports half the
+    bytes of wide coalesced reads), both counters are KiB.  Returns (traffic_bytes_per_gemm_launch, info, pmc) or raises."""
+    import collections
+    import csv
+    import glob
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        raise RuntimeError("rocprofv3 not found")
+    passes = [("FETCH_SIZE",), ("WRITE_SIZE",),
+              ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE")]
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    launches = collections.Counter()
+    t_begin = time.time()
+    root = tempfile.mkdtemp(prefix="rvlm_pmc_", dir="/tmp")
+    try:
+        for i, ctrs in enumerate(passes):
+            out = os.path.join(root, f"p{i}")
+            os.makedirs(out)
+            env = dict(os.environ, TMPDIR="/tmp", RVLM_BENCH_CHILD="1")
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_PORT", "RVLM_SELF_LAUNCHED"):
+                env.pop(k, None)
+            cmd = [exe, "--pmc", *ctrs, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "pmc", "--",
+                   sys.executable, os.path.join(ROOT, "bench.py"), *argv_child]
+            left = timeout_s - (time.time() - t_begin)
+            if left < 20:
+                raise RuntimeError("time budget of the PMC passes exhausted")
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=left)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                raise RuntimeError(f"rocprofv3 pass {ctrs[0]} failed (rc {r.returncode}): {(r.stderr or r.stdout)[-300:]}")
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    k = re.sub(r"^rvlm::", "", re.sub(r"\(.*", "", row["Kernel_Name"]).replace("void ", "").strip())
+                    agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
+                    if row["Counter_Name"] == "FETCH_SIZE":
+                        launches[k] += 1
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+    gemm = {k: v for k, v in agg.items() if "gemm_bf16" in k or "splitk_reduce" in k}
+    logical = sum(launches[k] for k in gemm if "256p" in k)
+    if not logical:
+        raise RuntimeError("no persistent-GEMM launches in the counter files")
+    total = sum((2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024.0 for v in gemm.values())
+    info = {"measured_in_run": True, "seconds": round(time.time() - t_begin, 1), "gemm_logical_launches": logical,
+            "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over a child run of this script (one pgd() call + the e0 forward) on "
+                   "this box; bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB summed over every bf16 GEMM kernel / persistent-kernel "
+                   "launches; fabric side: Infinity-Cache hits included (profiles/r04_pmc_l2.json separates them by read latency)"}
+    tot_active = sum(v.get("GRBM_GUI_ACTIVE", 0.0) for v in agg.values()) or 1.0
+    pmc = {"measured_in_run": True, "source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT "
+                                              "SQ_LDS_IDX_ACTIVE pass over the same child run",
+           "mfma_busy": {}, "lds_conflict_share": {}}
+    for k, v in sorted(agg.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0.0)):
+        if v.get("GRBM_GUI_ACTIVE", 0.0) < 0.004 * tot_active:
+            continue
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in v:
+            pmc["mfma_busy"][k] = round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (v["GRBM_GUI_ACTIVE"] / 8.0), 4)
+        if v.get("SQ_LDS_IDX_ACTIVE"):
+            pmc["lds_conflict_share"][k] = round(v.get("SQ_LDS_BANK_CONFLICT", 0.0) / v["SQ_LDS_IDX_ACTIVE"], 4)
+    return round(total / logical), info, pmc
 
 
 def _baseline_config_name(attack: str, world: int, per_gpu_batch: int) -> str:
@@ -492,6 +565,15 @@ def main():
         # read from inside this process); the committed measurement of this same command is reported.
         traffic, traffic_src, pmc = None, None, None
         headline = args.model == "ViT-L-14" and args.batch == 128 and args.precision == "bf16" and args.attack == "pgd"
+        pmc_error = None
+        if headline and world == 1 and not args.no_pmc and not os.environ.get("RVLM_BENCH_CHILD"):
+            try:
+                torch.cuda.synchronize()
+                traffic, traffic_src, pmc = pmc_in_run(["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-roofline", "--no-pmc",
+                                                        "--iterations", str(args.iterations)])
+            except Exception as e:                    # measurement aid: fall back to the committed passes, flagged as such
+                pmc_error = f"{type(e).__name__}: {e}"[:400]
+                traffic, traffic_src, pmc = None, None, None
         for tag in ("r04", "r03", "r02"):
             tj = os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_traffic.json")
             if traffic is None and os.path.exists(tj) and headline:
@@ -509,7 +591,7 @@ def main():
         # matrix-pipe utilisation INSIDE this pipeline (not of a cube): rocprofv3 --pmc passes over this same command,
         # summarised per kernel by scripts/pmc_pipeline.sh (counters cannot be read from inside this process either)
         pj = next((q for q in (os.path.join(ROOT, "profiles", f"{t}_pmc_pipeline.json") for t in ("r04", "r03")) if os.path.exists(q)), "")
-        if pj and headline:
+        if pj and headline and pmc is None:
             try:
                 kd = json.load(open(pj))["kernels"]
                 pmc = {"measured_in_run": False,
@@ -524,7 +606,7 @@ def main():
             "bound": "mfma", "kernel": "gemm_bf16_nt_256p_kernel (QKV/out-proj/fc1/fc2, fwd + dgrad; the 128 remainder rows ride in the same launch)",
             "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
             "traffic": traffic, "traffic_unit": "bytes per GEMM launch (fabric side: 2*FETCH_SIZE + WRITE_SIZE)",
-            "traffic_source": traffic_src,
+            "traffic_source": traffic_src, "pmc_in_run_error": pmc_error,
             "flops_per_launch": gflops / max(glaunch, 1), "avg_launch_ms": gms / max(glaunch, 1),
             "launches": glaunch,
             "pmc_in_pipeline": pmc,
