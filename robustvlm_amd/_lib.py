@@ -164,6 +164,7 @@ _SIGS = {
     "rvlm_k_gemm_last_kernels": (C.c_int, []),
     "rvlm_k_gemm_set_trace": (C.c_int, [C.c_void_p]),
     "rvlm_k_gemm_set_pingpong": (C.c_int, [C.c_int, C.c_int]),
+    "rvlm_k_gemm_set_m16": (C.c_int, [C.c_int]),
     "rvlm_k_gemm_x_set_trace": (C.c_int, [C.c_void_p]),
     "rvlm_k_gemm_set_ablate": (C.c_int, [C.c_int]),
     "rvlm_k_probe_operand_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

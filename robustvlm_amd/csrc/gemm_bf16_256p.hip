@@ -29,6 +29,10 @@
 #include "gemm_strip.h"
 #include <type_traits>
 
+#ifndef RVLM_GEMM_M16_DEFAULT
+#define RVLM_GEMM_M16_DEFAULT 0
+#endif
+
 namespace rvlm {
 
 // Knobs that were measured neutral or worse (start stagger, K rotation, static wave priority: DESIGN.md section 3, rounds 2-3)
@@ -63,6 +67,13 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
     constexpr bool SPLIT = (ABL & 256) == 0 && (ABL & 8) == 0;   // (the register-path experiment keeps the lockstep form)
 #endif
     constexpr bool SWAP = (ABL & 512) == 0;
+    // MFMA shape (round 4).  ABL & 8192: the wave tile (128 x 64) is 8 x 4 tiles of v_mfma_f32_16x16x32_bf16 instead of 4 x 2 of
+    // v_mfma_f32_32x32x16_bf16 - same FLOPs, LDS fragment bytes and accumulator count per K-step, half the accumulator traffic per
+    // FLOP inside the matrix pipe.  A register-only probe of the two instruction streams under the socket power cap
+    // (profiles/r04_mfma_shape_power.log) holds 2 169 against 1 919 TFLOP/s (2.17 vs 1.93 GHz at ~1.33 kW).  A K-step is then
+    // 2 slices of 32 x 2 halves of 4 m-tiles = 4 phases of 16 MFMAs (the 32x32 form: 4 slices of 8 MFMAs); accumulator layout:
+    // tile (mt, nt), lane (i16 = lane & 15, G = lane >> 4) holds row m = 16 mt + i16, columns n = 16 nt + 4 G + {0..3}.
+    constexpr bool M16 = (ABL & 8192) != 0;
     constexpr int NPIECE = SPLIT ? 8 : 4;      // DMA pieces per wave and operand half
     // Fragment reads between the MFMAs of the previous k-slice (2 ds_read_b128 after each of its first three MFMAs)
     // instead of 6 in a row between two groups of 8 MFMAs: with the role split each wave runs alone on its SIMD while
@@ -269,7 +280,67 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
         asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(b[1]) : "v"(bb));
     };
 
-    f32x16 acc[4][2];
+    // M16: lane (i16, G) reads row (row block) + 16 t + i16, logical 16-B chunk 4 ks + G of the 32-deep slice ks; the ring's
+    // swizzle key (row >> 1) & 7 only depends on i16.  (Conflict-free under ds_read_b128's 4 x 16 lane groups: every group sees
+    // each (row parity, chunk) pair once - checked by hand for the four groups.)
+    const int i16 = lane & 15, G = lane >> 4;
+    unsigned fa16[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) fa16[ks] = lds_base + (wm * 128 + i16) * 128 + (((ks * 4 + G) ^ ((i16 >> 1) & 7)) << 4);
+    f32x4 acc16[M16 ? 8 : 1][M16 ? 4 : 1];
+    // X fragments (activation rows) of m-tiles 4 h .. 4 h + 3 of slice ks
+    auto load_x16 = [&](int sa, int ks, int h, i32x4 (&x)[4]) __attribute__((always_inline)) {
+        if (ABL & 4) return;
+        int oa = sa * PA_SLOT;
+        asm volatile("" : "+s"(oa));
+        const unsigned aa = fa16[ks] + oa + h * 8192;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(x[0]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(x[1]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(x[2]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(x[3]) : "v"(aa));
+    };
+    // W fragments (weight rows) of the wave's 4 n-tiles of slice ks
+    auto load_w16 = [&](int sb, int ks, i32x4 (&wf)[4]) __attribute__((always_inline)) {
+        if (ABL & 4) return;
+        int ob = sb * PB_SLOT + ab_delta;
+        asm volatile("" : "+s"(ob));
+        const unsigned bb = fa16[ks] + ob;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(wf[0]) : "v"(bb));
+        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(wf[1]) : "v"(bb));
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(wf[2]) : "v"(bb));
+        asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(wf[3]) : "v"(bb));
+    };
+    // one phase: the 16 MFMAs of m-tiles 4 h .. 4 h + 3 x 4 n-tiles; with LOADS, the next phase's fragment reads go out one
+    // behind each of the first MFMAs (nks, nh: the next phase; its W fragments only when it opens a new slice)
+    auto mma16_phase = [&](const i32x4 (&x)[4], const i32x4 (&wf)[4], int h, bool loads, int sa, int sb, int nks, int nh,
+                           i32x4 (&nx)[4], i32x4 (&nw)[4]) __attribute__((always_inline)) {
+        int oa = sa * PA_SLOT, ob = sb * PB_SLOT + ab_delta;
+        asm volatile("" : "+s"(oa), "+s"(ob));
+        const unsigned aa = fa16[nks] + oa + nh * 8192, bb = fa16[nks] + ob;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                if (!(ABL & 2))
+                    acc16[M16 ? 4 * h + q : 0][M16 ? nt : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, wf[nt]), __builtin_bit_cast(bf16x8, x[q]), acc16[M16 ? 4 * h + q : 0][M16 ? nt : 0], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (loads && !(ABL & 4)) {
+                    const int n = q * 4 + nt;          // position in the phase
+                    if (n == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(nx[0]) : "v"(aa));
+                    else if (n == 1) asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(nx[1]) : "v"(aa));
+                    else if (n == 2) asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(nx[2]) : "v"(aa));
+                    else if (n == 3) asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(nx[3]) : "v"(aa));
+                    else if (nh == 0 && n == 4) asm volatile("ds_read_b128 %0, %1" : "=v"(nw[0]) : "v"(bb));
+                    else if (nh == 0 && n == 5) asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(nw[1]) : "v"(bb));
+                    else if (nh == 0 && n == 6) asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(nw[2]) : "v"(bb));
+                    else if (nh == 0 && n == 7) asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(nw[3]) : "v"(bb));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    };
+
+    f32x16 acc[M16 ? 1 : 4][M16 ? 1 : 2];
     auto mma = [&](const i32x4 (&a)[4], const i32x4 (&b)[2]) {
         if (ABL & 2) return;
 #ifdef RVLM_MFMA_PRIO
@@ -279,9 +350,8 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b[j]),
-                                                                    __builtin_bit_cast(bf16x8, a[i]), acc[i][j],
-                                                                    0, 0, 0);
+                acc[M16 ? 0 : i][M16 ? 0 : j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                    __builtin_bit_cast(bf16x8, b[j]), __builtin_bit_cast(bf16x8, a[i]), acc[M16 ? 0 : i][M16 ? 0 : j], 0, 0, 0);
 #ifdef RVLM_MFMA_PRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
@@ -298,9 +368,8 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 if (!(ABL & 2))
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b[j]),
-                                                                        __builtin_bit_cast(bf16x8, a[i]), acc[i][j],
-                                                                        0, 0, 0);
+                    acc[M16 ? 0 : i][M16 ? 0 : j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        __builtin_bit_cast(bf16x8, b[j]), __builtin_bit_cast(bf16x8, a[i]), acc[M16 ? 0 : i][M16 ? 0 : j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (!(ABL & 4)) {
                     if (i == 0 && j == 0) {
@@ -317,9 +386,15 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
                 __builtin_amdgcn_sched_barrier(0);
             }
     };
+    // zero the accumulators of the 32 x 32 sub-tile (mi, ni) of the wave tile
     auto init_acc = [&](int mi, int ni) {
+        if (M16) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.0f;
+            for (int pc = 0; pc < 4; ++pc) acc16[M16 ? 2 * mi + (pc >> 1) : 0][M16 ? 2 * ni + (pc & 1) : 0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[M16 ? 0 : mi][M16 ? 0 : ni][e] = 0.0f;
+        }
     };
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) { init_acc(mi, 0); init_acc(mi, 1); }
@@ -337,6 +412,7 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
     __builtin_amdgcn_sched_barrier(0);
 
     i32x4 a0[4], b0[2], a1[4], b1[2];
+    i32x4 w0[4], w1[4];          // M16: W fragments of the current / next 32-deep slice (a0 / a1 hold the X fragments of a phase)
     // lane offsets of the epilogue's coalesced accesses (bytes); one instruction = 8 rows (16 for the 64-B rows)
     const int st16_loff = ((lane >> 3) * ldo + (lane & 7) * 8) * 2;   // bf16: 128 B (64 columns) per row
     const int st32_loff = ((lane >> 3) * ldo + (lane & 7) * 4) * 4;   // fp32: 128 B (32 columns) per row
@@ -363,14 +439,29 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
         tile_origin(blockIdx.x + ti * gridDim.x, m0, n0);
         const bool last_tile = (ti + 1 == ntw);
         stamp(ti, 0);
-        load_frags(ca_slot, cb_slot, 0, a0, b0);
+        if (M16) { load_x16(ca_slot, 0, 0, a0); load_w16(cb_slot, 0, w0); }
+        else load_frags(ca_slot, cb_slot, 0, a0, b0);
 
         // One K-step.  At its barrier the next stage has landed for every wave and every wave is done reading this
         // stage, whose two slots are refilled right away: B of stage g+2, then A of stage g+3 (in that order: the
         // next step may leave exactly the 4 youngest pieces, the A half, in flight).
         auto k_step = [&](bool first_of_tile, bool last_of_tile) {
             const int na_slot = (ca_slot == 2) ? 0 : ca_slot + 1, nb_slot = cb_slot ^ 1;
-            if (FINE) {
+            if (M16) {
+                // phases 0 - 2 of the K-step (slice 0 half 0, slice 0 half 1, slice 1 half 0); phase 3 runs behind the barrier
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                mma16_phase(a0, w0, 0, true, ca_slot, cb_slot, 0, 1, a1, w1);
+                if (ABL & 2048) tl[3] = __builtin_amdgcn_s_memtime();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                mma16_phase(a1, w0, 1, true, ca_slot, cb_slot, 1, 0, a0, w1);
+                if (ABL & 2048) tl[4] = __builtin_amdgcn_s_memtime();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                mma16_phase(a0, w1, 0, true, ca_slot, cb_slot, 1, 1, a1, w0);
+                if (ABL & 2048) tl[5] = __builtin_amdgcn_s_memtime();
+            } else if (FINE) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 mma_lf(a0, b0, ca_slot, cb_slot, 1, a1, b1);
@@ -435,7 +526,7 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
             if (SPLIT) {
                 // (B is deferred past the epilogue in a tile's last step: staging uses that slot)
                 if (!last_of_tile) {
-                    if (!FINE) load_frags(na_slot, nb_slot, 0, a0, b0);     // (FINE: among the caller's 8 MFMAs)
+                    if (!FINE && !M16) load_frags(na_slot, nb_slot, 0, a0, b0);     // (FINE / M16: among the caller's MFMAs)
                     issue_b();
                 }
             } else {
@@ -444,20 +535,22 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
             }
             if (ABL & 128) { wt_dma += __builtin_amdgcn_s_memtime() - wt_mark; }
             if (ABL & 2048) tl[1] = __builtin_amdgcn_s_memtime();
-            if (!SPLIT && !FINE && !last_of_tile) load_frags(na_slot, nb_slot, 0, a0, b0);
+            if (!SPLIT && !FINE && !M16 && !last_of_tile) load_frags(na_slot, nb_slot, 0, a0, b0);
             ca_slot = na_slot;
             cb_slot = nb_slot;
         };
         k_step(true, false);
         __builtin_amdgcn_sched_barrier(0);
         // + the next stage's first fragments (its barrier is behind us)
-        if (FINE) mma_lf(a1, b1, ca_slot, cb_slot, 0, a0, b0);
+        if (M16) mma16_phase(a1, w1, 1, true, ca_slot, cb_slot, 0, 0, a0, w0);
+        else if (FINE) mma_lf(a1, b1, ca_slot, cb_slot, 0, a0, b0);
         else mma(a1, b1);
         __builtin_amdgcn_sched_barrier(0);
         for (int kt = 1; kt < nk - 1; ++kt) {
             k_step(false, false);
             __builtin_amdgcn_sched_barrier(0);
-            if (FINE) mma_lf(a1, b1, ca_slot, cb_slot, 0, a0, b0);
+            if (M16) mma16_phase(a1, w1, 1, true, ca_slot, cb_slot, 0, 0, a0, w0);
+            else if (FINE) mma_lf(a1, b1, ca_slot, cb_slot, 0, a0, b0);
             else mma(a1, b1);
             if (ABL & 2048) tl[2] = __builtin_amdgcn_s_memtime();
             __builtin_amdgcn_sched_barrier(0);
@@ -471,7 +564,8 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
 #pragma unroll
             for (int g = 0; g < 4; ++g)   // (a null bias has a zero-length descriptor: out-of-range loads return 0)
                 bv[ni][g] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
-                    bias_rs, hi * 16, __builtin_amdgcn_readfirstlane((n0 + wn * 64 + ni * 32 + 8 * g) * 4), 0));
+                    bias_rs, M16 ? G * 16 : hi * 16,     // M16: bv[ni][g] = the columns of n-tile 2 ni + (g >> 1) (g & 1 unused)
+                    __builtin_amdgcn_readfirstlane((n0 + wn * 64 + (M16 ? (2 * ni + (g >> 1)) * 16 : ni * 32 + 8 * g)) * 4), 0));
         // Side input of the epilogue (fp32 residual / bf16 h_pre), read in the SAME coalesced pattern as the output is
         // stored (after the LDS transpose) and prefetched SIDE_DEPTH 32x32 sub-tiles ahead: sub-tile s = 2*mi + ni lives
         // in side[s % SIDE_DEPTH].  The first ones are requested under the last MFMAs of the tile.
@@ -495,18 +589,29 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
         if (EPI == EPI_F32_RESID) load_side(0);                            // a0/b0 are dead
         if (EPI == EPI_BF16_DACT) { load_side(0); load_side(1); }
         __builtin_amdgcn_sched_barrier(0);
-        mma(a1, b1);
+        if (M16) mma16_phase(a1, w1, 1, false, 0, 0, 0, 0, a0, w0);
+        else mma(a1, b1);
         __builtin_amdgcn_sched_barrier(0);
         // bias joins the accumulators here, so that its registers are free for the side-input prefetch
+        if (M16) {
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const float4 bq = bv[nt >> 1][(nt & 1) * 2];
+                    acc16[M16 ? mt : 0][M16 ? nt : 0] += f32x4{bq.x, bq.y, bq.z, bq.w};
+                }
+        } else {
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    acc[mi][ni][g * 4 + 0] += bv[ni][g].x; acc[mi][ni][g * 4 + 1] += bv[ni][g].y;
-                    acc[mi][ni][g * 4 + 2] += bv[ni][g].z; acc[mi][ni][g * 4 + 3] += bv[ni][g].w;
+                    acc[M16 ? 0 : mi][M16 ? 0 : ni][g * 4 + 0] += bv[ni][g].x; acc[M16 ? 0 : mi][M16 ? 0 : ni][g * 4 + 1] += bv[ni][g].y;
+                    acc[M16 ? 0 : mi][M16 ? 0 : ni][g * 4 + 2] += bv[ni][g].z; acc[M16 ? 0 : mi][M16 ? 0 : ni][g * 4 + 3] += bv[ni][g].w;
                 }
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (EPI == EPI_F32_RESID) { load_side(1); load_side(2); load_side(3); }
         if (EPI == EPI_BF16_DACT) { load_side(2); load_side(3); }
@@ -518,6 +623,27 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
         const unsigned w16_pre = ebuf + l31 * 128 + ((hi ^ (l31 & 15)) << 3);   // bf16: 8-B chunk (ni*8 + 2g + hi) ^ (row & 15)
         const unsigned wp_pre = ebuf + l31 * 128 + ((hi ^ pair_key(l31)) << 3);     // activation pair: see pair_key()
         const unsigned w32_pre = ebuf + l31 * 128 + ((hi ^ (l31 & 7)) << 4);    // fp32: 16-B chunk (2g + hi) ^ (row & 7)
+        // M16: the SAME staged layouts (element (row, col) of the 32-row block lands at the same LDS address, so the read-back
+        // and store side below is shared): piece pc = (a, b) of a 32 x 32 sub-tile is accumulator tile (2 mi + a, 2 ni + b),
+        // row 16 a + i16, columns 16 b + 4 G .. + 3, i.e. 4-column chunk 4 b + G (row & 15 = i16: the keys only need i16)
+        const unsigned w16n_pre = ebuf + i16 * 128 + ((G ^ i16) << 3);
+        const unsigned wpn_pre = ebuf + i16 * 128 + ((G ^ pair_key(i16)) << 3);
+        const unsigned w32n_pre = ebuf + i16 * 128 + ((G ^ (i16 & 7)) << 4);
+        // piece pc (g in the 32x32 form) of sub-tile (mi, ni): its 4 values and its staging addresses
+        auto piece = [&](int mi, int ni, int pc) -> f32x4 {
+            if (M16) return acc16[M16 ? 2 * mi + (pc >> 1) : 0][M16 ? 2 * ni + (pc & 1) : 0];
+            return f32x4{acc[M16 ? 0 : mi][M16 ? 0 : ni][pc * 4 + 0], acc[M16 ? 0 : mi][M16 ? 0 : ni][pc * 4 + 1],
+                         acc[M16 ? 0 : mi][M16 ? 0 : ni][pc * 4 + 2], acc[M16 ? 0 : mi][M16 ? 0 : ni][pc * 4 + 3]};
+        };
+        auto w16_addr = [&](int ni, int pc) -> unsigned {      // bf16, 64-column rows
+            return M16 ? (w16n_pre ^ ((ni * 8 + 4 * (pc & 1)) << 3)) + (pc >> 1) * 2048 : w16_pre ^ ((ni * 8 + 2 * pc) << 3);
+        };
+        auto wp_addr = [&](int which, int pc) -> unsigned {    // activation pair: which = 0 act', 1 act
+            return M16 ? (wpn_pre ^ ((which * 8 + 4 * (pc & 1)) << 3)) + (pc >> 1) * 2048 : wp_pre ^ ((which * 8 + 2 * pc) << 3);
+        };
+        auto w32_addr = [&](int pc) -> unsigned {              // fp32, 32-column rows
+            return M16 ? (w32n_pre ^ ((pc & 1) << 6)) + (pc >> 1) * 2048 : w32_pre ^ (pc << 5);
+        };
         const unsigned r16_a = ebuf + r0 * 128 + (((lane & 7) ^ (r0 >> 1)) << 4);       // bf16, it even
         const unsigned r16_b = ebuf + r0 * 128 + (((lane & 7) ^ (r0 >> 1) ^ 4) << 4);   // bf16, it odd ((row & 15) >> 1 flips bit 2)
         const unsigned r32 = ebuf + r0 * 128 + (((lane & 7) ^ r0) << 4);                // fp32 ((r0 + 8*it) & 7 == r0)
@@ -532,8 +658,7 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
                     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
-                            float v[4] = {acc[mi][ni][g * 4 + 0], acc[mi][ni][g * 4 + 1], acc[mi][ni][g * 4 + 2],
-                                          acc[mi][ni][g * 4 + 3]};
+                            const f32x4 v = piece(mi, ni, g);
                             bf16x4 o;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
@@ -541,7 +666,7 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
                                 actp_pair<ACT>(v[e], av, dv);
                                 o[e] = (bf16_t)(what == 1 ? av : what == 2 ? dv : v[e]);
                             }
-                            lds_w64(w16_pre ^ ((ni * 8 + 2 * g) << 3), __builtin_bit_cast(u32x2, o));
+                            lds_w64(w16_addr(ni, g), __builtin_bit_cast(u32x2, o));
                         }
                     u32x4 t0 = lds_r128<0>(r16_a), t1 = lds_r128<8 * 128>(r16_b), t2 = lds_r128<16 * 128>(r16_a),
                           t3 = lds_r128<24 * 128>(r16_b);
@@ -585,15 +710,16 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
                             bf16x4 oa, od;
+                            const f32x4 hv = piece(mi, ni, g);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 float av, dv;
-                                actp_pair<ACT>(acc[mi][ni][g * 4 + e], av, dv);
+                                actp_pair<ACT>(hv[e], av, dv);
                                 oa[e] = (bf16_t)av; od[e] = (bf16_t)dv;
                             }
                             // 8-B chunk index within the 128-B row: (which * 8 + 2 g + hi) ^ pair_key(row); which = 0 act', 1 act
-                            lds_w64(wp_pre ^ ((2 * g) << 3), __builtin_bit_cast(u32x2, od));
-                            lds_w64(wp_pre ^ ((8 + 2 * g) << 3), __builtin_bit_cast(u32x2, oa));
+                            lds_w64(wp_addr(0, g), __builtin_bit_cast(u32x2, od));
+                            lds_w64(wp_addr(1, g), __builtin_bit_cast(u32x2, oa));
                         }
                         init_acc(mi, ni);
                         // read back: 16 rows per instruction, 4 lanes x 16 B per row and output; lane -> row rr (+ 16), 16-B
@@ -630,11 +756,7 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
                     // fp32 staging of one 32x32 sub-tile: 128-B rows, 16-B chunk index XOR (row & 7)
                     const int sub = mi * 2 + ni;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const float4 v = make_float4(acc[mi][ni][g * 4 + 0], acc[mi][ni][g * 4 + 1],
-                                                     acc[mi][ni][g * 4 + 2], acc[mi][ni][g * 4 + 3]);
-                        lds_w128(w32_pre ^ (g << 5), __builtin_bit_cast(u32x4, v));
-                    }
+                    for (int g = 0; g < 4; ++g) lds_w128(w32_addr(g), __builtin_bit_cast(u32x4, piece(mi, ni, g)));
                     init_acc(mi, ni);
                     {
                         const int so = __builtin_amdgcn_readfirstlane(((m_base + mi * 32) * ldo + n_base + ni * 32) * 4);
@@ -692,6 +814,14 @@ bool gemm_has_ablate() { return P_KNOBS; }
 unsigned long long* g_persist_trace = nullptr;   // [256 workgroups][8 tiles][4 stamps] or null
 void gemm_set_trace(unsigned long long* ptr) { g_persist_trace = ptr; }
 
+// MFMA shape of the tile phase: 1 = v_mfma_f32_16x16x32_bf16 (RVLM_GEMM_M16; rvlm_k_gemm_set_m16 for same-process A/Bs)
+static int g_m16 = -1;
+static bool gemm_m16() {
+    if (g_m16 < 0) { const char* e = getenv("RVLM_GEMM_M16"); g_m16 = e ? atoi(e) : RVLM_GEMM_M16_DEFAULT; }
+    return g_m16 != 0;
+}
+void gemm_set_m16(int v) { g_m16 = v; }
+
 template <int EPI, int ACT, int ABL>
 static int launch_256p_abl(const GemmBf16& p, int tiles_m, int tiles_n, int m_total, hipStream_t s) {
     static unsigned long long attr_devices = 0;
@@ -742,8 +872,11 @@ static int launch_256p_act(const GemmBf16& p, int tiles_m, int tiles_n, int m_to
         // fp32 output stored nt from K = 2048 on (profiles/r03_ab_nt_threshold.log; EXPERIMENTAL builds: RVLM_GEMM_NT_K, 0 = never)
         static int nt_k = -1;
         if (nt_k < 0) { const char* e = P_KNOBS ? getenv("RVLM_GEMM_NT_K") : nullptr; nt_k = e ? atoi(e) : 2048; }
-        if (nt_k > 0 && p.K >= nt_k && g_persist_ablate == 0) return launch_256p_abl<EPI, ACT, 4096>(p, tiles_m, tiles_n, m_total, s);
+        if (nt_k > 0 && p.K >= nt_k && g_persist_ablate == 0)
+            return gemm_m16() ? launch_256p_abl<EPI, ACT, 4096 | 8192>(p, tiles_m, tiles_n, m_total, s)
+                              : launch_256p_abl<EPI, ACT, 4096>(p, tiles_m, tiles_n, m_total, s);
     }
+    if (gemm_m16() && g_persist_ablate == 0) return launch_256p_abl<EPI, ACT, 8192>(p, tiles_m, tiles_n, m_total, s);
     return launch_256p_abl<EPI, ACT, 0>(p, tiles_m, tiles_n, m_total, s);
 }
 template <int EPI>

@@ -14,6 +14,7 @@ bool gemm_has_pingpong();
 void gemm_x_set_trace(unsigned long long* ptr);
 #endif
 void gemm_set_ablate(int v);
+void gemm_set_m16(int v);
 int attn_occupancy(int S, int* out3);
 
 __global__ void probe_tr16_kernel(const bf16_t* __restrict__ src, const int32_t* __restrict__ offs,
@@ -276,6 +277,7 @@ extern "C" int rvlm_k_attn_set_use_tr(int on) { attn_set_use_tr(on); return RVLM
 extern "C" int rvlm_k_gemm_set_variant(int v) { gemm_set_variant(v); return RVLM_OK; }
 extern "C" int rvlm_k_gemm_last_kernels(void) { return gemm_last_kernels(); }
 extern "C" int rvlm_k_gemm_set_ablate(int v) { gemm_set_ablate(v); return RVLM_OK; }
+extern "C" int rvlm_k_gemm_set_m16(int v) { gemm_set_m16(v); return RVLM_OK; }
 extern "C" int rvlm_k_gemm_set_trace(void* ptr) { gemm_set_trace((unsigned long long*)ptr); return RVLM_OK; }
 // the shipped library does not contain the ping-pong kernel (make EXPERIMENTAL=1 builds it): a non-zero mask is refused
 extern "C" int rvlm_k_gemm_set_pingpong(int mask, int kmax) {
