@@ -55,8 +55,9 @@ int rvlm_k_gemm_x_set_trace(void* ptr);
 /* persistent kernel timing experiments (results become garbage): bit 0 no operand DMA, bit 1 no MFMA, bit 2 no LDS
  * fragment reads; 0 = normal */
 int rvlm_k_gemm_set_ablate(int v);
-/* MFMA shape of the persistent kernel's tile phase: 1 = v_mfma_f32_16x16x32_bf16 (8 x 4 accumulator tiles per wave), 0 =
- * v_mfma_f32_32x32x16_bf16 (4 x 2), -1 = environment / build default (RVLM_GEMM_M16).  Same results to fp32 summation order. */
+/* MFMA shape of the persistent kernel's tile phase: 1 = v_mfma_f32_16x16x32_bf16 (8 x 4 accumulator tiles per wave; the
+ * shipped form since round 4), 0 = v_mfma_f32_32x32x16_bf16 (4 x 2; EXPERIMENTAL builds only, RVLM_ERR_UNSUPPORTED otherwise),
+ * -1 = environment / build default (RVLM_GEMM_M16).  Same results to fp32 summation order. */
 int rvlm_k_gemm_set_m16(int v);
 /* measurement only: the persistent GEMM's operand request stream (same tile order, 8 waves x (4 + 4) pieces of 8 rows x
  * 128 B per K-step) with no MFMA and no LDS, `depth` K-steps (depth x 64 KiB per CU) in flight in registers.

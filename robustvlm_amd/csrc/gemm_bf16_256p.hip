@@ -29,8 +29,11 @@
 #include "gemm_strip.h"
 #include <type_traits>
 
+#ifndef RVLM_M16_SIDE_DEPTH
+#define RVLM_M16_SIDE_DEPTH 2        // side-input prefetch slots of the 16x16x32 form (4 in the 32x32x16 form), see SIDE_DEPTH below
+#endif
 #ifndef RVLM_GEMM_M16_DEFAULT
-#define RVLM_GEMM_M16_DEFAULT 0
+#define RVLM_GEMM_M16_DEFAULT 1      // the shipped MFMA shape since round 4: v_mfma_f32_16x16x32_bf16 (0: 32x32x16, EXPERIMENTAL builds)
 #endif
 
 namespace rvlm {
@@ -327,14 +330,22 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (loads && !(ABL & 4)) {
                     const int n = q * 4 + nt;          // position in the phase
-                    if (n == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(nx[0]) : "v"(aa));
-                    else if (n == 1) asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(nx[1]) : "v"(aa));
-                    else if (n == 2) asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(nx[2]) : "v"(aa));
-                    else if (n == 3) asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(nx[3]) : "v"(aa));
-                    else if (nh == 0 && n == 4) asm volatile("ds_read_b128 %0, %1" : "=v"(nw[0]) : "v"(bb));
-                    else if (nh == 0 && n == 5) asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(nw[1]) : "v"(bb));
-                    else if (nh == 0 && n == 6) asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(nw[2]) : "v"(bb));
-                    else if (nh == 0 && n == 7) asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(nw[3]) : "v"(bb));
+#ifndef RVLM_M16_READS_PER_SLOT
+#define RVLM_M16_READS_PER_SLOT 1
+#endif
+                    // fragment read r of the next phase (X: 0..3, W: 4..7) goes out behind MFMA r / RVLM_M16_READS_PER_SLOT
+                    auto rd = [&](int r) __attribute__((always_inline)) {
+                        if (r == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(nx[0]) : "v"(aa));
+                        else if (r == 1) asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(nx[1]) : "v"(aa));
+                        else if (r == 2) asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(nx[2]) : "v"(aa));
+                        else if (r == 3) asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(nx[3]) : "v"(aa));
+                        else if (nh == 0 && r == 4) asm volatile("ds_read_b128 %0, %1" : "=v"(nw[0]) : "v"(bb));
+                        else if (nh == 0 && r == 5) asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(nw[1]) : "v"(bb));
+                        else if (nh == 0 && r == 6) asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(nw[2]) : "v"(bb));
+                        else if (nh == 0 && r == 7) asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(nw[3]) : "v"(bb));
+                    };
+#pragma unroll
+                    for (int r = n * RVLM_M16_READS_PER_SLOT; r < (n + 1) * RVLM_M16_READS_PER_SLOT && r < 8; ++r) rd(r);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -413,11 +424,6 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
 
     i32x4 a0[4], b0[2], a1[4], b1[2];
     i32x4 w0[4], w1[4];          // M16: W fragments of the current / next 32-deep slice (a0 / a1 hold the X fragments of a phase)
-    // lane offsets of the epilogue's coalesced accesses (bytes); one instruction = 8 rows (16 for the 64-B rows)
-    const int st16_loff = ((lane >> 3) * ldo + (lane & 7) * 8) * 2;   // bf16: 128 B (64 columns) per row
-    const int st32_loff = ((lane >> 3) * ldo + (lane & 7) * 4) * 4;   // fp32: 128 B (32 columns) per row
-    const int h16_loff = ((lane >> 2) * ldo + (lane & 3) * 8) * 2;    // bf16 32-column sub-tile: 16 rows x 64 B per instruction
-    const int r0 = lane >> 3;                                         // flush: row r0 + 8*it, 16-B slot lane & 7
 
     auto stamp = [&](int ti, int k) {   // optional per-tile timeline (test hook rvlm_k_gemm_set_trace), wave 0 only
         if (!(ABL & (128 | 2048)) && p.trace && w == 0 && ti < 7) {
@@ -558,19 +564,38 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
         const int stage_slot = cb_slot;   // B slot of the tile's last stage = epilogue staging area after its barrier
         k_step(false, true);
 
+        // Lane constants of the epilogue, re-derived PER TILE from an opaque copy of the lane id (round 4): as kernel-scope
+        // constants hipcc kept ~15 of them (and sums it precomputes from them) live through the whole mainloop, where the
+        // 16x16x32 form has no register to spare - they were spilled and reloaded from scratch in every tile's epilogue, behind
+        // the stores (VMEM returns in order).  ~20 VALU per tile instead.
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const int l31 = lane_e & 31, hi = lane_e >> 5, i16 = lane_e & 15, G = lane_e >> 4;
+        // lane offsets of the epilogue's coalesced accesses (bytes); one instruction = 8 rows (16 for the 64-B rows)
+        const int st16_loff = ((lane_e >> 3) * ldo + (lane_e & 7) * 8) * 2;   // bf16: 128 B (64 columns) per row
+        const int st32_loff = ((lane_e >> 3) * ldo + (lane_e & 7) * 4) * 4;   // fp32: 128 B (32 columns) per row
+        const int h16_loff = ((lane_e >> 2) * ldo + (lane_e & 3) * 8) * 2;    // bf16 32-column sub-tile: 16 rows x 64 B per instruction
+        const int r0 = lane_e >> 3;                                           // flush: row r0 + 8*it, 16-B slot lane & 7
+
         float4 bv[2][4];
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-            for (int g = 0; g < 4; ++g)   // (a null bias has a zero-length descriptor: out-of-range loads return 0)
+            for (int g = 0; g < 4; ++g) {  // (a null bias has a zero-length descriptor: out-of-range loads return 0)
+                if (M16 && (g & 1)) continue;            // M16: bv[ni][g], g even = the 4 columns of n-tile 2 ni + (g >> 1); 4 vectors, not 8
                 bv[ni][g] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
-                    bias_rs, M16 ? G * 16 : hi * 16,     // M16: bv[ni][g] = the columns of n-tile 2 ni + (g >> 1) (g & 1 unused)
+                    bias_rs, M16 ? G * 16 : hi * 16,
                     __builtin_amdgcn_readfirstlane((n0 + wn * 64 + (M16 ? (2 * ni + (g >> 1)) * 16 : ni * 32 + 8 * g)) * 4), 0));
+            }
         // Side input of the epilogue (fp32 residual / bf16 h_pre), read in the SAME coalesced pattern as the output is
         // stored (after the LDS transpose) and prefetched SIDE_DEPTH 32x32 sub-tiles ahead: sub-tile s = 2*mi + ni lives
         // in side[s % SIDE_DEPTH].  The first ones are requested under the last MFMAs of the tile.
         const int m_base = m0 + wm * 128, n_base = n0 + wn * 64;
-        constexpr int SIDE_DEPTH = 4;
+        // (M16: 2 slots - behind the tile's last MFMAs the 16x16 form holds more live registers, and with 4 sub-tiles of side
+        // input in flight hipcc parked five of the twelve loads in scratch, each behind its own s_waitcnt vmcnt(0): an HBM
+        // round trip apiece, per tile.  Same-box micro-benchmark, 4 / 3 / 2 slots (us): out-proj forward 99.6 / 97.1 / 95.5, fc2
+        // forward 244.3 / 241.4 / 241.2, fc2 dgrad 272.2 / 273.2 / 269.1; the 32x32 form: 95.1 / 245.4 / 284.6)
+        constexpr int SIDE_DEPTH = M16 ? RVLM_M16_SIDE_DEPTH : 4;
         u32x4 side[SIDE_DEPTH][4];
         auto load_side = [&](int sub) {
             if (EPI == EPI_F32_RESID) {    // sub = 2*mi + ni: 32 rows x 128 B, 4 loads of 8 rows
@@ -613,8 +638,14 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
                 }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (EPI == EPI_F32_RESID) { load_side(1); load_side(2); load_side(3); }
-        if (EPI == EPI_BF16_DACT) { load_side(2); load_side(3); }
+        if (EPI == EPI_F32_RESID) {
+#pragma unroll
+            for (int sd = 1; sd < SIDE_DEPTH; ++sd) load_side(sd);
+        }
+        if (EPI == EPI_BF16_DACT) {
+#pragma unroll
+            for (int sd = 2; sd < SIDE_DEPTH; ++sd) load_side(sd);
+        }
         stamp(ti, 2);
 
         // ---- epilogue of (m0, n0): staging through the freed B slot, accumulators re-zeroed sub-tile by sub-tile ----
@@ -644,9 +675,9 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
         auto w32_addr = [&](int pc) -> unsigned {              // fp32, 32-column rows
             return M16 ? (w32n_pre ^ ((pc & 1) << 6)) + (pc >> 1) * 2048 : w32_pre ^ (pc << 5);
         };
-        const unsigned r16_a = ebuf + r0 * 128 + (((lane & 7) ^ (r0 >> 1)) << 4);       // bf16, it even
-        const unsigned r16_b = ebuf + r0 * 128 + (((lane & 7) ^ (r0 >> 1) ^ 4) << 4);   // bf16, it odd ((row & 15) >> 1 flips bit 2)
-        const unsigned r32 = ebuf + r0 * 128 + (((lane & 7) ^ r0) << 4);                // fp32 ((r0 + 8*it) & 7 == r0)
+        const unsigned r16_a = ebuf + r0 * 128 + (((lane_e & 7) ^ (r0 >> 1)) << 4);       // bf16, it even
+        const unsigned r16_b = ebuf + r0 * 128 + (((lane_e & 7) ^ (r0 >> 1) ^ 4) << 4);   // bf16, it odd ((row & 15) >> 1 flips bit 2)
+        const unsigned r32 = ebuf + r0 * 128 + (((lane_e & 7) ^ r0) << 4);                // fp32 ((r0 + 8*it) & 7 == r0)
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
             if (!OUT_F32) {
@@ -724,7 +755,7 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
                         init_acc(mi, ni);
                         // read back: 16 rows per instruction, 4 lanes x 16 B per row and output; lane -> row rr (+ 16), 16-B
                         // slot q of output `which`: 8-B chunks (which * 8 + 2 q, + 1) ^ (row & 15)
-                        const int rr = lane >> 2, q = lane & 3;
+                        const int rr = lane_e >> 2, q = lane_e & 3;
                         u32x2 rq[8];
 #pragma unroll
                         for (int which = 0; which < 2; ++which)
@@ -747,6 +778,7 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
                 } else {
                     // (forward-only callers - no backward to come - pass out_pre = null: act'(h) is then not written)
                     stage_flush(o_rs, EPI == EPI_BF16_ACT ? 1 : EPI == EPI_BF16_DACT ? 3 : 0);
+                    if (EPI == EPI_BF16_DACT && mi + SIDE_DEPTH < 4) load_side(mi + SIDE_DEPTH);   // (only with fewer than 4 slots)
                     init_acc(mi, 0);
                     init_acc(mi, 1);
                 }
@@ -817,10 +849,16 @@ void gemm_set_trace(unsigned long long* ptr) { g_persist_trace = ptr; }
 // MFMA shape of the tile phase: 1 = v_mfma_f32_16x16x32_bf16 (RVLM_GEMM_M16; rvlm_k_gemm_set_m16 for same-process A/Bs)
 static int g_m16 = -1;
 static bool gemm_m16() {
+#ifdef RVLM_EXPERIMENTAL_GEMM
     if (g_m16 < 0) { const char* e = getenv("RVLM_GEMM_M16"); g_m16 = e ? atoi(e) : RVLM_GEMM_M16_DEFAULT; }
     return g_m16 != 0;
+#else
+    return true;       // the shipped library instantiates the measured form only
+#endif
 }
+
 void gemm_set_m16(int v) { g_m16 = v; }
+bool gemm_has_m32() { return P_KNOBS; }
 
 template <int EPI, int ACT, int ABL>
 static int launch_256p_abl(const GemmBf16& p, int tiles_m, int tiles_n, int m_total, hipStream_t s) {
@@ -872,12 +910,17 @@ static int launch_256p_act(const GemmBf16& p, int tiles_m, int tiles_n, int m_to
         // fp32 output stored nt from K = 2048 on (profiles/r03_ab_nt_threshold.log; EXPERIMENTAL builds: RVLM_GEMM_NT_K, 0 = never)
         static int nt_k = -1;
         if (nt_k < 0) { const char* e = P_KNOBS ? getenv("RVLM_GEMM_NT_K") : nullptr; nt_k = e ? atoi(e) : 2048; }
-        if (nt_k > 0 && p.K >= nt_k && g_persist_ablate == 0)
-            return gemm_m16() ? launch_256p_abl<EPI, ACT, 4096 | 8192>(p, tiles_m, tiles_n, m_total, s)
-                              : launch_256p_abl<EPI, ACT, 4096>(p, tiles_m, tiles_n, m_total, s);
+        if (nt_k > 0 && p.K >= nt_k && g_persist_ablate == 0) {
+#ifdef RVLM_EXPERIMENTAL_GEMM
+            if (!gemm_m16()) return launch_256p_abl<EPI, ACT, 4096>(p, tiles_m, tiles_n, m_total, s);
+#endif
+            return launch_256p_abl<EPI, ACT, 4096 | 8192>(p, tiles_m, tiles_n, m_total, s);
+        }
     }
-    if (gemm_m16() && g_persist_ablate == 0) return launch_256p_abl<EPI, ACT, 8192>(p, tiles_m, tiles_n, m_total, s);
-    return launch_256p_abl<EPI, ACT, 0>(p, tiles_m, tiles_n, m_total, s);
+#ifdef RVLM_EXPERIMENTAL_GEMM            // the 32x32x16 form of the tile phase (rounds 1-3) is the A/B arm now
+    if (!gemm_m16() || g_persist_ablate != 0) return launch_256p_abl<EPI, ACT, 0>(p, tiles_m, tiles_n, m_total, s);
+#endif
+    return launch_256p_abl<EPI, ACT, 8192>(p, tiles_m, tiles_n, m_total, s);
 }
 template <int EPI>
 static int launch_256p(const GemmBf16& p, int tiles_m, int tiles_n, int m_total, hipStream_t s) {

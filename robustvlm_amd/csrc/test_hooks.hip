@@ -15,6 +15,7 @@ void gemm_x_set_trace(unsigned long long* ptr);
 #endif
 void gemm_set_ablate(int v);
 void gemm_set_m16(int v);
+bool gemm_has_m32();
 int attn_occupancy(int S, int* out3);
 
 __global__ void probe_tr16_kernel(const bf16_t* __restrict__ src, const int32_t* __restrict__ offs,
@@ -277,7 +278,12 @@ extern "C" int rvlm_k_attn_set_use_tr(int on) { attn_set_use_tr(on); return RVLM
 extern "C" int rvlm_k_gemm_set_variant(int v) { gemm_set_variant(v); return RVLM_OK; }
 extern "C" int rvlm_k_gemm_last_kernels(void) { return gemm_last_kernels(); }
 extern "C" int rvlm_k_gemm_set_ablate(int v) { gemm_set_ablate(v); return RVLM_OK; }
-extern "C" int rvlm_k_gemm_set_m16(int v) { gemm_set_m16(v); return RVLM_OK; }
+extern "C" int rvlm_k_gemm_set_m16(int v) {
+    if (v == 0 && !gemm_has_m32())
+        return fail(RVLM_ERR_UNSUPPORTED, "rvlm_k_gemm_set_m16: this build holds the 16x16x32 form only (make EXPERIMENTAL=1)");
+    gemm_set_m16(v);
+    return RVLM_OK;
+}
 extern "C" int rvlm_k_gemm_set_trace(void* ptr) { gemm_set_trace((unsigned long long*)ptr); return RVLM_OK; }
 // the shipped library does not contain the ping-pong kernel (make EXPERIMENTAL=1 builds it): a non-zero mask is refused
 extern "C" int rvlm_k_gemm_set_pingpong(int mask, int kmax) {

@@ -20,7 +20,9 @@ def pingpong():
     if l.rvlm_k_gemm_set_pingpong(31, 1 << 30) != 0:
         pytest.skip("librvlm.so was built without the experimental ping-pong kernel (make EXPERIMENTAL=1)")
     l.rvlm_k_gemm_set_variant(3)
+    l.rvlm_k_gemm_set_m16(0)            # the ping-pong kernel is bit-identical with the 32x32x16 form of the persistent kernel
     yield l
+    l.rvlm_k_gemm_set_m16(-1)
     l.rvlm_k_gemm_set_pingpong(-1, -1)
     l.rvlm_k_gemm_set_variant(-1)
 
