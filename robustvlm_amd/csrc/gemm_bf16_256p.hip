@@ -29,6 +29,9 @@
 #include "gemm_strip.h"
 #include <type_traits>
 
+#ifndef RVLM_M16_LAST_PHASE_INPLACE
+#define RVLM_M16_LAST_PHASE_INPLACE 1
+#endif
 #ifndef RVLM_M16_SIDE_DEPTH
 #define RVLM_M16_SIDE_DEPTH 2        // side-input prefetch slots of the 16x16x32 form (4 in the 32x32x16 form), see SIDE_DEPTH below
 #endif
@@ -320,16 +323,32 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
         int oa = sa * PA_SLOT, ob = sb * PB_SLOT + ab_delta;
         asm volatile("" : "+s"(oa), "+s"(ob));
         const unsigned aa = fa16[nks] + oa + nh * 8192, bb = fa16[nks] + ob;
+#ifndef RVLM_M16_ORDER
+#define RVLM_M16_ORDER 0            // 0: m-tile outer, n-tile inner (consecutive MFMAs share the X fragment); 1: the other way round
+#endif
+#ifndef RVLM_M16_READ_STRIDE
+#define RVLM_M16_READ_STRIDE 1      // a fragment read behind every RVLM_M16_READ_STRIDE-th MFMA
+#endif
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int o = 0; o < 4; ++o)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                if (!(ABL & 2))
+            for (int in = 0; in < 4; ++in) {
+                const int q = RVLM_M16_ORDER ? in : o, nt = RVLM_M16_ORDER ? o : in;
+                if (!(ABL & 2)) {
+#if RVLM_M16_LAST_PHASE_INPLACE
+                    // the tile's LAST phase (no fragment reads): accumulate in place by construction.  Outside the K loop hipcc gives
+                    // the builtin's result fresh registers (D != C), 64 of them over the phase, right where the epilogue's
+                    // side-input prefetch wants its registers - it then parked side loads (or accumulators) in scratch.
+                    if (!loads) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc16[M16 ? 4 * h + q : 0][M16 ? nt : 0])
+                                             : "v"(wf[nt]), "v"(x[q]));
+                    else
+#endif
                     acc16[M16 ? 4 * h + q : 0][M16 ? nt : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                         __builtin_bit_cast(bf16x8, wf[nt]), __builtin_bit_cast(bf16x8, x[q]), acc16[M16 ? 4 * h + q : 0][M16 ? nt : 0], 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
-                if (loads && !(ABL & 4)) {
-                    const int n = q * 4 + nt;          // position in the phase
+                if (loads && !(ABL & 4) && ((o * 4 + in) % RVLM_M16_READ_STRIDE) == 0) {
+                    const int n = (o * 4 + in) / RVLM_M16_READ_STRIDE;          // position in the phase
 #ifndef RVLM_M16_READS_PER_SLOT
 #define RVLM_M16_READS_PER_SLOT 1
 #endif
@@ -591,10 +610,10 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
         // stored (after the LDS transpose) and prefetched SIDE_DEPTH 32x32 sub-tiles ahead: sub-tile s = 2*mi + ni lives
         // in side[s % SIDE_DEPTH].  The first ones are requested under the last MFMAs of the tile.
         const int m_base = m0 + wm * 128, n_base = n0 + wn * 64;
-        // (M16: 2 slots - behind the tile's last MFMAs the 16x16 form holds more live registers, and with 4 sub-tiles of side
-        // input in flight hipcc parked five of the twelve loads in scratch, each behind its own s_waitcnt vmcnt(0): an HBM
-        // round trip apiece, per tile.  Same-box micro-benchmark, 4 / 3 / 2 slots (us): out-proj forward 99.6 / 97.1 / 95.5, fc2
-        // forward 244.3 / 241.4 / 241.2, fc2 dgrad 272.2 / 273.2 / 269.1; the 32x32 form: 95.1 / 245.4 / 284.6)
+        // (M16: 2 slots.  Before the tile's last phase accumulated in place (RVLM_M16_LAST_PHASE_INPLACE) hipcc parked five of the
+        // twelve side loads of 4 slots in scratch, each behind its own s_waitcnt vmcnt(0) - an HBM round trip apiece, per tile;
+        // with the in-place phase nothing spills at any depth and 2 / 3 / 4 slots measure within 0.3 % of each other end to end
+        // (278.0 / 277.5 / 277.4 img/s on one box, profiles/r04_ab_mfma16_inplace.log): the shallowest one ships)
         constexpr int SIDE_DEPTH = M16 ? RVLM_M16_SIDE_DEPTH : 4;
         u32x4 side[SIDE_DEPTH][4];
         auto load_side = [&](int sub) {
@@ -614,8 +633,12 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
         if (EPI == EPI_F32_RESID) load_side(0);                            // a0/b0 are dead
         if (EPI == EPI_BF16_DACT) { load_side(0); load_side(1); }
         __builtin_amdgcn_sched_barrier(0);
-        if (M16) mma16_phase(a1, w1, 1, false, 0, 0, 0, 0, a0, w0);
-        else mma(a1, b1);
+        if (M16) {
+            mma16_phase(a1, w1, 1, false, 0, 0, 0, 0, a0, w0);
+#if RVLM_M16_LAST_PHASE_INPLACE
+            asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");     // inline-asm MFMAs: the VALU reads below need their wait states by hand
+#endif
+        } else mma(a1, b1);
         __builtin_amdgcn_sched_barrier(0);
         // bias joins the accumulators here, so that its registers are free for the side-input prefetch
         if (M16) {
