@@ -334,18 +334,9 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
 #pragma unroll
             for (int in = 0; in < 4; ++in) {
                 const int q = RVLM_M16_ORDER ? in : o, nt = RVLM_M16_ORDER ? o : in;
-                if (!(ABL & 2)) {
-#if RVLM_M16_LAST_PHASE_INPLACE
-                    // the tile's LAST phase (no fragment reads): accumulate in place by construction.  Outside the K loop hipcc gives
-                    // the builtin's result fresh registers (D != C), 64 of them over the phase, right where the epilogue's
-                    // side-input prefetch wants its registers - it then parked side loads (or accumulators) in scratch.
-                    if (!loads) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc16[M16 ? 4 * h + q : 0][M16 ? nt : 0])
-                                             : "v"(wf[nt]), "v"(x[q]));
-                    else
-#endif
+                if (!(ABL & 2))
                     acc16[M16 ? 4 * h + q : 0][M16 ? nt : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                         __builtin_bit_cast(bf16x8, wf[nt]), __builtin_bit_cast(bf16x8, x[q]), acc16[M16 ? 4 * h + q : 0][M16 ? nt : 0], 0, 0, 0);
-                }
                 __builtin_amdgcn_sched_barrier(0);
                 if (loads && !(ABL & 4) && ((o * 4 + in) % RVLM_M16_READ_STRIDE) == 0) {
                     const int n = (o * 4 + in) / RVLM_M16_READ_STRIDE;          // position in the phase
@@ -634,9 +625,18 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
         if (EPI == EPI_BF16_DACT) { load_side(0); load_side(1); }
         __builtin_amdgcn_sched_barrier(0);
         if (M16) {
-            mma16_phase(a1, w1, 1, false, 0, 0, 0, 0, a0, w0);
 #if RVLM_M16_LAST_PHASE_INPLACE
-            asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");     // inline-asm MFMAs: the VALU reads below need their wait states by hand
+            // The tile's LAST phase (no fragment reads) sits in a loop of (opaque) trip count 1: the accumulators are then
+            // loop-carried and the MFMAs accumulate in place, as in the K loop.  As straight-line code hipcc gave every result of
+            // the phase fresh registers (D != C, 64 of them over the phase) right where the epilogue's side-input prefetch wants
+            // its registers, and parked side loads - or accumulators, behind s_nop 7 each - in scratch.  (Inline-asm MFMAs with
+            // "+v" do the same but hide the MFMA -> VALU wait states from the compiler: a spill it placed behind one read garbage.)
+            int once = 1;
+            asm volatile("" : "+s"(once));
+#pragma unroll 1
+            for (int rep = 0; rep < once; ++rep) mma16_phase(a1, w1, 1, false, 0, 0, 0, 0, a0, w0);
+#else
+            mma16_phase(a1, w1, 1, false, 0, 0, 0, 0, a0, w0);
 #endif
         } else mma(a1, b1);
         __builtin_amdgcn_sched_barrier(0);
