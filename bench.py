@@ -150,8 +150,9 @@ def cpu_baseline(iterations_full=10, l14_sample=True):
 PEAK_HBM_TBPS = 8.0         # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md (6.3 TB/s achievable)
 
 
-def hbm_classes(prof: dict, cfg, B: int) -> dict:
-    """Roofline objects of the HBM-bound kernel classes of one profiled pgd() call."""
+def hbm_classes(prof: dict, cfg, B: int, traffic: dict | None = None) -> dict:
+    """Roofline objects of the HBM-bound kernel classes of one profiled pgd() call; `traffic` (bytes per launch, fabric side:
+    2 x FETCH_SIZE + WRITE_SIZE of the in-run PMC passes) when it was measured, else null."""
     S = (cfg.image_size // cfg.patch) ** 2 + 1
     per_launch = {"attn_fwd": 4.0 * B * cfg.heads * S * 64 * 2, "attn_bwd": 8.0 * B * cfg.heads * S * 64 * 2}
     out = {}
@@ -163,7 +164,8 @@ def hbm_classes(prof: dict, cfg, B: int) -> dict:
         tbps = nbytes / (v["ms"] * 1e-3) / 1e12
         out[k] = {"bound": "hbm", "achieved": tbps, "peak": PEAK_HBM_TBPS, "unit": "TB/s", "frac": tbps / PEAK_HBM_TBPS,
                   "bytes_per_launch": nbytes / v["launches"], "avg_launch_us": 1e3 * v["ms"] / v["launches"],
-                  "launches": v["launches"], "ms_per_step": round(v["ms"], 3)}
+                  "launches": v["launches"], "ms_per_step": round(v["ms"], 3),
+                  "traffic": (traffic or {}).get(k)}
     return out
 
 
@@ -234,6 +236,15 @@ def pmc_in_run(argv_child, timeout_s=240):
             pmc["mfma_busy"][k] = round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (v["GRBM_GUI_ACTIVE"] / 8.0), 4)
         if v.get("SQ_LDS_IDX_ACTIVE"):
             pmc["lds_conflict_share"][k] = round(v.get("SQ_LDS_BANK_CONFLICT", 0.0) / v["SQ_LDS_IDX_ACTIVE"], 4)
+    # fabric-side bytes per launch of the HBM-bound classes, from the same two passes (for roofline.hbm_classes[*].traffic)
+    cls = {"attn_fwd": "attn_fwd_odd_kernel", "attn_bwd": "attn_bwd_fused_kernel", "layernorm_fwd": "layernorm_fwd8_kernel",
+           "layernorm_bwd": "layernorm_bwd8_kernel"}
+    pmc["hbm_class_traffic"] = {}
+    for name, pat in cls.items():
+        ks = [k for k in agg if pat in k and launches[k]]
+        if ks:
+            n = sum(launches[k] for k in ks)
+            pmc["hbm_class_traffic"][name] = round(sum((2.0 * agg[k].get("FETCH_SIZE", 0.0) + agg[k].get("WRITE_SIZE", 0.0)) * 1024.0 for k in ks) / n)
     return round(total / logical), info, pmc
 
 
@@ -617,7 +628,7 @@ def main():
             # the HBM-bound quarter of the step against ITS roofline: algorithmic bytes / HIP-event time / 8 TB/s
             # (attention: q, k, v in + o out forward; q, k, v, o, dO in + dq, dk, dv out backward, bf16; LayerNorm: the
             # byte counts the engine's profile scopes carry - 6 B per element forward, 16 B backward)
-            "hbm_classes": hbm_classes(prof, cfg, B),
+            "hbm_classes": hbm_classes(prof, cfg, B, (pmc or {}).get("hbm_class_traffic")),
             "per_class": {k: {"ms": round(v["ms"], 3), "launches": v["launches"],
                               "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 and v["flops"] > 0 else None,
                               "gbps": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 and v["bytes"] > 0 else None}
