@@ -323,39 +323,26 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
         int oa = sa * PA_SLOT, ob = sb * PB_SLOT + ab_delta;
         asm volatile("" : "+s"(oa), "+s"(ob));
         const unsigned aa = fa16[nks] + oa + nh * 8192, bb = fa16[nks] + ob;
-#ifndef RVLM_M16_ORDER
-#define RVLM_M16_ORDER 0            // 0: m-tile outer, n-tile inner (consecutive MFMAs share the X fragment); 1: the other way round
-#endif
-#ifndef RVLM_M16_READ_STRIDE
-#define RVLM_M16_READ_STRIDE 1      // a fragment read behind every RVLM_M16_READ_STRIDE-th MFMA
-#endif
+        // (measured and not kept, profiles/r04_ab_mfma16_*.log: two reads per slot, a read behind every second MFMA, n-tile-outer order)
 #pragma unroll
-        for (int o = 0; o < 4; ++o)
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int in = 0; in < 4; ++in) {
-                const int q = RVLM_M16_ORDER ? in : o, nt = RVLM_M16_ORDER ? o : in;
+            for (int nt = 0; nt < 4; ++nt) {
                 if (!(ABL & 2))
                     acc16[M16 ? 4 * h + q : 0][M16 ? nt : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                         __builtin_bit_cast(bf16x8, wf[nt]), __builtin_bit_cast(bf16x8, x[q]), acc16[M16 ? 4 * h + q : 0][M16 ? nt : 0], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (loads && !(ABL & 4) && ((o * 4 + in) % RVLM_M16_READ_STRIDE) == 0) {
-                    const int n = (o * 4 + in) / RVLM_M16_READ_STRIDE;          // position in the phase
-#ifndef RVLM_M16_READS_PER_SLOT
-#define RVLM_M16_READS_PER_SLOT 1
-#endif
-                    // fragment read r of the next phase (X: 0..3, W: 4..7) goes out behind MFMA r / RVLM_M16_READS_PER_SLOT
-                    auto rd = [&](int r) __attribute__((always_inline)) {
-                        if (r == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(nx[0]) : "v"(aa));
-                        else if (r == 1) asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(nx[1]) : "v"(aa));
-                        else if (r == 2) asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(nx[2]) : "v"(aa));
-                        else if (r == 3) asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(nx[3]) : "v"(aa));
-                        else if (nh == 0 && r == 4) asm volatile("ds_read_b128 %0, %1" : "=v"(nw[0]) : "v"(bb));
-                        else if (nh == 0 && r == 5) asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(nw[1]) : "v"(bb));
-                        else if (nh == 0 && r == 6) asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(nw[2]) : "v"(bb));
-                        else if (nh == 0 && r == 7) asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(nw[3]) : "v"(bb));
-                    };
-#pragma unroll
-                    for (int r = n * RVLM_M16_READS_PER_SLOT; r < (n + 1) * RVLM_M16_READS_PER_SLOT && r < 8; ++r) rd(r);
+                if (loads && !(ABL & 4)) {
+                    // fragment read r of the next phase (X: 0..3, W: 4..7) goes out behind MFMA r of this one
+                    const int r = q * 4 + nt;
+                    if (r == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(nx[0]) : "v"(aa));
+                    else if (r == 1) asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(nx[1]) : "v"(aa));
+                    else if (r == 2) asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(nx[2]) : "v"(aa));
+                    else if (r == 3) asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(nx[3]) : "v"(aa));
+                    else if (nh == 0 && r == 4) asm volatile("ds_read_b128 %0, %1" : "=v"(nw[0]) : "v"(bb));
+                    else if (nh == 0 && r == 5) asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(nw[1]) : "v"(bb));
+                    else if (nh == 0 && r == 6) asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(nw[2]) : "v"(bb));
+                    else if (nh == 0 && r == 7) asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(nw[3]) : "v"(bb));
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
