@@ -83,6 +83,9 @@ int rvlm_k_probe_tr16(const uint16_t* src, const int32_t* offs, uint16_t* out, r
 size_t rvlm_k_wgrad_work_bytes(int M, int N, int K);
 int rvlm_k_wgrad_bf16(const uint16_t* dY, long lddy, const uint16_t* X, long ldx, int M, int N, int K, float* dW,
                       long lddw, int accumulate, float* dbias, void* work, size_t work_bytes, rvlm_stream_t stream);
+/* 1: rvlm_k_wgrad_bf16 runs the form the training step used until round 4 (token-chunk transposes + NT GEMM) instead of the
+ * copy-free contraction-major GEMM - the A/B arm of tests and benches; 0 (default): the training step's path. */
+void rvlm_k_wgrad_set_transposed(int v);
 
 #ifdef __cplusplus
 }

@@ -176,6 +176,7 @@ _SIGS = {
                                            C.c_int, C.c_int, c_stream]),
     "rvlm_k_probe_tr16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_stream]),
     "rvlm_k_wgrad_work_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "rvlm_k_wgrad_set_transposed": (None, [C.c_int]),
     "rvlm_k_wgrad_bf16": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, c_f32p,
                                     C.c_long, C.c_int, c_f32p, C.c_void_p, C.c_size_t, c_stream]),
 }

@@ -66,7 +66,8 @@ struct rvlm_vit {
     bool inference_only = false;
     std::vector<void*> ln1_out, ln2_out, g_act_l;   // L x [Mp,W], [Mp,W], [Mp,4W] T
     float *tokens, *dtok;      // [Mp, W] f32
-    void *tA, *tB;             // bf16 mode: [4W, Mpt] transposed operands of the wgrad GEMMs
+    void *tA, *tB;             // bf16 mode: [4W, Mpt] transposed operands of the wgrad GEMMs the copy-free form does not take
+                               // (conv1, widths that are no multiple of 256, fewer than 256 tokens)
     long Mpt = 0;
     // attack state
     float* img_buf[5];         // [maxB*3*img*img]
@@ -617,15 +618,15 @@ static int wgrad(rvlm_vit* h, hipStream_t s, const void* dY, long lddy, const vo
 template <>
 int wgrad<bf16_t>(rvlm_vit* h, hipStream_t s, const void* dY, long lddy, const void* X, long ldx, int M, int N,
                   int K, float* dW, long lddw, int accumulate, float* dbias) {
-    // contraction over the token dimension: both operands are transposed so that it is the contiguous (MFMA k)
-    // dimension.  Encoder shapes: token chunks [splits][.][Kc] + one batched launch of the persistent kernel.
+    // contraction over the token dimension.  Encoder shapes: the persistent kernel's contraction-major form reads dY and X as the
+    // backward left them (token-major), split-K over token chunks in one batched launch - no transposed copies.
     int rc, splits = 0, Kc = 0;
-    if (wgrad_split_plan(M, N, K, h->splitk_bytes, &splits, &Kc) && (long)splits * Kc <= h->Mpt) {
-        if ((rc = transpose_split((const bf16_t*)dY, lddy, M, N, (bf16_t*)h->tA, Kc, splits, dbias, accumulate, h->red_scratch,
-                                  h->red_floats, s))) return rc;
-        if ((rc = transpose_split((const bf16_t*)X, ldx, M, K, (bf16_t*)h->tB, Kc, splits, nullptr, 0, nullptr, 0, s))) return rc;
-        return gemm_bf16_wgrad_split((const bf16_t*)h->tA, (const bf16_t*)h->tB, splits, Kc, N, K, dW, lddw, accumulate,
-                                     h->splitk_scratch, h->splitk_bytes, s);
+    if (wgrad_split_plan(M, N, K, h->splitk_bytes, &splits, &Kc) && lddy % 8 == 0 && ldx % 8 == 0 &&
+        (((size_t)dY | (size_t)X) & 15) == 0) {
+        if (dbias && (rc = colsum<bf16_t>((const bf16_t*)dY, lddy, M, N, dbias, accumulate, h->red_scratch, h->red_floats, s)))
+            return rc;
+        return gemm_bf16_wgrad_tn((const bf16_t*)dY, lddy, (const bf16_t*)X, ldx, M, splits, Kc, N, K, dW, lddw, accumulate,
+                                  h->splitk_scratch, h->splitk_bytes, s);
     }
     // other shapes (conv1: K = 3*P*P): whole-K transposes zero-padded to a multiple of 64, NT GEMM as usual
     if (dbias && (rc = colsum<bf16_t>((const bf16_t*)dY, lddy, M, N, dbias, accumulate, h->red_scratch, h->red_floats, s)))
@@ -885,7 +886,7 @@ extern "C" int rvlm_vit_create(const rvlm_vit_config* cfg, const rvlm_vit_weight
         ALLOC_OR_DIE(h->tokens, Mp * W * 4);
         ALLOC_OR_DIE(h->dtok, Mp * W * 4);
         if (h->bf16) {
-            h->Mpt = (long)Mp + 16 * 128;   // token chunks of the split-K weight gradient: up to 16 x Kc
+            h->Mpt = (long)Mp + 16 * 128;
             const size_t rows = (size_t)std::max(4 * W, h->Kpad);
             ALLOC_OR_DIE(h->tA, rows * h->Mpt * 2);
             ALLOC_OR_DIE(h->tB, rows * h->Mpt * 2);

@@ -324,6 +324,34 @@ int gemm_bf16_wgrad_split(const bf16_t* tA, const bf16_t* tB, int splits, int Kc
     return RVLM_OK;
 }
 
+// Weight gradient without operand copies: the persistent kernel's contraction-major form (gemm_bf16_256p.hip, TN) reads dY and X
+// token-major as the backward left them; split-K over token chunks of Kc (the tail chunk's rows beyond M read as zero), fp32
+// slabs, deterministic reduce.
+int gemm_bf16_wgrad_tn(const bf16_t* dY, long lddy, const bf16_t* X, long ldx, int M, int splits, int Kc, int N, int K, float* dW,
+                       long lddw, int accumulate, float* slab, size_t slab_bytes, hipStream_t s) {
+    if (!slab || (size_t)splits * N * K * sizeof(float) > slab_bytes)
+        return fail(RVLM_ERR_STATE, "gemm_bf16_wgrad_tn: slab scratch too small");
+    if ((long)splits * Kc < M) return fail(RVLM_ERR_ARG, "gemm_bf16_wgrad_tn: the token chunks do not cover M");
+    GemmBf16 g;
+    g.A = dY; g.lda = lddy; g.Bw = X; g.ldb = ldx;
+    g.M = splits * N; g.N = K; g.K = Kc;
+    g.batch_m_rows = N; g.tn = 1; g.k_rows = M;
+    g.epi = EPI_F32; g.out = slab; g.ldo = K;
+    int done = 0;
+    int rc = gemm_bf16_nt_256p(g, &done, s);
+    if (rc) return rc;
+    if (done != g.M) return fail(RVLM_ERR_UNSUPPORTED, "gemm_bf16_wgrad_tn: shape not covered by the persistent kernel");
+    GemmBf16 r;
+    r.M = N; r.N = K; r.out = dW; r.ldo = lddw; r.residual = accumulate ? dW : nullptr;
+    const int rb = cdiv((long)N * (K / 4), 256);
+    if (accumulate)
+        hipLaunchKernelGGL((splitk_reduce_kernel<EPI_F32_RESID>), dim3(rb), dim3(256), 0, s, slab, splits, r);
+    else
+        hipLaunchKernelGGL((splitk_reduce_kernel<EPI_F32>), dim3(rb), dim3(256), 0, s, slab, splits, r);
+    RVLM_CHECK_LAUNCH();
+    return RVLM_OK;
+}
+
 int gemm_bf16_nt(const GemmBf16& p, hipStream_t s) {
     if (!p.A || !p.Bw || !p.out || p.M <= 0 || p.N <= 0 || p.K <= 0)
         return fail(RVLM_ERR_ARG, "gemm_bf16_nt: bad arguments");

@@ -50,6 +50,22 @@ constexpr bool P_KNOBS = true;
 constexpr bool P_KNOBS = false;
 #endif
 
+// Contraction-major form: both transposing reads of one fragment - tile t (its pair index XORed into the per-lane base + slot
+// address `base`) of the 32-deep slice ks.  (A namespace-scope function: as a lambda called from the kernel's other lambdas it
+// made hipcc drop the instantiation's host stub.)
+static __device__ __forceinline__ void tr_frag(unsigned base, int t, int ks, i32x4& out) {
+    const unsigned ad = base ^ (unsigned)(t << 5);
+    i32x2 lo, hi2;
+    if (ks == 0) {
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(ad));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(hi2) : "v"(ad));
+    } else {
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:16384" : "=v"(lo) : "v"(ad));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:18432" : "=v"(hi2) : "v"(ad));
+    }
+    out = i32x4{lo[0], lo[1], hi2[0], hi2[1]};
+}
+
 template <int EPI, int ACT, int ABL>
 __global__ void __launch_bounds__(512)
 gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
@@ -80,6 +96,15 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
     // 2 slices of 32 x 2 halves of 4 m-tiles = 4 phases of 16 MFMAs (the 32x32 form: 4 slices of 8 MFMAs); accumulator layout:
     // tile (mt, nt), lane (i16 = lane & 15, G = lane >> 4) holds row m = 16 mt + i16, columns n = 16 nt + 4 G + {0..3}.
     constexpr bool M16 = (ABL & 8192) != 0;
+    // Operand layout (round 4, the weight-gradient GEMM of the training step).  ABL & 16384 ("TN"): both operands are stored
+    // CONTRACTION-major - A = dY[k][m] (ld = lda), Bw = X[k][n] (ld = ldb), k = token - and C[m][n] = sum_k A[k][m] Bw[k][n] is
+    // computed from them as they lie: a stage's LDS image is [64 k][256 rows] (512-B k-rows, the 32-B pairs of a k-row XORed with
+    // f(k) = (k & 3) | ((k >> 3) & 1) << 2), filled by the same 16-B-per-lane DMA (one instruction = 2 k-rows x 512 B, fully
+    // coalesced) and read through ds_read_b64_tr_b16 (2 per fragment: a 16-lane group gathers [4 k][16 rows] -> lane = row, 4 k
+    // each), so the token-chunk transposes the NT form needs in front (9 ms per training step) are gone.  Batched form: batch b =
+    // k-rows [b K, (b+1) K) (zero beyond k_rows: buffer range check), output rows [b batch_m_rows, ...).  M16, SPLIT roles only.
+    constexpr bool TN = (ABL & 16384) != 0;
+    static_assert(!TN || (M16 && (ABL & (256 | 8)) == 0), "TN: 16x16x32 split-role form only");
     constexpr int NPIECE = SPLIT ? 8 : 4;      // DMA pieces per wave and operand half
     // Fragment reads between the MFMAs of the previous k-slice (2 ds_read_b128 after each of its first three MFMAs)
     // instead of 6 in a row between two groups of 8 MFMAs: with the role split each wave runs alone on its SIMD while
@@ -121,11 +146,12 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
 
     // buffer descriptors (wave-uniform, built from kernel arguments only): every global access below is
     // descriptor + 32-bit lane offset (VGPR, constant for the whole kernel) + 32-bit scalar offset
-    const auto a_rs = make_rsrc(p.A, (unsigned)((p.M - 1) * lda + p.K) * 2u);
+    const int tn_cols = p.batch_m_rows > 0 ? p.batch_m_rows : p.M;        // TN: columns of A = output rows per batch
+    const auto a_rs = make_rsrc(p.A, TN ? (unsigned)((p.k_rows - 1) * lda + tn_cols) * 2u : (unsigned)((p.M - 1) * lda + p.K) * 2u);
     // batched form (batch_m_rows > 0, the split-K weight-gradient GEMM): rows [b*batch_m_rows, (b+1)*batch_m_rows) of A
     // meet rows [b*N, (b+1)*N) of Bw; the output keeps A's row index (a stack of per-batch [batch_m_rows, N] slabs)
     const int nbatch = p.batch_m_rows > 0 ? p.M / p.batch_m_rows : 1;
-    const auto b_rs = make_rsrc(p.Bw, (unsigned)((nbatch * p.N - 1) * ldb + p.K) * 2u);
+    const auto b_rs = make_rsrc(p.Bw, TN ? (unsigned)((p.k_rows - 1) * ldb + p.N) * 2u : (unsigned)((nbatch * p.N - 1) * ldb + p.K) * 2u);
     auto b_row0 = [&](int m0, int n0) { return p.batch_m_rows > 0 ? n0 + (m0 / p.batch_m_rows) * p.N : n0; };
     const unsigned out_elems = (unsigned)((p.M - 1) * ldo + p.N);
     const auto o_rs = make_rsrc(p.out, out_elems * (OUT_F32 ? 4u : 2u));
@@ -167,15 +193,33 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
         b_loff[jp] = ((lane >> 3) * ldb + clog * 8) * 2;
     }
     const int wrow = SPLIT ? (w & 3) * 64 : w * 32;     // first row (of each 256-row half) this wave requests
-    const int stage_wave_off = wrow * 128;
+    // TN: wave (w & 3) = 2 b + r1 requests k-rows 32 a + 16 a' + 8 b + 4 c + 2 r1 + {0, 1} (piece j = 4 a + 2 a' + c; lanes 0-31 the
+    // even row, 32-63 the odd one), so f(k) = (lane >> 5) | (w & 3) << 1 is one constant per lane: slot chunk z = lane & 31 of a
+    // k-row holds logical 16-B chunk (((z >> 1) ^ f) << 1) | (z & 1) (the XOR stays inside the 256-B bank row: f < 8)
+    const int tn_kw = 8 * ((w & 3) >> 1) + 2 * (w & 1);
+    if (TN) {
+        const int z = lane & 31, f = (lane >> 5) | ((w & 3) << 1);
+        const int clog = (((z >> 1) ^ f) << 1) | (z & 1);
+        a_loff[0] = a_loff[1] = ((lane >> 5) * lda + clog * 8) * 2;
+        b_loff[0] = b_loff[1] = ((lane >> 5) * ldb + clog * 8) * 2;
+    }
+    const int stage_wave_off = TN ? tn_kw * 512 : wrow * 128;
+    // (the helpers below are macros: as lambdas called from the role lambdas they made hipcc drop every instantiation's host stub)
+    // byte offset of a tile's operand block, this wave's share folded in (NT: row block; TN: column block + the batch's k-rows)
+#define RVLM_A_TILE_OFF(m0) (TN ? (((m0) % tn_cols) + (((m0) / tn_cols) * p.K + tn_kw) * lda) * 2 : ((m0) + wrow) * lda * 2)
+#define RVLM_B_TILE_OFF(m0, n0) (TN ? ((n0) + (((m0) / tn_cols) * p.K + tn_kw) * ldb) * 2 : (b_row0(m0, n0) + wrow) * ldb * 2)
+    // piece j of a stage: LDS offset inside the wave's share / global offset (K-step kt); TN k-row of piece j: 32 a + 16 a' + 4 c
+#define RVLM_PIECE_KROW(j) (32 * ((j) >> 2) + 16 * (((j) >> 1) & 1) + 4 * ((j) & 1))
+#define RVLM_PIECE_LDS(j) (TN ? RVLM_PIECE_KROW(j) * 512 : (j) * 1024)
+#define RVLM_PIECE_GOFF(j, kt, ld) (TN ? ((kt) * P_K + RVLM_PIECE_KROW(j)) * (ld) * 2 : (kt) * (P_K * 2) + (j) * 16 * (ld))
     // cursors: next stage to request = K-step a_kt of this workgroup's tile number a_ti (likewise b_*)
     int a_ti = 0, a_kt = 0, a_soff = 0, a_slot = 0;
     int b_ti = 0, b_kt = 0, b_soff = 0, b_slot = 0;
     {
         int m0, n0;
         tile_origin(blockIdx.x, m0, n0);
-        a_soff = (m0 + wrow) * lda * 2;
-        b_soff = (b_row0(m0, n0) + wrow) * ldb * 2;
+        a_soff = RVLM_A_TILE_OFF(m0);
+        b_soff = RVLM_B_TILE_OFF(m0, n0);
     }
     // experiment (ABL & 8): the same operand stream as plain buffer_load_dwordx4 into registers (folded into a sink one
     // K-step later) - compares the VGPR return path of the texture unit with the LDS-DMA path
@@ -195,8 +239,8 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
         __attribute__((address_space(3))) char* dst =
             (__attribute__((address_space(3))) char*)lds + (a_slot * PA_SLOT + stage_wave_off);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
-            a_rs, (lds_ptr_t)(dst + j * 1024), 16, a_loff[j & 1],
-            __builtin_amdgcn_readfirstlane(a_soff + (a_kt + k0 >= nk ? a_kt + k0 - nk : a_kt + k0) * (P_K * 2) + j * 16 * lda), 0, 0);
+            a_rs, (lds_ptr_t)(dst + RVLM_PIECE_LDS(j)), 16, a_loff[j & 1],
+            __builtin_amdgcn_readfirstlane(a_soff + RVLM_PIECE_GOFF(j, (a_kt + k0 >= nk ? a_kt + k0 - nk : a_kt + k0), lda)), 0, 0);
     };
     auto a_advance = [&]() __attribute__((always_inline)) -> bool {
         if (a_ti >= ntw) return false;
@@ -206,7 +250,7 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
             if (++a_ti < ntw) {
                 int m0, n0;
                 tile_origin(blockIdx.x + a_ti * gridDim.x, m0, n0);
-                a_soff = (m0 + wrow) * lda * 2;
+                a_soff = RVLM_A_TILE_OFF(m0);
             }
         }
         return true;
@@ -216,8 +260,8 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
         __attribute__((address_space(3))) char* dst =
             (__attribute__((address_space(3))) char*)lds + (PB_BASE + b_slot * PB_SLOT + stage_wave_off);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
-            b_rs, (lds_ptr_t)(dst + j * 1024), 16, b_loff[j & 1],
-            __builtin_amdgcn_readfirstlane(b_soff + (b_kt + k0 >= nk ? b_kt + k0 - nk : b_kt + k0) * (P_K * 2) + j * 16 * ldb), 0, 0);
+            b_rs, (lds_ptr_t)(dst + RVLM_PIECE_LDS(j)), 16, b_loff[j & 1],
+            __builtin_amdgcn_readfirstlane(b_soff + RVLM_PIECE_GOFF(j, (b_kt + k0 >= nk ? b_kt + k0 - nk : b_kt + k0), ldb)), 0, 0);
     };
     auto b_advance = [&]() __attribute__((always_inline)) -> bool {
         if (b_ti >= ntw) return false;
@@ -227,7 +271,7 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
             if (++b_ti < ntw) {
                 int m0, n0;
                 tile_origin(blockIdx.x + b_ti * gridDim.x, m0, n0);
-                b_soff = (b_row0(m0, n0) + wrow) * ldb * 2;
+                b_soff = RVLM_B_TILE_OFF(m0, n0);
             }
         }
         return true;
@@ -294,11 +338,24 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) fa16[ks] = lds_base + (wm * 128 + i16) * 128 + (((ks * 4 + G) ^ ((i16 >> 1) & 7)) << 4);
     f32x4 acc16[M16 ? 8 : 1][M16 ? 4 : 1];
+    // TN: lane (i16, G) of a fragment of slice ks holds row (tile) + i16, k = 32 ks + 8 G + 0..7 = two transposing reads (k-rows
+    // 32 ks + 8 G + 4 hh + (i16 >> 2), hh = 0 / 1: +2048 B), each lane pointing at the 8 bytes (i16 & 3) of its k-row's 32-B
+    // pair p ^ f(k), p = the tile's pair index (A: 8 wm + t, B: 4 wn + nt), f(k) = (i16 >> 2) | (G & 1) << 2 - independent of
+    // ks / hh / tile, so tile t is one v_xor of (t << 5) into the per-lane base and (ks, hh) are immediates.  A 32-lane half
+    // (two groups G) reads 8 k-rows x 32 B at 8 different pair positions of the 256-B bank row: conflict-free.
+    const unsigned tr_lane = (8 * G + (i16 >> 2)) * 512 + (i16 & 3) * 8 + (((i16 >> 2) | ((G & 1) << 2)) << 5);
+    const unsigned trA = lds_base + (tr_lane ^ (wm * 256));
+    const unsigned trB = lds_base + PB_BASE + (tr_lane ^ (wn * 128));
     // X fragments (activation rows) of m-tiles 4 h .. 4 h + 3 of slice ks
     auto load_x16 = [&](int sa, int ks, int h, i32x4 (&x)[4]) __attribute__((always_inline)) {
         if (ABL & 4) return;
         int oa = sa * PA_SLOT;
         asm volatile("" : "+s"(oa));
+        if (TN) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tr_frag(trA + oa, 4 * h + q, ks, x[q]);
+            return;
+        }
         const unsigned aa = fa16[ks] + oa + h * 8192;
         asm volatile("ds_read_b128 %0, %1" : "=v"(x[0]) : "v"(aa));
         asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(x[1]) : "v"(aa));
@@ -308,8 +365,13 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
     // W fragments (weight rows) of the wave's 4 n-tiles of slice ks
     auto load_w16 = [&](int sb, int ks, i32x4 (&wf)[4]) __attribute__((always_inline)) {
         if (ABL & 4) return;
-        int ob = sb * PB_SLOT + ab_delta;
+        int ob = sb * PB_SLOT + (TN ? 0 : ab_delta);
         asm volatile("" : "+s"(ob));
+        if (TN) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) tr_frag(trB + ob, nt, ks, wf[nt]);
+            return;
+        }
         const unsigned bb = fa16[ks] + ob;
         asm volatile("ds_read_b128 %0, %1" : "=v"(wf[0]) : "v"(bb));
         asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(wf[1]) : "v"(bb));
@@ -320,9 +382,9 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
     // behind each of the first MFMAs (nks, nh: the next phase; its W fragments only when it opens a new slice)
     auto mma16_phase = [&](const i32x4 (&x)[4], const i32x4 (&wf)[4], int h, bool loads, int sa, int sb, int nks, int nh,
                            i32x4 (&nx)[4], i32x4 (&nw)[4]) __attribute__((always_inline)) {
-        int oa = sa * PA_SLOT, ob = sb * PB_SLOT + ab_delta;
+        int oa = sa * PA_SLOT, ob = sb * PB_SLOT + (TN ? 0 : ab_delta);
         asm volatile("" : "+s"(oa), "+s"(ob));
-        const unsigned aa = fa16[nks] + oa + nh * 8192, bb = fa16[nks] + ob;
+        const unsigned aa = TN ? trA + oa : fa16[nks] + oa + nh * 8192, bb = TN ? trB + ob : fa16[nks] + ob;
         // (measured and not kept, profiles/r04_ab_mfma16_*.log: two reads per slot, a read behind every second MFMA, n-tile-outer order)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -335,6 +397,10 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
                 if (loads && !(ABL & 4)) {
                     // fragment read r of the next phase (X: 0..3, W: 4..7) goes out behind MFMA r of this one
                     const int r = q * 4 + nt;
+                    if (TN) {            // both transposing reads of a fragment behind one MFMA
+                        if (r < 4) tr_frag(aa, 4 * nh + r, nks, nx[r]);
+                        else if (nh == 0 && r < 8) tr_frag(bb, r - 4, nks, nw[r - 4]);
+                    } else
                     if (r == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(nx[0]) : "v"(aa));
                     else if (r == 1) asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(nx[1]) : "v"(aa));
                     else if (r == 2) asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(nx[2]) : "v"(aa));
@@ -849,6 +915,12 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
     }
 }
 
+#undef RVLM_A_TILE_OFF
+#undef RVLM_B_TILE_OFF
+#undef RVLM_PIECE_KROW
+#undef RVLM_PIECE_LDS
+#undef RVLM_PIECE_GOFF
+
 int g_persist_ablate = 0;
 // (shipped library: the ablation kernels are not instantiated - any value other than 0 is ignored)
 void gemm_set_ablate(int v) { g_persist_ablate = P_KNOBS ? v : 0; }
@@ -946,6 +1018,20 @@ int gemm_bf16_nt_256p(const GemmBf16& p, int* rows_done, hipStream_t s) {
     if (p.M < P_M || p.N % P_N != 0 || p.K % (2 * P_K) != 0 || p.K < 2 * P_K) return RVLM_OK;
     // buffer descriptors address with 32-bit offsets
     const long lim = 1L << 31;
+    if (p.tn) {
+        // contraction-major operands (weight gradient): fp32 slabs only, whole 256-row batches, 16-B aligned k-rows
+        if (p.epi != EPI_F32 || p.batch_m_rows <= 0 || p.batch_m_rows % P_M != 0 || p.M % p.batch_m_rows != 0 || p.k_rows <= 0 ||
+            p.lda % 8 != 0 || p.ldb % 8 != 0)
+            return fail(RVLM_ERR_ARG, "gemm_bf16_nt_256p: contraction-major form needs epi F32, batch_m_rows % 256, k_rows, ld % 8");
+        if ((long)p.k_rows * p.lda * 2 >= lim || (long)p.k_rows * p.ldb * 2 >= lim || (long)p.M * p.ldo * 4 >= lim ||
+            (long)(p.M / p.batch_m_rows) * p.K * std::max(p.lda, p.ldb) * 2 >= lim) return RVLM_OK;
+        GemmBf16 q = p;
+        q.stagger = 0; q.wave_prio = 0; q.krot = 0; q.group_m = 4;
+        int rc = launch_256p_abl<EPI_F32, RVLM_ACT_QUICK_GELU, 8192 | 16384>(q, p.M / P_M, p.N / P_N, p.M, s);
+        if (rc) return rc;
+        *rows_done = p.M;
+        return RVLM_OK;
+    }
     if ((long)p.M * p.lda * 2 >= lim || (long)p.N * p.ldb * 2 >= lim || (long)p.M * p.ldo * 4 >= lim) return RVLM_OK;
     if (p.batch_m_rows > 0) {
         if (p.batch_m_rows % P_M != 0 || p.M % p.batch_m_rows != 0)

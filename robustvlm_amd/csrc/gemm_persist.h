@@ -7,6 +7,7 @@
 namespace rvlm {
 
 typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(2))) int i32x2;
 
 constexpr int P_M = 256, P_N = 256, P_K = 64;
 constexpr int P_OPER_BYTES = P_M * P_K * 2;      // 32 KiB per operand per stage

@@ -58,6 +58,9 @@ struct GemmBf16 {
     int krot = 0;                       // persistent kernel only: K-step rotation per workgroup (RVLM_GEMM_KROT experiment)
     int batch_m_rows = 0;               // persistent kernel only, > 0: batched form - rows [b*batch_m_rows, ...) of A meet
                                         // rows [b*N, (b+1)*N) of Bw (the split-K weight-gradient GEMM, gemm_bf16_wgrad)
+    int tn = 0;                         // persistent kernel only, 1: CONTRACTION-major operands - A = [k_rows][lda] (columns = output
+    int k_rows = 0;                     // rows of a batch), Bw = [k_rows][ldb] (columns = output columns); batch b contracts k-rows
+                                        // [b*K, (b+1)*K), rows >= k_rows read as zero (gemm_bf16_wgrad_tn)
 };
 int gemm_bf16_nt(const GemmBf16& p, hipStream_t s);
 // default routing to the phase-shifted persistent kernel (gemm_bf16_256x.hip): epilogue-kind mask and K limit, from
@@ -157,6 +160,9 @@ int transpose_pad(const T* in, long ldi, int R, int C, T* out, long ldo, int Rp,
 int wgrad_split_plan(int M, int N, int K, size_t slab_bytes, int* splits, int* Kc);
 int transpose_split(const bf16_t* in, long ldi, int R, int C, bf16_t* out, int Kc, int splits, float* dbias,
                     int accumulate, float* red, size_t red_floats, hipStream_t s);
+// the same from the operands AS THEY LIE (dY [M, N] ld lddy, X [M, K] ld ldx, token-major): no transposed copies
+int gemm_bf16_wgrad_tn(const bf16_t* dY, long lddy, const bf16_t* X, long ldx, int M, int splits, int Kc, int N, int K, float* dW,
+                       long lddw, int accumulate, float* slab, size_t slab_bytes, hipStream_t s);
 int gemm_bf16_wgrad_split(const bf16_t* tA, const bf16_t* tB, int splits, int Kc, int N, int K, float* dW, long lddw,
                           int accumulate, float* slab, size_t slab_bytes, hipStream_t s);
 // `red` / `red_floats`: caller-owned scratch for the partial column sums (no process-wide state)

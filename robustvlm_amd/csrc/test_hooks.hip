@@ -318,6 +318,7 @@ extern "C" int rvlm_k_probe_tr16(const uint16_t* src, const int32_t* offs, uint1
 }
 extern "C" int rvlm_k_attn_occupancy(int S, int* out3) { return attn_occupancy(S, out3); }
 
+static int g_wgrad_transposed = 0;
 // dW[N,K] (+)= dY[M,N]^T X[M,K], dbias[N] (+)= column sums of dY, on the split-K path of the training step.  `work` is a
 // caller-provided device buffer of rvlm_k_wgrad_work_bytes(M, N, K) bytes (token-chunk operands, fp32 slabs, partials).
 extern "C" size_t rvlm_k_wgrad_work_bytes(int M, int N, int K) {
@@ -337,8 +338,16 @@ extern "C" int rvlm_k_wgrad_bf16(const uint16_t* dY, long lddy, const uint16_t* 
     if ((size_t)(w - (char*)work) + slab_bytes > work_bytes) return fail(RVLM_ERR_ARG, "rvlm_k_wgrad_bf16: work buffer too small");
     int rc = RVLM_OK;
     if (!wgrad_split_plan(M, N, K, slab_bytes, &splits, &Kc)) rc = fail(RVLM_ERR_UNSUPPORTED, "rvlm_k_wgrad_bf16: N, K % 256, M >= 256");
-    if (!rc) rc = transpose_split((const bf16_t*)dY, lddy, M, N, tA, Kc, splits, dbias, accumulate, red, redf, (hipStream_t)stream);
-    if (!rc) rc = transpose_split((const bf16_t*)X, ldx, M, K, tB, Kc, splits, nullptr, 0, nullptr, 0, (hipStream_t)stream);
-    if (!rc) rc = gemm_bf16_wgrad_split(tA, tB, splits, Kc, N, K, dW, lddw, accumulate, slab, slab_bytes, (hipStream_t)stream);
+    if (g_wgrad_transposed) {       // the token-chunk transposes + NT form the training step used until round 4 (A/B arm)
+        if (!rc) rc = transpose_split((const bf16_t*)dY, lddy, M, N, tA, Kc, splits, dbias, accumulate, red, redf, (hipStream_t)stream);
+        if (!rc) rc = transpose_split((const bf16_t*)X, ldx, M, K, tB, Kc, splits, nullptr, 0, nullptr, 0, (hipStream_t)stream);
+        if (!rc) rc = gemm_bf16_wgrad_split(tA, tB, splits, Kc, N, K, dW, lddw, accumulate, slab, slab_bytes, (hipStream_t)stream);
+        return rc;
+    }
+    // the training step's path (engine.hip wgrad<bf16_t>): column sums + the contraction-major persistent GEMM on the operands as they lie
+    if (!rc && dbias) rc = colsum<bf16_t>((const bf16_t*)dY, lddy, M, N, dbias, accumulate, red, redf, (hipStream_t)stream);
+    if (!rc) rc = gemm_bf16_wgrad_tn((const bf16_t*)dY, lddy, (const bf16_t*)X, ldx, M, splits, Kc, N, K, dW, lddw, accumulate, slab,
+                                     slab_bytes, (hipStream_t)stream);
     return rc;
 }
+extern "C" void rvlm_k_wgrad_set_transposed(int v) { g_wgrad_transposed = v; }

@@ -4,6 +4,7 @@
 // positional / class-embedding gradients) and the AdamW update.  HBM-bound helpers; the wgrad FLOPs
 // themselves run on gemm_bf16_nt (contraction over the token dimension on transposed operands).
 #include "kernels.h"
+#include <type_traits>
 
 namespace rvlm {
 
@@ -169,10 +170,44 @@ ln_param_partial_kernel(const T* __restrict__ dy, long lddy, const float* __rest
         pb[(long)blockIdx.y * C + c] = (rb[0][t] + rb[1][t]) + (rb[2][t] + rb[3][t]);
     }
 }
+// bf16 rows of C % 256 == 0 columns, 16-B aligned (the linear layers' dY next to the copy-free weight-gradient GEMM): 16 B per
+// lane - a workgroup = 32 column groups of 8 x 8 row lanes, each lane 8 fp32 sums over its rows, LDS sum over the row lanes.
+__global__ void __launch_bounds__(256)
+colsum8_partial_kernel(const bf16_t* __restrict__ in, long ld, int R, int C, float* __restrict__ partial) {
+    __shared__ float red[8][256 + 8];
+    const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 256 + cg * 8;
+    const int rows_per = (R + gridDim.y - 1) / gridDim.y;
+    const int r0 = blockIdx.y * rows_per, r1 = min(R, r0 + rows_per);
+    float acc[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 4
+    for (int r = r0 + rl; r < r1; r += 8) {
+        const uint4 v = *(const uint4*)(in + (long)r * ld + c);
+        const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc[2 * i] += __uint_as_float(u[i] << 16);
+            acc[2 * i + 1] += __uint_as_float(u[i] & 0xffff0000u);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[rl][cg * 8 + i] = acc[i];
+    __syncthreads();
+    const int t = threadIdx.x;
+    partial[(long)blockIdx.y * C + blockIdx.x * 256 + t] =
+        ((red[0][t] + red[1][t]) + (red[2][t] + red[3][t])) + ((red[4][t] + red[5][t]) + (red[6][t] + red[7][t]));
+}
 template <typename T>
 int colsum(const T* in, long ld, int R, int C, float* out, int accumulate, float* red, size_t red_floats, hipStream_t s) {
     const int nch = R >= 4096 ? RED_NCH : (R >= 256 ? 16 : 1);
     if (!red || (size_t)nch * C > red_floats) return fail(RVLM_ERR_STATE, "colsum: no reduce scratch");
+    if (std::is_same<T, bf16_t>::value && C % 256 == 0 && ld % 8 == 0 && ((size_t)in & 15) == 0) {
+        hipLaunchKernelGGL(colsum8_partial_kernel, dim3(C / 256, nch), dim3(256), 0, s, (const bf16_t*)in, ld, R, C, red);
+        RVLM_CHECK_LAUNCH();
+        hipLaunchKernelGGL(reduce_partials16_kernel, dim3(cdiv(C, 16)), dim3(256), 0, s, red, nch, C, out, accumulate);
+        RVLM_CHECK_LAUNCH();
+        return RVLM_OK;
+    }
     hipLaunchKernelGGL((colsum_partial_kernel<T>), dim3(cdiv(C, 64), nch), dim3(256), 0, s, in, ld, R, C, red);
     RVLM_CHECK_LAUNCH();
     hipLaunchKernelGGL(reduce_partials16_kernel, dim3(cdiv(C, 16)), dim3(256), 0, s, red, nch, C, out, accumulate);

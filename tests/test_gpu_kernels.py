@@ -265,16 +265,29 @@ def test_gemm_bf16_splitk_remainder(K):
         lib().rvlm_k_gemm_set_variant(-1)
 
 
+@pytest.fixture(params=[0, 1], ids=["copy_free", "transposed"])
+def wgrad_form(request):
+    """0: the training step's weight-gradient path (column sums + contraction-major persistent GEMM on the token-major operands);
+    1: the token-chunk transposes + NT GEMM it replaced (kept as the A/B arm)."""
+    lib().rvlm_k_wgrad_set_transposed(request.param)
+    yield request.param
+    lib().rvlm_k_wgrad_set_transposed(0)
+
+
 @pytest.mark.parametrize("M,N,K", [(257 * 7, 256, 256), (257 * 24, 512, 256), (257 * 24, 256, 1024), (300, 768, 256),
-                                   (257 * 128, 1024, 1024)])
-def test_wgrad_split_vs_fp32(M, N, K):
-    """Split-K weight gradient of the training step (token-chunk transposes with the fused bias gradient + batched
-    persistent GEMM + slab reduce) against an fp64 matmul of the same bf16 operands; strided operands (column
-    slices of wider buffers, as dqkv / the MLP activations are) and accumulate on top."""
+                                   (257 * 128, 1024, 1024), (257 * 9, 1024, 3072), (50 * 33, 768, 768)])
+def test_wgrad_split_vs_fp32(M, N, K, wgrad_form):
+    """Split-K weight gradient of the training step (bias gradient + batched persistent GEMM over token chunks + slab
+    reduce) against an fp64 matmul of the same bf16 operands; strided operands (column slices of wider buffers, as
+    dqkv / the MLP activations are), token counts that are no multiple of the 64-token K-step (the tail chunk's rows
+    beyond M must read as zero, whatever follows the operands in memory) and accumulate on top."""
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
-    dYw = torch.randn(M, N + 64, generator=g, device=dev()).bfloat16()
-    Xw = torch.randn(M, K + 8, generator=g, device=dev()).bfloat16()
-    dY, X = dYw[:, :N], Xw[:, :K]
+    # the operands sit inside larger buffers of NaN: a read of any element that is not theirs poisons the result
+    dYw = torch.full((M + 4096, N + 64), float("nan"), device=dev()).bfloat16()
+    Xw = torch.full((M + 4096, K + 8), float("nan"), device=dev()).bfloat16()
+    dYw[:M, :N] = torch.randn(M, N, generator=g, device=dev()).bfloat16()
+    Xw[:M, :K] = torch.randn(M, K, generator=g, device=dev()).bfloat16()
+    dY, X = dYw[:M, :N], Xw[:M, :K]
     ref = dY.double().t() @ X.double()
     refb = dY.double().sum(0)
     nb = lib().rvlm_k_wgrad_work_bytes(M, N, K)
