@@ -621,6 +621,17 @@ int wgrad<bf16_t>(rvlm_vit* h, hipStream_t s, const void* dY, long lddy, const v
     // contraction over the token dimension.  Encoder shapes: the persistent kernel's contraction-major form reads dY and X as the
     // backward left them (token-major), split-K over token chunks in one batched launch - no transposed copies.
     int rc, splits = 0, Kc = 0;
+#ifdef RVLM_EXPERIMENTAL_GEMM     // A/B arm (make EXPERIMENTAL=1, RVLM_WGRAD_TRANSPOSED=1): the token-chunk transposes + NT GEMM of round 3
+    static int transposed = -1;
+    if (transposed < 0) { const char* e = getenv("RVLM_WGRAD_TRANSPOSED"); transposed = e ? atoi(e) : 0; }
+    if (transposed && wgrad_split_plan(M, N, K, h->splitk_bytes, &splits, &Kc) && (long)splits * Kc <= h->Mpt) {
+        if ((rc = transpose_split((const bf16_t*)dY, lddy, M, N, (bf16_t*)h->tA, Kc, splits, dbias, accumulate, h->red_scratch,
+                                  h->red_floats, s))) return rc;
+        if ((rc = transpose_split((const bf16_t*)X, ldx, M, K, (bf16_t*)h->tB, Kc, splits, nullptr, 0, nullptr, 0, s))) return rc;
+        return gemm_bf16_wgrad_split((const bf16_t*)h->tA, (const bf16_t*)h->tB, splits, Kc, N, K, dW, lddw, accumulate,
+                                     h->splitk_scratch, h->splitk_bytes, s);
+    }
+#endif
     if (wgrad_split_plan(M, N, K, h->splitk_bytes, &splits, &Kc) && lddy % 8 == 0 && ldx % 8 == 0 &&
         (((size_t)dY | (size_t)X) & 15) == 0) {
         if (dbias && (rc = colsum<bf16_t>((const bf16_t*)dY, lddy, M, N, dbias, accumulate, h->red_scratch, h->red_floats, s)))
