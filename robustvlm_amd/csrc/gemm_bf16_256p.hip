@@ -951,7 +951,13 @@ static int launch_256p_abl(const GemmBf16& p, int tiles_m, int tiles_n, int m_to
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return fail(RVLM_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
     });
-    const int grid = std::min(tiles_m * tiles_n, 256);
+    int max_wg = 256;
+#ifdef RVLM_EXPERIMENTAL_GEMM      // experiment: fewer workgroups than CUs (two half-batch pipelines side by side, scripts/two_stream_probe.py)
+    static int e_max_wg = -1;
+    if (e_max_wg < 0) { const char* e = getenv("RVLM_GEMM_MAX_WG"); e_max_wg = e ? std::max(8, atoi(e)) : 256; }
+    max_wg = e_max_wg;
+#endif
+    const int grid = std::min(tiles_m * tiles_n, max_wg);
     GemmBf16 q = p;
     q.trace = g_persist_trace;
     hipLaunchKernelGGL((gemm_bf16_nt_256p_kernel<EPI, ACT, ABL>), dim3(grid), dim3(512), lds_bytes, s, q, tiles_m, tiles_n, m_total);
