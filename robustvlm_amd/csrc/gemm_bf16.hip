@@ -329,6 +329,24 @@ int gemm_bf16_wgrad_split(const bf16_t* tA, const bf16_t* tB, int splits, int Kc
 // slabs, deterministic reduce.
 int gemm_bf16_wgrad_tn(const bf16_t* dY, long lddy, const bf16_t* X, long ldx, int M, int splits, int Kc, int N, int K, float* dW,
                        long lddw, int accumulate, float* slab, size_t slab_bytes, hipStream_t s) {
+    // The kernel addresses its operands with 32-bit byte offsets: token ranges beyond 2 GiB of either operand go in row chunks, the
+    // later ones accumulating (dY and X are token-major, so a chunk is a pointer offset; the slabs are reused in stream order).
+    const long row_bytes = 2 * std::max(lddy, ldx);
+    const long addressable = ((1L << 31) - 1) / row_bytes;                    // k-rows a launch can reach (its last chunk is padded)
+    const long max_rows = (addressable - 17 * 128) / 256 * 256;                // chunk size: its padded split stays addressable
+    if ((long)splits * Kc > addressable) {
+        if (max_rows < 256) return fail(RVLM_ERR_UNSUPPORTED, "gemm_bf16_wgrad_tn: leading dimension too large");
+        for (long r0 = 0; r0 < M; r0 += max_rows) {
+            const int rows = (int)std::min<long>(max_rows, M - r0);
+            int sp = 0, kc = 0;
+            if (!wgrad_split_plan(std::max(rows, 256), N, K, slab_bytes, &sp, &kc))       // (a tail of < 256 tokens: one zero-padded chunk)
+                return fail(RVLM_ERR_UNSUPPORTED, "gemm_bf16_wgrad_tn: N, K % 256");
+            int rc = gemm_bf16_wgrad_tn(dY + r0 * lddy, lddy, X + r0 * ldx, ldx, rows, sp, kc, N, K, dW, lddw, r0 > 0 ? 1 : accumulate, slab,
+                                        slab_bytes, s);
+            if (rc) return rc;
+        }
+        return RVLM_OK;
+    }
     if (!slab || (size_t)splits * N * K * sizeof(float) > slab_bytes)
         return fail(RVLM_ERR_STATE, "gemm_bf16_wgrad_tn: slab scratch too small");
     if ((long)splits * Kc < M) return fail(RVLM_ERR_ARG, "gemm_bf16_wgrad_tn: the token chunks do not cover M");

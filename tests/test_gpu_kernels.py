@@ -314,6 +314,28 @@ def test_wgrad_split_vs_fp32(M, N, K, wgrad_form):
     assert torch.equal(dW2, dW3)
 
 
+def test_wgrad_operand_beyond_2gib():
+    """The weight-gradient GEMM addresses its operands with 32-bit byte offsets; an operand whose token range spans more than
+    2 GiB (here: a column slice of a [70 000, 16 384] buffer) goes in row chunks that accumulate."""
+    M, N, K, ld = 70000, 256, 256, 16384
+    g = torch.Generator(device="cuda").manual_seed(5)
+    dYw = torch.empty(M, ld, dtype=torch.bfloat16, device=dev())            # 2.3 GB; only the slice is read
+    dYw[:, :N] = torch.randn(M, N, generator=g, device=dev()).bfloat16()
+    X = torch.randn(M, K, generator=g, device=dev()).bfloat16()
+    dY = dYw[:, :N]
+    ref = dY.double().t() @ X.double()
+    refb = dY.double().sum(0)
+    nb = lib().rvlm_k_wgrad_work_bytes(M, N, K)
+    work = torch.empty(nb, dtype=torch.uint8, device=dev())
+    dW = torch.full((N, K), 7.0, device=dev())
+    db = torch.full((N,), 7.0, device=dev())
+    L.check(lib().rvlm_k_wgrad_bf16(dY.data_ptr(), ld, X.data_ptr(), K, M, N, K, dW.data_ptr(), K, 0, db.data_ptr(),
+                                    work.data_ptr(), nb, st()), "wgrad")
+    torch.cuda.synchronize()
+    assert rel_max(dW, ref) < 3e-5
+    assert rel_max(db, refb) < 3e-5
+
+
 @pytest.mark.parametrize("r", [32, 100, 128, 255])
 @pytest.mark.parametrize("N,K", [(512, 128), (3072, 1024), (1024, 4096)])
 def test_gemm_bf16_remainder_rows_in_launch(r, N, K):
