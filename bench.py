@@ -31,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_F32_MFMA_TFLOPS = 157.3   # fp32-input MFMA (= the fp32 vector peak), same guide: --precision fp32 runs are priced against it
 FLOP_PER_IMG_ITER = {"ViT-L-14": 330.545e9, "ViT-B-32": 17.728e9}   # SURVEY.md Appendix C (fwd + input-bwd)
 
 
@@ -42,7 +43,9 @@ def parse():
     ap.add_argument("--model", default="ViT-L-14")
     ap.add_argument("--batch", type=int, default=128, help="images per GPU per step")
     ap.add_argument("--iterations", type=int, default=10)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16+fp32-first"],
+                    help="bf16: the throughput path (headline); fp32: the reference's own precision on the fp32 matrix-pipe tiles; "
+                         "bf16+fp32-first: pgd with its first iteration (and the clean embedding) in fp32")
     ap.add_argument("--attack", default="pgd", choices=["pgd", "apgd", "autopgd", "square"],
                     help="pgd: BASELINE configs 2/4 (FARE); apgd: config 3 (TeCoA apgd_train); autopgd: config 5 "
                          "(APGDAttack CE on the zero-shot head, use --iterations 100 --batch 256); square: the black-box "
@@ -147,6 +150,8 @@ def cpu_baseline(iterations_full=10, l14_sample=True):
     return out
 
 
+REHEARSAL_NOTE = ("RVLM_BENCH_REHEARSAL=gloo: the ranks of this job share GPU(s) and meet over gloo - the line proves the "
+                  "world > 1 code path (self-launch, process group, barriers, gather of per-rank times), it is NOT a measurement")
 PEAK_HBM_TBPS = 8.0         # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md (6.3 TB/s achievable)
 
 
@@ -262,7 +267,7 @@ def _baseline_config_name(attack: str, world: int, per_gpu_batch: int) -> str:
     return f"BASELINE configs[1] per GPU x {world} ranks: a point of the 1/2/4/8 curve that ends at configs[3]"
 
 
-def bench_train(args, R, cfg, sd, dev, dist, world, rank):
+def bench_train(args, R, cfg, sd, dev, dist, world, rank, coll_dev=None, rehearsal=""):
     """Full training step (the 'next' row of SURVEY.md 8(f)): reported separately from the headline metric."""
     from robustvlm_amd.trainer import AdversarialTrainer
     B = args.batch
@@ -284,7 +289,7 @@ def bench_train(args, R, cfg, sd, dev, dist, world, rank):
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        t = torch.tensor([el], device=coll_dev if coll_dev is not None else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     barrier()
@@ -292,7 +297,7 @@ def bench_train(args, R, cfg, sd, dev, dist, world, rank):
     ar = tr.profile_allreduce(x) if tr._reduce else None
     if rank == 0:
         print(json.dumps({
-            "allreduce": ar,
+            "allreduce": ar, **({"rehearsal": REHEARSAL_NOTE} if rehearsal else {}),
             "metric": f"FARE training images/sec ({args.model}, {args.iterations}-step {args.attack} + optimizer step)",
             "value": world * B * args.steps / el, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak",
@@ -390,15 +395,21 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
     # `python bench.py --gpus N` without a launcher creates its N ranks itself (and exits with their exit code);
     # under a launcher (WORLD_SIZE set) this process is one rank and --gpus must agree with it
-    from robustvlm_amd.launch import ensure_ranks
+    from robustvlm_amd.launch import ensure_ranks, rehearsal_backend
     plan = ensure_ranks(args.gpus)
     world = plan.world
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device(f"cuda:{local_rank}")
-    affinity = bind_rank_to_numa(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
+    # RVLM_BENCH_REHEARSAL=gloo (robustvlm_amd/launch.py): the world > 1 branch on a node with fewer GPUs than ranks - rank r
+    # on device r mod n, gloo instead of RCCL.  Exercises every line below except the RCCL-only ones;
+    # its JSON line says so and is not a measurement.
+    rehearsal = rehearsal_backend(os.environ) if world > 1 else ""
+    dev_index = local_rank % torch.cuda.device_count() if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device(f"cuda:{dev_index}")
+    affinity = bind_rank_to_numa(dev_index, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     dist = None
+    coll_dev = dev                     # device of the tensors handed to the metric collectives (gloo: host)
     if world > 1 or (args.mode == "train" and args.always_reduce):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -407,22 +418,30 @@ def main():
             with socket.socket() as sk:                      # one-rank group (--always-reduce): any free local port
                 sk.bind(("127.0.0.1", 0))
                 os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            coll_dev = torch.device("cpu")
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import robustvlm_amd as R
     cfg = R.CONFIGS[args.model]
     sd = R.random_state_dict(cfg, seed=0, device=dev)           # same weights on every rank
     B = args.batch
     if args.mode == "train":
-        return bench_train(args, R, cfg, sd, dev, dist, world, rank)
+        return bench_train(args, R, cfg, sd, dev, dist, world, rank, coll_dev, rehearsal)
     eng = R.VitEngine(cfg, sd, precision=args.precision, max_batch=args.batch, device=dev)
     del sd
     model = R.ClipVisionModel(eng).eval()
-    g = torch.Generator(device=dev).manual_seed(1000 + rank)   # each rank its own shard of images
+    # x = torch.rand seed 0, delta0 ~ U(-eps, eps) seed 1, y = randint seed 2 - drawn by the DEVICE generator
+    # (the parity tests draw the same seeds on the CPU generator: other streams, the same distribution), + 1000 * rank so
+    # that every rank holds its own shard of images
+    seeds = {"x": 0 + 1000 * rank, "delta0": 1 + 1000 * rank, "y": 2 + 1000 * rank}
+    g = torch.Generator(device=dev).manual_seed(seeds["x"])
     x = torch.rand(B, 3, cfg.image_size, cfg.image_size, generator=g, device=dev)
     eps, stepsize = 4 / 255, 1 / 255
-    d0 = (torch.rand(x.shape, generator=g, device=dev) * 2 - 1) * eps
-    y = torch.randint(0, 1000, (B,), generator=g, device=dev)
+    d0 = (torch.rand(x.shape, generator=torch.Generator(device=dev).manual_seed(seeds["delta0"]), device=dev) * 2 - 1) * eps
+    y = torch.randint(0, 1000, (B,), generator=torch.Generator(device=dev).manual_seed(seeds["y"]), device=dev)
     e0 = model(x, args.attack == "apgd")                        # embedding_orig (…clip.py:296-297)
     if args.attack == "pgd":
         wrap = R.ComputeLossWrapper(e0, None, "mean", "l2", 100.)
@@ -467,6 +486,8 @@ def main():
 
     for _ in range(args.warmup):
         out = step()
+    if os.environ.get("RVLM_BENCH_DIE_RANK") == str(rank):      # test hook: a rank that dies mid-job (tests/test_gpu_bench_entry.py)
+        os._exit(17)
     barrier()
     # the timed region: exactly --steps calls between two barrier + synchronize pairs, nothing else running in this process
     # (the rocm-smi clock sampler of round 3 now polls during extra UNTIMED steps below).  Device-side events between the
@@ -488,7 +509,7 @@ def main():
             torch.cuda.synchronize()
     per_rank_s = [el]
     if dist is not None:
-        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        t = torch.tensor([el], device=coll_dev, dtype=torch.float64)
         allt = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(allt, t)
         per_rank_s = [float(v.item()) for v in allt]
@@ -519,7 +540,8 @@ def main():
                                     f"1000-class zero-shot head, batch={B} per GPU (clip_robustbench.py --blackbox_only route; "
                                     f"forward passes only, samples leave the batch once fooled)"),
                        "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world} (no data-path collective)",
-                       "loss": "l2/mean" if args.attack == "pgd" else "margin" if args.attack == "square" else "ce/none"},
+                       "loss": "l2/mean" if args.attack == "pgd" else "margin" if args.attack == "square" else "ce/none",
+                       "input_seeds": {**seeds, "generator": "torch device generator, rank 0 (rank r: + 1000 r)"}},
             # pgd: I x (fwd+bwd); apgd_train: (I+1) fwd + I bwd; APGDAttack: (I+2) fwd + (I+1) bwd  ~ I+1 pairs;
             # square: at most I + 3 forwards (0.49 of a pair each; fewer once samples are fooled)
             "whole_loop_tflops_per_gpu": value / world * FLOP_PER_IMG_ITER.get(args.model, 0) *
@@ -527,14 +549,18 @@ def main():
                                           args.attack == "apgd" else 0.49 * (args.iterations + 3) if
                                           args.attack == "square" else args.iterations + 1.5) / 1e12,
         }
-        res["ranks"] = {"rccl_ranks": world if dist is not None else 0,
+        if rehearsal:
+            res["rehearsal"] = REHEARSAL_NOTE
+            res["data"] = "synthetic (REHEARSAL: ranks share a GPU over gloo - not a measurement)"
+        res["ranks"] = {"rccl_ranks": world if (dist is not None and not rehearsal) else 0,
+                        "gloo_ranks": world if rehearsal else 0,
                         "launcher": "none (single process)" if world == 1 else
                                     "bench.py self-launch (torch.distributed.run, 127.0.0.1)" if os.environ.get("RVLM_SELF_LAUNCHED")
                                     else "external torch.distributed.run",
                         "per_rank_images_per_sec_min": min(B * args.steps / t for t in per_rank_s),
                         "per_rank_images_per_sec_max": max(B * args.steps / t for t in per_rank_s),
                         "cpu_affinity_rank0": affinity}
-        res["whole_loop_frac_of_peak"] = res["whole_loop_tflops_per_gpu"] / PEAK_BF16_TFLOPS
+        res["whole_loop_frac_of_peak"] = res["whole_loop_tflops_per_gpu"] / (PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_TFLOPS)
         res["whole_loop_flop_basis"] = ("reference model FLOPs per image (SURVEY.md Appendix C); the engine's class-token "
                                         "tail skips the dead rows of the last block (~3 % of them) - roofline.achieved "
                                         "counts executed FLOPs only")
@@ -613,9 +639,15 @@ def main():
                                               if v.get("lds_conflict_share") is not None}}
             except Exception:
                 pmc = None
+        fp32_run = args.precision == "fp32"
+        peak = PEAK_F32_MFMA_TFLOPS if fp32_run else PEAK_BF16_TFLOPS
         res["roofline"] = {
-            "bound": "mfma", "kernel": "gemm_bf16_nt_256p_kernel (QKV/out-proj/fc1/fc2, fwd + dgrad; the 128 remainder rows ride in the same launch)",
-            "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
+            "bound": "mfma",
+            "kernel": "gemm_f32_mfma_kernel (v_mfma_f32_32x32x2_f32 tiles: QKV/out-proj/fc1/fc2, fwd + dgrad)" if fp32_run else
+                      "gemm_bf16_nt_256p_kernel (QKV/out-proj/fc1/fc2, fwd + dgrad; the 128 remainder rows ride in the same launch)"
+                      + (" - the bf16 handle's launches only (iterations 2..I); the fp32 first iteration is not in this object"
+                         if args.precision == "bf16+fp32-first" else ""),
+            "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
             "traffic": traffic, "traffic_unit": "bytes per GEMM launch (fabric side: 2*FETCH_SIZE + WRITE_SIZE)",
             "traffic_source": traffic_src, "pmc_in_run_error": pmc_error,
             "flops_per_launch": gflops / max(glaunch, 1), "avg_launch_ms": gms / max(glaunch, 1),
@@ -624,11 +656,13 @@ def main():
             "clock_in_kernel": eff_clock,
             "attention_gemm_subset": {
                 "tflops": sum(v["flops"] for v in attn_gemm.values()) / max(sum(v["ms"] for v in attn_gemm.values()), 1e-9) / 1e9,
-                "frac": sum(v["flops"] for v in attn_gemm.values()) / max(sum(v["ms"] for v in attn_gemm.values()), 1e-9) / 1e9 / PEAK_BF16_TFLOPS},
+                "frac": sum(v["flops"] for v in attn_gemm.values()) / max(sum(v["ms"] for v in attn_gemm.values()), 1e-9) / 1e9 / peak},
             # the HBM-bound quarter of the step against ITS roofline: algorithmic bytes / HIP-event time / 8 TB/s
             # (attention: q, k, v in + o out forward; q, k, v, o, dO in + dq, dk, dv out backward, bf16; LayerNorm: the
             # byte counts the engine's profile scopes carry - 6 B per element forward, 16 B backward)
             "hbm_classes": hbm_classes(prof, cfg, B, (pmc or {}).get("hbm_class_traffic")),
+            "per_class_source": "ONE separate profiled pgd() call after the timed region (HIP events between the kernels: the "
+                                "call runs ~1 % longer than a timed one, so the class sum exceeds ms_per_step)",
             "per_class": {k: {"ms": round(v["ms"], 3), "launches": v["launches"],
                               "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 and v["flops"] > 0 else None,
                               "gbps": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 and v["bytes"] > 0 else None}
@@ -641,7 +675,7 @@ def main():
         if clk or eff:
             # the dense peak = 256 CUs x 2.4 GHz x (bf16 FLOP per CU and cycle): it scales linearly with the shader clock;
             # the in-kernel measurement (cycles the waves actually got) is preferred over rocm-smi's reading
-            peak_at_clock = PEAK_BF16_TFLOPS * (eff if eff else clk["sclk_mhz_mean"]) / 2400.0
+            peak_at_clock = res["roofline"]["peak"] * (eff if eff else clk["sclk_mhz_mean"]) / 2400.0
             res["roofline"]["frac_at_measured_clock"] = res["roofline"]["achieved"] / peak_at_clock
             res["roofline"]["peak_at_measured_clock"] = peak_at_clock
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

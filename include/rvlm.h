@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RVLM_VERSION 105
+#define RVLM_VERSION 106
 
 typedef void* rvlm_stream_t; /* hipStream_t */
 typedef struct rvlm_vit rvlm_vit;
@@ -275,6 +275,14 @@ int rvlm_pgd_run_norm(rvlm_vit* h, const float* x, const float* delta0, int B, c
                       float eps, int iterations, float stepsize, float momentum, int mode_max, float* x_adv_out,
                       float* loss_trace, int32_t* flags, rvlm_stream_t stream);
 
+/* pgd() in two precisions: iterations [0, n_first) evaluate forward + loss + input gradient on h_first, a second handle of
+ * the SAME model (its fp32 mode: the reference's own precision, train/pgd_train.py:30-38), the rest on h; the attack state
+ * lives in h.  loss->ref should be the h_first-precision embedding (FARE's first cotangent is a difference of nearly equal
+ * embeddings).  Both handles need max_batch >= B. */
+int rvlm_pgd_run_mixed(rvlm_vit* h, rvlm_vit* h_first, int n_first, const float* x, const float* delta0, int B,
+                       const rvlm_loss_spec* loss, int norm_kind, float eps, int iterations, float stepsize, float momentum,
+                       int mode_max, float* x_adv_out, float* loss_trace, int32_t* flags, rvlm_stream_t stream);
+
 /* APGD L-inf.  x_init: NULL -> start from clamp(x,0,1) (apgd_train) or the caller-provided random
  * start (APGDAttack).  logits_from_head: 0 -> the `argmax(model output)==y` test runs on the
  * embedding (apgd_train quirk); 1 -> on emb @ (logit_scale*T) logits
@@ -285,8 +293,9 @@ int rvlm_apgd_run(rvlm_vit* h, const float* x, const float* x_init, int B,
                   int train_variant, int logits_from_head, float* x_best_adv, float* x_best,
                   float* loss_best, uint8_t* acc, rvlm_stream_t stream);
 
-/* `rho` of APGDAttack for the following rvlm_apgd_run* calls on this handle (default 0.75; train/apgd_train.py has no
- * such parameter).  Returns RVLM_ERR_ARG for NaN. */
+/* `rho` of APGDAttack for the following rvlm_apgd_run* calls WITH train_variant == 0 on this handle (default 0.75).
+ * train/apgd_train.py has no such parameter: train_variant != 0 runs always use 0.75, whatever was set here.
+ * Returns RVLM_ERR_ARG for NaN. */
 int rvlm_vit_set_apgd_rho(rvlm_vit* h, double rho);
 
 /* SURVEY.md section 8(b) `rvlm_vit_fwd_inputgrad`: ONE iteration's model work in one call - forward of x (+ delta,
@@ -363,7 +372,7 @@ int rvlm_version(void);   /* = RVLM_VERSION.  101: rvlm_loss_spec.y_target, rvlm
                            * rvlm_pgd_l2_update, rvlm_pgd_run_norm, rvlm_apgd_l2_step, rvlm_apgd_run_norm,
                            * rvlm_project_perturbation, rvlm_normalize_grad; 104: rvlm_preproc_run_batch, rvlm_ce_logits takes B = 1,
                            * rvlm_vit_backward_params_stages refuses out-of-order stages; 105: rvlm_apgd_controller_rho,
-                           * rvlm_vit_set_apgd_rho, rvlm_comm_* / rvlm_allreduce_grads */
+                           * rvlm_vit_set_apgd_rho, rvlm_comm_* / rvlm_allreduce_grads; 106: rvlm_pgd_run_mixed, fp32 mode on v_mfma_f32_32x32x2_f32 */
 
 #ifdef __cplusplus
 }

@@ -22,6 +22,15 @@ int rvlm_k_gemm_bf16_nt(const uint16_t* A, long lda, const uint16_t* Bw, long ld
 int rvlm_k_gemm_f32(const float* A, long sam, long sak, const float* B, long sbn, long sbk, float* C,
                     long scm, long scn, int M, int N, int K, float alpha, const float* bias,
                     rvlm_stream_t stream);
+/* the same with one batch dimension (element strides sab / sbb / scb) and the whole epilogue: act >= 0 applies RVLM_ACT_*
+ * (C_pre, if given, receives the pre-activation), dact_h multiplies by act'(dact_h[m, n]) (QuickGELU), residual adds */
+int rvlm_k_gemm_f32_ex(const float* A, long sam, long sak, long sab, const float* B, long sbn, long sbk, long sbb,
+                       float* C, long scm, long scn, long scb, int M, int N, int K, int nb, float alpha,
+                       const float* bias, int act, float* C_pre, const float* dact_h, const float* residual,
+                       rvlm_stream_t stream);
+/* 1: the VALU fmaf-chain tiles for every later fp32 GEMM instead of the v_mfma_f32_32x32x2_f32 tiles (the two are
+ * bit-identical: both evaluate every output element as the k-ordered fp32 fma chain); 0: default */
+int rvlm_k_gemm_f32_set_valu(int on);
 /* bf16 flash attention on packed qkv [B*S, 3W] (head_dim 64); lse2 [B*H*round_up(S,32)] */
 int rvlm_k_attn_fwd_bf16(const uint16_t* qkv, uint16_t* o, float* lse2, int B, int H, int S,
                          rvlm_stream_t stream);

@@ -134,6 +134,9 @@ _SIGS = {
     "rvlm_pgd_run": (C.c_int, [C.c_void_p, c_f32p, c_f32p, C.c_int, C.POINTER(LossSpecC), C.c_float,
                                C.c_int, C.c_float, C.c_float, C.c_int, c_f32p, c_f32p, C.c_void_p,
                                c_stream]),
+    "rvlm_pgd_run_mixed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_f32p, c_f32p, C.c_int, C.POINTER(LossSpecC), C.c_int,
+                                     C.c_float, C.c_int, C.c_float, C.c_float, C.c_int, c_f32p, c_f32p, C.c_void_p,
+                                     c_stream]),
     "rvlm_apgd_run": (C.c_int, [C.c_void_p, c_f32p, c_f32p, C.c_int, C.POINTER(LossSpecC), C.c_float,
                                 C.c_int, C.c_float, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p,
                                 C.c_void_p, c_stream]),
@@ -155,6 +158,10 @@ _SIGS = {
     "rvlm_k_gemm_f32": (C.c_int, [c_f32p, C.c_long, C.c_long, c_f32p, C.c_long, C.c_long, c_f32p,
                                   C.c_long, C.c_long, C.c_int, C.c_int, C.c_int, C.c_float, c_f32p,
                                   c_stream]),
+    "rvlm_k_gemm_f32_ex": (C.c_int, [c_f32p, C.c_long, C.c_long, C.c_long, c_f32p, C.c_long, C.c_long, C.c_long, c_f32p,
+                                     C.c_long, C.c_long, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, c_f32p,
+                                     C.c_int, c_f32p, c_f32p, c_f32p, c_stream]),
+    "rvlm_k_gemm_f32_set_valu": (C.c_int, [C.c_int]),
     "rvlm_k_attn_fwd_bf16": (C.c_int, [C.c_void_p, C.c_void_p, c_f32p, C.c_int, C.c_int, C.c_int,
                                        c_stream]),
     "rvlm_k_attn_bwd_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_f32p, c_f32p,

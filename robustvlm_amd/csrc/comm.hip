@@ -9,13 +9,24 @@
 // 1 / world folded in).
 //
 // librccl is resolved with dlopen at the first rvlm_comm_* call, not at load time: librvlm.so keeps no hard dependency on it
-// (the attack path needs no collective at all).
+// (the attack path needs no collective at all) - neither at run time nor at BUILD time: the handful of
+// RCCL types and enumerators the five entry points use are declared here (NCCL's stable public ABI: ncclUniqueId = 128
+// opaque bytes, ncclResult_t 0 = success, ncclSum = 0, ncclFloat32 = 7, ncclBfloat16 = 9), so the library builds on a box
+// without the RCCL headers.
 #include "kernels.h"
 
 #include <dlfcn.h>
 #include <string.h>
 #include <mutex>
-#include <rccl/rccl.h>
+
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+#define NCCL_UNIQUE_ID_BYTES 128
+typedef struct { char internal[NCCL_UNIQUE_ID_BYTES]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+typedef enum { ncclFloat32 = 7, ncclBfloat16 = 9 } ncclDataType_t;
+}
 
 struct rvlm_comm {
     ncclComm_t comm = nullptr;
@@ -119,6 +130,11 @@ extern "C" int rvlm_allreduce_grads(rvlm_comm* c, void* buf, size_t count, int d
     RVLM_REQUIRE(buf || count == 0, "rvlm_allreduce_grads: null buffer");
     RVLM_REQUIRE(dtype == RVLM_DTYPE_F32 || dtype == RVLM_DTYPE_BF16, "rvlm_allreduce_grads: dtype must be RVLM_DTYPE_F32 / _BF16");
     if (count == 0) return RVLM_OK;
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    if (cur != c->device)       // RCCL would enqueue on the communicator's device whatever `stream` belongs to
+        return fail(RVLM_ERR_STATE, "rvlm_allreduce_grads: the calling thread's current device (" + std::to_string(cur) +
+                                    ") is not the device the communicator was created on (" + std::to_string(c->device) + ")");
     const Rccl& R = rccl();
     const ncclResult_t r = R.AllReduce(buf, buf, count, dtype == RVLM_DTYPE_F32 ? ncclFloat32 : ncclBfloat16, ncclSum, c->comm,
                                        (hipStream_t)stream);

@@ -66,9 +66,10 @@ struct rvlm_vit {
     bool inference_only = false;
     std::vector<void*> ln1_out, ln2_out, g_act_l;   // L x [Mp,W], [Mp,W], [Mp,4W] T
     float *tokens, *dtok;      // [Mp, W] f32
-    void *tA, *tB;             // bf16 mode: [4W, Mpt] transposed operands of the wgrad GEMMs the copy-free form does not take
-                               // (conv1, widths that are no multiple of 256, fewer than 256 tokens)
+    void *tA, *tB;             // bf16 mode: transposed operands of the wgrad GEMMs the copy-free form does not take
+                               // (conv1, widths that are no multiple of 256, fewer than 256 tokens); t_elems elements each
     long Mpt = 0;
+    size_t t_elems = 0;        // bf16 elements of tA (= of tB)
     // attack state
     float* img_buf[5];         // [maxB*3*img*img]
     float *emb, *d_emb, *loss_ps, *loss_scalar, *loss_scratch;
@@ -643,11 +644,18 @@ int wgrad<bf16_t>(rvlm_vit* h, hipStream_t s, const void* dY, long lddy, const v
     if (dbias && (rc = colsum<bf16_t>((const bf16_t*)dY, lddy, M, N, dbias, accumulate, h->red_scratch, h->red_floats, s)))
         return rc;
     const int Mk = (int)round_up(M, 64);
-    if ((rc = transpose_pad<bf16_t>((const bf16_t*)dY, lddy, M, N, (bf16_t*)h->tA, h->Mpt, Mk, s))) return rc;
-    if ((rc = transpose_pad<bf16_t>((const bf16_t*)X, ldx, M, K, (bf16_t*)h->tB, h->Mpt, Mk, s))) return rc;
+    // leading dimension of the transposed copies: all tokens when the operand's rows fit that way (conv1; every linear of a
+    // width that is no multiple of 256), else the few tokens of this call (the < 256-token fallback of the encoder linears)
+    const size_t need_rows = (size_t)round_up(std::max(N, K), 128);
+    long ldt = h->Mpt;
+    if (need_rows * (size_t)ldt > h->t_elems) ldt = Mk;
+    if (need_rows * (size_t)ldt > h->t_elems || Mk > ldt)
+        return fail(RVLM_ERR_STATE, "wgrad: transposed-operand scratch too small for this shape");
+    if ((rc = transpose_pad<bf16_t>((const bf16_t*)dY, lddy, M, N, (bf16_t*)h->tA, ldt, Mk, s))) return rc;
+    if ((rc = transpose_pad<bf16_t>((const bf16_t*)X, ldx, M, K, (bf16_t*)h->tB, ldt, Mk, s))) return rc;
     GemmBf16 g;
-    g.A = (const bf16_t*)h->tA; g.lda = h->Mpt; g.Bw = (const bf16_t*)h->tB; g.ldb = h->Mpt;
-    g.M = N; g.N = K; g.K = Mk; g.a_rows = 4 * h->W;
+    g.A = (const bf16_t*)h->tA; g.lda = ldt; g.Bw = (const bf16_t*)h->tB; g.ldb = ldt;
+    g.M = N; g.N = K; g.K = Mk; g.a_rows = (int)std::min<size_t>(h->t_elems / (size_t)ldt, (size_t)4 * h->W);
     g.epi = accumulate ? EPI_F32_RESID : EPI_F32; g.residual = accumulate ? dW : nullptr;
     g.out = dW; g.ldo = lddw;
     with_scratch(h, g);
@@ -897,10 +905,19 @@ extern "C" int rvlm_vit_create(const rvlm_vit_config* cfg, const rvlm_vit_weight
         ALLOC_OR_DIE(h->tokens, Mp * W * 4);
         ALLOC_OR_DIE(h->dtok, Mp * W * 4);
         if (h->bf16) {
+            // What the copy-free contraction-major weight gradient leaves to these buffers: conv1 (max(W, Kpad) rows x all tokens),
+            // and every linear when fewer than 256 tokens are in flight (4W rows x < 320 columns, short leading dimension).
+            // Widths that are no multiple of 256 - and the EXPERIMENTAL build's transposing A/B arm - transpose every linear:
+            // 4W rows x all tokens (0.57 GB for ViT-L/14 at B = 128).
             h->Mpt = (long)Mp + 16 * 128;
-            const size_t rows = (size_t)std::max(4 * W, h->Kpad);
-            ALLOC_OR_DIE(h->tA, rows * h->Mpt * 2);
-            ALLOC_OR_DIE(h->tB, rows * h->Mpt * 2);
+            bool every_linear = W % 256 != 0;
+#ifdef RVLM_EXPERIMENTAL_GEMM
+            every_linear = true;
+#endif
+            const size_t rows = (size_t)(every_linear ? std::max(4 * W, h->Kpad) : std::max(W, h->Kpad));
+            h->t_elems = std::max(rows * (size_t)h->Mpt, (size_t)std::max(4 * W, h->Kpad) * 320);
+            ALLOC_OR_DIE(h->tA, h->t_elems * 2);
+            ALLOC_OR_DIE(h->tB, h->t_elems * 2);
         }
     }
     {
@@ -1037,15 +1054,12 @@ extern "C" int rvlm_vit_fwd_inputgrad(rvlm_vit* h, const float* x, const float* 
     return RVLM_OK;
 }
 
-extern "C" int rvlm_pgd_run_norm(rvlm_vit* h, const float* x, const float* delta0, int B,
-                                 const rvlm_loss_spec* loss, int norm_kind, float eps, int iterations, float stepsize,
-                                 float momentum, int mode_max, float* x_adv_out, float* loss_trace,
-                                 int32_t* flags, rvlm_stream_t stream) {
-    RVLM_REQUIRE(h && x && loss && x_adv_out && loss->ref, "rvlm_pgd_run: null argument");
-    if (norm_kind != 0 && norm_kind != 2) return fail(RVLM_ERR_UNSUPPORTED, "rvlm_pgd_run: norm must be L-inf (0) or L2 (2)");
-    RVLM_REQUIRE(B > 1 && B <= h->maxB, "rvlm_pgd_run: need 1 < B <= max_batch");
-    RVLM_REQUIRE(iterations >= 0 && iterations <= 4096, "rvlm_pgd_run: iterations");
-    hipStream_t s = (hipStream_t)stream;
+// One perturbation loop; iterations [0, n_first) evaluate model and gradient on `hf` (a second handle of the same model, e.g.
+// its fp32 mode), the others on `h`.  The attack state (delta, velocity, gradient) lives in h's buffers throughout; a
+// handle only contributes forward + loss + input gradient (what pgd_train.py:33-38 asks of the model).
+static int pgd_run_impl(rvlm_vit* h, rvlm_vit* hf, int n_first, const float* x, const float* delta0, int B,
+                        const rvlm_loss_spec* loss, int norm_kind, float eps, int iterations, float stepsize,
+                        float momentum, int mode_max, float* x_adv_out, float* loss_trace, int32_t* flags, hipStream_t s) {
     const size_t n = (size_t)B * 3 * h->img * h->img;
     float *delta = h->img_buf[0], *vel = h->img_buf[1], *grad = h->img_buf[2];
     int rc;
@@ -1058,10 +1072,11 @@ extern "C" int rvlm_pgd_run_norm(rvlm_vit* h, const float* x, const float* delta
         RVLM_CHECK_LAUNCH();
     }
     for (int it = 0; it < iterations; ++it) {
-        if ((rc = vit_forward(h, x, delta, B, loss->output_normalize, 1, h->emb, s))) return rc;
+        rvlm_vit* m = (hf && it < n_first) ? hf : h;
+        if ((rc = vit_forward(m, x, delta, B, loss->output_normalize, 1, m->emb, s))) return rc;
         float* lsc = loss_trace ? loss_trace + it : (it < 4096 ? h->loss_scalar + it : nullptr);
-        if ((rc = loss_step(h, loss, B, loss->reduction, lsc, nullptr, s))) return rc;
-        if ((rc = vit_backward(h, h->d_emb, B, grad, s))) return rc;
+        if ((rc = loss_step(m, loss, B, loss->reduction, lsc, nullptr, s))) return rc;
+        if ((rc = vit_backward(m, m->d_emb, B, grad, s))) return rc;
         {
             PROF("linf_update", 0, (double)n * 28);
             float* xo = it == iterations - 1 ? x_adv_out : nullptr;
@@ -1071,6 +1086,40 @@ extern "C" int rvlm_pgd_run_norm(rvlm_vit* h, const float* x, const float* delta
         }
     }
     return RVLM_OK;
+}
+
+extern "C" int rvlm_pgd_run_norm(rvlm_vit* h, const float* x, const float* delta0, int B,
+                                 const rvlm_loss_spec* loss, int norm_kind, float eps, int iterations, float stepsize,
+                                 float momentum, int mode_max, float* x_adv_out, float* loss_trace,
+                                 int32_t* flags, rvlm_stream_t stream) {
+    RVLM_REQUIRE(h && x && loss && x_adv_out && loss->ref, "rvlm_pgd_run: null argument");
+    if (norm_kind != 0 && norm_kind != 2) return fail(RVLM_ERR_UNSUPPORTED, "rvlm_pgd_run: norm must be L-inf (0) or L2 (2)");
+    RVLM_REQUIRE(B > 1 && B <= h->maxB, "rvlm_pgd_run: need 1 < B <= max_batch");
+    RVLM_REQUIRE(iterations >= 0 && iterations <= 4096, "rvlm_pgd_run: iterations");
+    return pgd_run_impl(h, nullptr, 0, x, delta0, B, loss, norm_kind, eps, iterations, stepsize, momentum, mode_max,
+                        x_adv_out, loss_trace, flags, (hipStream_t)stream);
+}
+
+// Mixed-precision loop (precision "bf16+fp32-first" of the Python mirror): the first n_first iterations on h_first - a
+// handle of the SAME model in the reference's own precision (fp32: train/pgd_train.py:30-38 runs no autocast) - and the
+// rest on h.  FARE's first cotangent 2 (phi(x + d0) - phi(x)) is a difference of two nearly equal embeddings (~1e-2 of
+// their norm at the random start), one part bf16 rounding noise in three; one fp32
+// iteration - with loss->ref = the fp32 embedding of x - gives the reference's first step, after which the difference has
+// grown tenfold and bf16 agrees to 0.98-0.996.
+extern "C" int rvlm_pgd_run_mixed(rvlm_vit* h, rvlm_vit* h_first, int n_first, const float* x, const float* delta0, int B,
+                                  const rvlm_loss_spec* loss, int norm_kind, float eps, int iterations, float stepsize,
+                                  float momentum, int mode_max, float* x_adv_out, float* loss_trace,
+                                  int32_t* flags, rvlm_stream_t stream) {
+    RVLM_REQUIRE(h && h_first && x && loss && x_adv_out && loss->ref, "rvlm_pgd_run_mixed: null argument");
+    if (norm_kind != 0 && norm_kind != 2) return fail(RVLM_ERR_UNSUPPORTED, "rvlm_pgd_run_mixed: norm must be L-inf (0) or L2 (2)");
+    RVLM_REQUIRE(B > 1 && B <= h->maxB && B <= h_first->maxB, "rvlm_pgd_run_mixed: need 1 < B <= max_batch of both handles");
+    RVLM_REQUIRE(iterations >= 0 && iterations <= 4096 && n_first >= 0, "rvlm_pgd_run_mixed: iterations");
+    RVLM_REQUIRE(h->img == h_first->img && h->P == h_first->P && h->W == h_first->W && h->L == h_first->L &&
+                 h->H == h_first->H && h->D == h_first->D && h->cfg.act == h_first->cfg.act,
+                 "rvlm_pgd_run_mixed: the two handles must hold the same architecture");
+    RVLM_REQUIRE(!h->inference_only && !h_first->inference_only, "rvlm_pgd_run_mixed: inference-only handle");
+    return pgd_run_impl(h, h_first, n_first, x, delta0, B, loss, norm_kind, eps, iterations, stepsize, momentum, mode_max,
+                        x_adv_out, loss_trace, flags, (hipStream_t)stream);
 }
 
 extern "C" int rvlm_pgd_run(rvlm_vit* h, const float* x, const float* delta0, int B,
@@ -1136,7 +1185,9 @@ extern "C" int rvlm_apgd_run_norm(rvlm_vit* h, const float* x, const float* x_in
         if ((rc = eval(need_grad))) return rc;
         counter3 += 1;
         const int do_check = counter3 == k;
-        if ((rc = rvlm_apgd_controller_rho(i, B, n_iter, k, do_check, h->ap_rho, h->loss_ps, h->ap_pred, h->ap_loss_steps,
+        // apgd_train hard-codes the threshold (train/apgd_train.py:117,334: k3 = 0.75); `rho` is APGDAttack's parameter only, so
+        // a value left on the handle by an APGDAttack(rho != 0.75) run does not reach a later apgd_train on the same handle
+        if ((rc = rvlm_apgd_controller_rho(i, B, n_iter, k, do_check, train_variant ? 0.75 : h->ap_rho, h->loss_ps, h->ap_pred, h->ap_loss_steps,
                                        h->ap_loss_best, h->ap_loss_best_lc, h->ap_reduced_lc, h->ap_step,
                                        h->ap_acc, h->ap_f0, h->ap_f1, h->ap_f2, s))) return rc;
         {

@@ -288,7 +288,9 @@ int wgrad_split_plan(int M, int N, int K, size_t slab_bytes, int* splits, int* K
     const int tiles = (N / 256) * (K / 256), nk128 = cdiv(M, 128);
     int sp = std::max(1, std::min(16, 256 / tiles));
     sp = std::min(sp, nk128);
-    if (sp > 1 && (size_t)sp * N * K * sizeof(float) > slab_bytes) return 0;
+    // (also for one split: the copy-free contraction-major form always writes fp32 slabs and reduces them - a plan whose slab
+    // does not fit is no plan, and the caller falls back to the transposing path instead of failing in the launch)
+    if ((size_t)sp * N * K * sizeof(float) > slab_bytes) return 0;
     *splits = sp;
     *Kc = cdiv(nk128, sp) * 128;
     return 1;

@@ -24,6 +24,7 @@ struct GemmF32 {
     const float* residual = nullptr;   // optional: + residual[m,n] (layout of C)
 };
 int gemm_f32(const GemmF32& p, hipStream_t s);
+void gemm_f32_set_valu(int on);   // test hook: 1 = the VALU fmaf-chain tiles instead of the fp32 MFMA tiles
 
 // ---------------------------------------------------------------------------------------------
 // bf16 MFMA GEMM, NT form: C[M,N] = A[M,K] (row-major, lda) x Bw[N,K]^T (row-major, ldb)

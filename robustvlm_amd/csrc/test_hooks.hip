@@ -264,6 +264,17 @@ extern "C" int rvlm_k_gemm_f32(const float* A, long sam, long sak, const float* 
     g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.bias = bias;
     return gemm_f32(g, (hipStream_t)stream);
 }
+extern "C" int rvlm_k_gemm_f32_ex(const float* A, long sam, long sak, long sab, const float* B, long sbn, long sbk, long sbb,
+                                  float* C, long scm, long scn, long scb, int M, int N, int K, int nb, float alpha,
+                                  const float* bias, int act, float* C_pre, const float* dact_h, const float* residual,
+                                  rvlm_stream_t stream) {
+    GemmF32 g;
+    g.A = A; g.sam = sam; g.sak = sak; g.sab2 = sab; g.B = B; g.sbn = sbn; g.sbk = sbk; g.sbb2 = sbb;
+    g.C = C; g.scm = scm; g.scn = scn; g.scb2 = scb; g.M = M; g.N = N; g.K = K; g.nb1 = 1; g.nb2 = nb; g.alpha = alpha;
+    g.bias = bias; g.act = act; g.C_pre = C_pre; g.dact_h = dact_h; g.residual = residual;
+    return gemm_f32(g, (hipStream_t)stream);
+}
+extern "C" int rvlm_k_gemm_f32_set_valu(int on) { gemm_f32_set_valu(on); return RVLM_OK; }
 extern "C" int rvlm_k_attn_fwd_bf16(const uint16_t* qkv, uint16_t* o, float* lse2, int B, int H, int S,
                                     rvlm_stream_t stream) {
     return attn_fwd_bf16((const bf16_t*)qkv, 3L * H * 64, (bf16_t*)o, H * 64L, lse2, B, H, S, (hipStream_t)stream);

@@ -22,7 +22,13 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
 class VitEngine:
     """Owns a ``rvlm_vit`` handle: converted weights + a workspace sized for ``max_batch`` images.
 
-    precision: 'bf16' (MFMA throughput path) or 'fp32' (parity path, config C1)."""
+    precision: 'bf16' (MFMA throughput path), 'fp32' (the reference's own precision - train/pgd_train.py:30-38 runs no
+    autocast - on the fp32 matrix-pipe tiles: parity path, config C1), or 'bf16+fp32-first': a bf16 handle plus an fp32
+    handle of the same weights; ``pgd_run`` evaluates its FIRST iteration on the fp32 handle (rvlm_pgd_run_mixed) and
+    gradient-free forwards (``save=False``: the clean embedding FARE's loss is measured against) run there too, everything
+    else in bf16.  Why: FARE's first cotangent 2 (phi(x + d0) - phi(x)) is a difference of nearly equal embeddings and
+    one part bf16 rounding noise in three; with one fp32 iteration the attack takes the
+    reference's first step (gradient-sign agreement 0.82 -> 0.9999) at the price of one fp32 iteration per call."""
 
     def __init__(self, cfg, state_dict: dict, precision: str = "bf16", max_batch: int = 128,
                  mean=CLIP_MEAN, std=CLIP_STD, device=None, trainable: bool = False,
@@ -46,9 +52,13 @@ class VitEngine:
         c.image_size, c.patch, c.width, c.layers = cfg.image_size, cfg.patch, cfg.width, cfg.layers
         c.heads, c.out_dim = cfg.heads, cfg.out_dim
         c.act = L.ACT_QUICK_GELU if cfg.act == "quick_gelu" else L.ACT_GELU
-        c.precision = L.PREC_BF16 if precision == "bf16" else L.PREC_F32
-        if precision not in ("bf16", "fp32"):
+        if precision not in ("bf16", "fp32", "bf16+fp32-first"):
             raise ValueError(f"precision {precision!r} not supported")
+        self.mixed = precision == "bf16+fp32-first"
+        if self.mixed and (trainable or inference_only):
+            raise ValueError("precision 'bf16+fp32-first' is an attack-engine option (not trainable / inference_only)")
+        c.precision = L.PREC_F32 if precision == "fp32" else L.PREC_BF16
+        self._h32 = C.c_void_p()
         c.max_batch = self.max_batch
         c.trainable = 1 if trainable else (-1 if inference_only else 0)
         self.trainable = bool(trainable)
@@ -58,6 +68,10 @@ class VitEngine:
             w, keep = self._weights_struct(state_dict)
             L.check(self.lib.rvlm_vit_create(C.byref(c), C.byref(w), L.stream_ptr(), C.byref(self._h)),
                     "rvlm_vit_create")
+            if self.mixed:
+                c.precision = L.PREC_F32
+                L.check(self.lib.rvlm_vit_create(C.byref(c), C.byref(w), L.stream_ptr(), C.byref(self._h32)),
+                        "rvlm_vit_create (fp32 handle)")
         del keep
 
     # ---- weights ------------------------------------------------------------------------------
@@ -95,6 +109,8 @@ class VitEngine:
         with torch.cuda.device(self.device):
             w, keep = self._weights_struct(state_dict)
             L.check(self.lib.rvlm_vit_load_weights(self._h, C.byref(w), L.stream_ptr()))
+            if self.mixed:
+                L.check(self.lib.rvlm_vit_load_weights(self._h32, C.byref(w), L.stream_ptr()))
             torch.cuda.current_stream().synchronize()
         del keep
 
@@ -116,7 +132,8 @@ class VitEngine:
         B = x.shape[0]
         out = torch.empty(B, self.cfg.out_dim, device=x.device, dtype=torch.float32)
         with torch.cuda.device(x.device):
-            L.check(self.lib.rvlm_vit_forward(self._h, x.data_ptr(), L.ptr(d), B, int(bool(output_normalize)),
+            h = self._h32 if (self.mixed and not save) else self._h      # (mixed: gradient-free forwards in fp32)
+            L.check(self.lib.rvlm_vit_forward(h, x.data_ptr(), L.ptr(d), B, int(bool(output_normalize)),
                                               int(save), out.data_ptr(), L.stream_ptr()),
                     "rvlm_vit_forward")
         # every forward (saving or not) overwrites state a pending backward would read: rvlm_vit_forward invalidates the
@@ -232,10 +249,17 @@ class VitEngine:
         flags = torch.zeros(1, dtype=torch.int32, device=x.device)
         trace = torch.zeros(max(iterations, 1), dtype=torch.float32, device=x.device) if want_trace else None
         with torch.cuda.device(x.device):
-            L.check(self.lib.rvlm_pgd_run_norm(self._h, x.data_ptr(), L.ptr(d0), x.shape[0], C.byref(ls),
-                                               int(norm_kind), float(eps), int(iterations), float(stepsize),
-                                               float(momentum), 1 if mode == "max" else 0, out.data_ptr(),
-                                               L.ptr(trace), flags.data_ptr(), L.stream_ptr()), "rvlm_pgd_run")
+            if self.mixed:
+                L.check(self.lib.rvlm_pgd_run_mixed(self._h, self._h32, 1, x.data_ptr(), L.ptr(d0), x.shape[0],
+                                                    C.byref(ls), int(norm_kind), float(eps), int(iterations),
+                                                    float(stepsize), float(momentum), 1 if mode == "max" else 0,
+                                                    out.data_ptr(), L.ptr(trace), flags.data_ptr(), L.stream_ptr()),
+                        "rvlm_pgd_run_mixed")
+            else:
+                L.check(self.lib.rvlm_pgd_run_norm(self._h, x.data_ptr(), L.ptr(d0), x.shape[0], C.byref(ls),
+                                                   int(norm_kind), float(eps), int(iterations), float(stepsize),
+                                                   float(momentum), 1 if mode == "max" else 0, out.data_ptr(),
+                                                   L.ptr(trace), flags.data_ptr(), L.stream_ptr()), "rvlm_pgd_run")
         self.generation += 1
         return out, flags, trace
 
@@ -285,12 +309,16 @@ class VitEngine:
                                            launches=arr[i].launches) for i in range(n.value)}
 
     def workspace_bytes(self) -> int:
-        return int(self.lib.rvlm_vit_workspace_bytes(self._h))
+        return int(self.lib.rvlm_vit_workspace_bytes(self._h)) + (
+            int(self.lib.rvlm_vit_workspace_bytes(self._h32)) if self._h32.value else 0)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             self.lib.rvlm_vit_destroy(self._h)
             self._h = C.c_void_p()
+        if getattr(self, "_h32", None) is not None and self._h32.value:
+            self.lib.rvlm_vit_destroy(self._h32)
+            self._h32 = C.c_void_p()
 
     def __del__(self):
         try:

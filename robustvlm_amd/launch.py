@@ -8,6 +8,12 @@ local ranks on 127.0.0.1 and a free port, and returns that agent's exit code (no
 the agent tears the other ranks down).  When the rendezvous IS in the environment (the driver's own
 ``python -m torch.distributed.run ... bench.py --gpus N``) the script is a rank and nothing is launched.
 
+REHEARSAL (``RVLM_BENCH_REHEARSAL=gloo``): an N > 1 job on a node with fewer than N GPUs - rank r uses device
+r mod visible_devices and the process group is gloo.  It exists so that the world > 1 branch of bench.py (self-launch,
+process-group init, barriers, the gather of per-rank times, rank 0's JSON line, a dying rank's exit code) runs on the
+1-GPU boxes this project is developed on BEFORE an 8-GPU node executes it for the first time; its line is flagged
+``rehearsal`` and is not a measurement.
+
 Everything here is host logic and runs without a GPU (tests/test_launch.py)."""
 from __future__ import annotations
 
@@ -52,6 +58,9 @@ def plan_launch(gpus: int, argv: list, environ: dict, visible_devices: int, port
     """
     if gpus < 1:
         raise LaunchError(f"--gpus {gpus}: need at least one GPU")
+    rehearsal = rehearsal_backend(environ)
+    if rehearsal and visible_devices >= 1:
+        visible_devices = max(visible_devices, gpus)       # ranks share devices (rank r -> device r mod visible)
     if "WORLD_SIZE" in environ:
         world = int(environ["WORLD_SIZE"])
         if world != gpus:
@@ -74,6 +83,14 @@ def plan_launch(gpus: int, argv: list, environ: dict, visible_devices: int, port
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or gpus) // gpus)))
     env["RVLM_SELF_LAUNCHED"] = "1"
     return LaunchPlan("spawn", gpus, cmd, env)
+
+
+def rehearsal_backend(environ) -> str:
+    """'' (a real job: one GPU per rank, RCCL) or 'gloo' (RVLM_BENCH_REHEARSAL=gloo: ranks may share a GPU)."""
+    v = environ.get("RVLM_BENCH_REHEARSAL", "")
+    if v not in ("", "0", "gloo"):
+        raise LaunchError(f"RVLM_BENCH_REHEARSAL={v!r}: the only rehearsal backend is 'gloo'")
+    return "gloo" if v == "gloo" else ""
 
 
 def run_plan(plan: LaunchPlan) -> int:

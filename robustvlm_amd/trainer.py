@@ -185,6 +185,12 @@ class AdversarialTrainer:
                 w.wait()                                                         # the compute stream waits, not the host
         return loss.detach(), emb
 
+    def _verify_pending_global_batch(self):
+        pend, self._pending_global_batch = getattr(self, "_pending_global_batch", None), None
+        if pend is not None and int(pend[0].item()) != pend[1]:
+            raise ValueError(f"global_batch={pend[1]} but the ranks held {int(pend[0].item())} images in that step "
+                             f"(its gradients were mis-scaled by {pend[1] / max(int(pend[0].item()), 1):.4g})")
+
     def _shard_weight(self, n_local: int, global_batch: int | None = None) -> float:
         """The reference's loss is the mean over the GLOBAL batch (DataParallel gathers the outputs first, …clip.py:
         184-191).  Here every rank takes the mean over its shard and AdamW divides the summed gradients by world_size;
@@ -193,13 +199,17 @@ class AdversarialTrainer:
         if self.world == 1:
             return 1.0
         if global_batch is not None:
+            # A wrong value (the last partial batch of an epoch passed with the nominal size, uneven shards) would silently
+            # mis-scale every rank's gradients, so EVERY step that is given one checks it against the all-reduced shard
+            # sizes - without a host sync in front of the backward: the tiny all-reduce is enqueued now, its result is
+            # read at the start of the NEXT step (long complete by then); only the first step waits for it.  Every rank
+            # must pass global_batch (or omit it) consistently: the check is a collective.
+            self._verify_pending_global_batch()
+            n = torch.tensor([float(n_local)], dtype=torch.float64, device=self.device if self._device_collectives else None)
+            dist.all_reduce(n, op=dist.ReduceOp.SUM, group=self.pg)
+            self._pending_global_batch = (n, int(global_batch))
             if not self._checked_global_batch:
-                # a wrong value (a last partial batch, uneven shards) would silently mis-scale every rank's gradients:
-                # the first step that is given one checks it against the all-reduced shard sizes, once
-                n = torch.tensor([float(n_local)], dtype=torch.float64, device=self.device if self._device_collectives else None)
-                dist.all_reduce(n, op=dist.ReduceOp.SUM, group=self.pg)
-                if int(n.item()) != int(global_batch):
-                    raise ValueError(f"global_batch={global_batch} but the ranks hold {int(n.item())} images in this step")
+                self._verify_pending_global_batch()
                 self._checked_global_batch = True
             return n_local * self.world / float(global_batch)
         n = torch.tensor([float(n_local)], dtype=torch.float64)

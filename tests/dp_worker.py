@@ -46,8 +46,20 @@ def main(out):
     for _ in range(2):
         o = tr.train_step(x[lo:hi], None, data_adv=xa_fix[lo:hi], global_metrics=True)
         losses.append(float(o["loss"]))
+    # global_batch given: every step's value is checked against the all-reduced shard sizes - the first step at once,
+    # later ones without a host sync, reported by the following call
+    tr2 = AdversarialTrainer(cfg, w, **kw)
+    for _ in range(2):
+        tr2.train_step(x[lo:hi], None, data_adv=xa_fix[lo:hi], global_batch=B)
+    tr2.train_step(x[lo:hi], None, data_adv=xa_fix[lo:hi], global_batch=B + 1)          # wrong on every rank
+    try:
+        tr2.train_step(x[lo:hi], None, data_adv=xa_fix[lo:hi], global_batch=B)
+        gb_caught = False
+    except ValueError as e:
+        gb_caught = f"global_batch={B + 1}" in str(e)
+    tr2.close()
     torch.save(dict(x_adv=attack(x[lo:hi], d0[lo:hi]), params={k: v.cpu() for k, v in tr.state_dict().items()}, loss_global=losses[-1],
-                    cos_global=float(o["cos_sim"]), cos_clean_global=float(o["cos_sim_clean"])),
+                    cos_global=float(o["cos_sim"]), cos_clean_global=float(o["cos_sim_clean"]), gb_caught=gb_caught),
                os.path.join(out, f"rank{rank}.pt"))
     tr.close()
     dist.barrier()

@@ -471,3 +471,25 @@ def test_apgdattack_rho_vs_reference_golden(tag):
     # is still the closer one (by a wide margin at rho = 0.5, where 38 % of the reference's pixels depend on it)
     assert same > 0.85 and same > same_other + (0.03 if tag == "rho050" else 0.0), (same, same_other)
     eng.close()
+
+
+def test_apgd_train_ignores_a_rho_left_on_the_handle():
+    """rvlm_vit_set_apgd_rho is handle state; train/apgd_train.py hard-codes 0.75 (:117,334), so a C host that ran
+    APGDAttack(rho = 0.5) and then apgd_train on the same handle must still get the 0.75 schedule."""
+    import ctypes as C
+    from oracle import vit_ref as V
+    from tests.test_gpu_engine import make_engine
+    z = load_golden("autopgd_tiny_rho050.npz")
+    cfg = V.VIT_TINY
+    w = V.init_weights(cfg, seed=int(z["weights_seed"]))
+    eng = make_engine(cfg, w, "fp32")
+    model = R.ClipVisionModel(eng).eval()
+    x, y = torch.from_numpy(z["x"]).to(dev()), torch.from_numpy(z["y"]).to(dev())
+    T = torch.from_numpy(z["T"]).to(dev())
+    wrap = R.ComputeLossWrapper(None, T, "none", "ce", 100.)
+    run = lambda: R.apgd_train(model, x, y, "linf", float(z["eps"]), n_iter=30, loss_fn=wrap)     # noqa: E731
+    want = run()
+    L.check(eng.lib.rvlm_vit_set_apgd_rho(eng._h, C.c_double(0.5)))       # behind the Python mirror's back, like a C host
+    assert torch.equal(run(), want)
+    L.check(eng.lib.rvlm_vit_set_apgd_rho(eng._h, C.c_double(0.75)))
+    eng.close()

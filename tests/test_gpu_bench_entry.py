@@ -52,3 +52,60 @@ def test_two_gpu_self_launch():
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert d["n_gpus"] == 2 and d["ranks"]["rccl_ranks"] == 2 and "self-launch" in d["ranks"]["launcher"]
+
+
+# ---- the world > 1 branch of bench.py BEFORE an 8-GPU node runs it -----------------------------------
+# RVLM_BENCH_REHEARSAL=gloo: two ranks share cuda:0 and meet over gloo.  Everything of the N > 1 path runs except the
+# RCCL-only lines (init_process_group("nccl", device_id=...), device-tensor collectives): self-launch under
+# torch.distributed.run on 127.0.0.1, per-rank engines and image shards, barriers, the gather of per-rank times, rank 0's
+# ONE JSON line, the agent's exit code.  Reference's multi-GPU: train/adversarial_training_clip.py:184-191.
+REH = {"RVLM_BENCH_REHEARSAL": "gloo"}
+SMALL = ("--steps", "2", "--warmup", "1", "--model", "ViT-B-32", "--batch", "8", "--no-cpu-baseline")
+
+
+def _one_line(r):
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_two_rank_rehearsal_attack_line():
+    d = _one_line(run("--gpus", "2", *SMALL, env=REH))
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert "rehearsal" in d and "REHEARSAL" in d["data"]
+    rk = d["ranks"]
+    assert rk["gloo_ranks"] == 2 and rk["rccl_ranks"] == 0 and "self-launch" in rk["launcher"]
+    assert 0 < rk["per_rank_images_per_sec_min"] <= rk["per_rank_images_per_sec_max"]
+    assert d["config"]["global_batch"] == 16 and d["config"]["parallelism"].startswith("dp2")
+    # value = all ranks' images / the slowest rank's time
+    assert abs(d["value"] - 2 * rk["per_rank_images_per_sec_min"]) / d["value"] < 1e-6
+
+
+def test_two_rank_rehearsal_under_an_external_launcher():
+    """The driver's own form: python -m torch.distributed.run ... bench.py --gpus 2 (the script is a rank)."""
+    e = dict(os.environ, **REH)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    from robustvlm_amd.launch import free_port
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(free_port()), BENCH, "--gpus", "2", *SMALL],
+                       capture_output=True, text=True, env=e, timeout=600, cwd=ROOT)
+    d = _one_line(r)
+    assert d["n_gpus"] == 2 and d["ranks"]["launcher"] == "external torch.distributed.run"
+
+
+def test_two_rank_rehearsal_dying_rank_exits_nonzero():
+    r = run("--gpus", "2", *SMALL, env=dict(REH, RVLM_BENCH_DIE_RANK="1"), timeout=900)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")], "no throughput line from a job that lost a rank"
+    assert "a rank of the 2-GPU job failed" in r.stderr
+
+
+def test_two_rank_rehearsal_train_step_line():
+    """--mode train --gpus 2: the bucketed gradient all-reduce (through the host copy, gloo) inside bench.py's own loop."""
+    d = _one_line(run("--gpus", "2", "--mode", "train", "--steps", "1", "--warmup", "1", "--model", "ViT-B-32", "--batch", "4",
+                      "--iterations", "2", env=REH, timeout=900))
+    assert d["n_gpus"] == 2 and "rehearsal" in d and d["value"] > 0
+    assert d["allreduce"]["world"] == 2 and "gloo" in d["allreduce"]["backend"]
+    assert d["final_loss"] == d["final_loss"]        # finite

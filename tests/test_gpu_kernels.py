@@ -89,6 +89,80 @@ def test_gemm_f32_strided():
     assert rel_max(C, A.double() @ Bt.double()) < 1e-6
 
 
+def _gemm_f32_ex(A, sA, B, sB, M, N, K, nb=1, alpha=1.0, bias=None, act=-1, want_pre=False, dact_h=None, residual=None,
+                 scn=1):
+    """C[b, m, n] = epi(alpha * sum_k A[b, m, k] B[b, n, k]) through rvlm_k_gemm_f32_ex; sA / sB = (row, k, batch) element
+    strides of the buffers as given."""
+    l = lib()
+    C = torch.full((nb, M, N * scn), float("nan"), device=dev())
+    pre = torch.full_like(C, float("nan")) if want_pre else None
+    L.check(l.rvlm_k_gemm_f32_ex(A.data_ptr(), sA[0], sA[1], sA[2], B.data_ptr(), sB[0], sB[1], sB[2], C.data_ptr(),
+                                 N * scn, scn, M * N * scn, M, N, K, nb, alpha, L.ptr(bias), act, L.ptr(pre), L.ptr(dact_h),
+                                 L.ptr(residual), st()))
+    torch.cuda.synchronize()
+    return C, pre
+
+
+F32_CASES = [   # M, N, K, nb, A k-contiguous, B k-contiguous
+    (70, 130, 50, 1, True, False), (70, 130, 50, 1, False, True), (257, 257, 64, 6, True, True),     # scores = Q K^T
+    (257, 64, 257, 6, True, False), (257, 64, 257, 6, False, False),                                  # P V / dS^T Q
+    (1028, 3072, 1024, 1, True, True), (514, 1024, 4096, 1, True, False), (1285, 768, 3072, 1, True, True),
+    (640, 512, 37, 1, True, True), (33, 1000, 768, 1, True, False), (300, 70, 129, 3, False, True),
+]
+
+
+@pytest.mark.parametrize("M,N,K,nb,akc,bkc", F32_CASES)
+def test_gemm_f32_mfma_bit_identical_to_valu_chain(M, N, K, nb, akc, bkc):
+    """The fp32 parity mode runs on v_mfma_f32_32x32x2_f32 since round 5.  The guide states the instruction IS the
+    k-ordered fp32 fma chain (one rounding per product, no wider internal sum); this pins it on our kernels: every
+    stride form of the encoder's fp32 GEMMs (incl. the unaligned S = 257 attention products, K tails, batches) gives the
+    SAME BITS on the matrix-pipe tiles and on the explicit VALU fmaf-chain tiles - and both agree with fp64."""
+    l = lib()
+    g = torch.Generator(device="cuda").manual_seed(M * 7 + N * 3 + K + nb)
+    A = torch.randn(nb, M, K, generator=g, device=dev())
+    B = torch.randn(nb, N, K, generator=g, device=dev()) * K ** -0.5
+    ref = torch.einsum("bmk,bnk->bmn", A.double(), B.double())
+    Ab, sA = (A, (K, 1, M * K)) if akc else (A.transpose(1, 2).contiguous(), (1, M, M * K))
+    Bb, sB = (B, (K, 1, N * K)) if bkc else (B.transpose(1, 2).contiguous(), (1, N, N * K))
+    bias = torch.randn(N, generator=g, device=dev())
+    outs = []
+    for valu in (0, 1):
+        l.rvlm_k_gemm_f32_set_valu(valu)
+        try:
+            c_plain, _ = _gemm_f32_ex(Ab, sA, Bb, sB, M, N, K, nb, alpha=0.125)
+            c_bias, _ = _gemm_f32_ex(Ab, sA, Bb, sB, M, N, K, nb, bias=bias)
+            hp = torch.randn(nb, M, N, generator=torch.Generator(device="cuda").manual_seed(5), device=dev())
+            res = torch.randn(nb, M, N, generator=torch.Generator(device="cuda").manual_seed(6), device=dev())
+            c_act, c_pre = _gemm_f32_ex(Ab, sA, Bb, sB, M, N, K, nb, bias=bias, act=0, want_pre=True)
+            c_dact, _ = _gemm_f32_ex(Ab, sA, Bb, sB, M, N, K, nb, dact_h=hp)
+            c_res, _ = _gemm_f32_ex(Ab, sA, Bb, sB, M, N, K, nb, bias=bias, residual=res)
+        finally:
+            l.rvlm_k_gemm_f32_set_valu(0)
+        outs.append((c_plain, c_bias, c_act, c_pre, c_dact, c_res))
+    for a, b in zip(*outs):
+        assert not torch.isnan(a).any()
+        assert torch.equal(a, b), float((a - b).abs().max())
+    c_plain, c_bias, c_act, c_pre, c_dact, c_res = outs[0]
+    assert rel_max(c_plain, 0.125 * ref) < 2e-6
+    assert rel_max(c_bias, ref + bias.double()) < 2e-6
+    assert rel_max(c_pre, ref + bias.double()) < 2e-6
+    assert rel_max(c_act, act_ref(ref + bias.double(), 0)) < 1e-5
+    assert rel_max(c_dact, ref * dact_ref(hp.double(), 0)) < 1e-5
+    assert rel_max(c_res, ref + bias.double() + res.double()) < 2e-6
+
+
+def test_gemm_f32_column_strided_output():
+    """scn != 1 (the strided-output form GemmF32 allows) on the matrix-pipe tiles."""
+    g = torch.Generator(device="cuda").manual_seed(11)
+    M, N, K = 130, 70, 96
+    A = torch.randn(1, M, K, generator=g, device=dev())
+    B = torch.randn(1, N, K, generator=g, device=dev())
+    C, _ = _gemm_f32_ex(A, (K, 1, M * K), B, (K, 1, N * K), M, N, K, scn=2)
+    ref = (A[0].double() @ B[0].double().t())
+    assert rel_max(C[0, :, 0::2], ref) < 2e-6
+    assert torch.isnan(C[0, :, 1::2]).all()
+
+
 def test_ds_read_tr16_semantics():
     """Pins the LDS transpose-read the attention kernels rely on: within a 16-lane group, lanes
     4j..4j+3 supply the 8-byte chunks of row j of a 4x16 block and lane i receives column i."""

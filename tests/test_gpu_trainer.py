@@ -328,6 +328,7 @@ def test_data_parallel_step_two_ranks_one_gpu(tmp_path):
         assert float((got - want).abs().max()) < 5e-2 * moved, (k, float((got - want).abs().max()), moved)
     # logging values with global_metrics=True: the global-batch means the reference's DataParallel would log, on every rank
     for r_ in res:
+        assert r_["gb_caught"] is True                    # a wrong global_batch in a LATER step is reported too
         assert abs(r_["loss_global"] - single["loss"]) <= 1e-5 * abs(single["loss"])
         assert abs(r_["cos_global"] - single["cos"]) <= 1e-5 and abs(r_["cos_clean_global"] - single["cos_clean"]) <= 1e-5
 
@@ -363,6 +364,25 @@ def test_cabi_allreduce_grads_on_rccl(tmp_path):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     got = torch.load(out)
     assert got["ok"] and got["bad_dtype_rc"] == L.RVLM_ERR_ARG, got
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL refuses two ranks on one device)")
+def test_cabi_allreduce_grads_two_ranks_sum(tmp_path):
+    """a REAL multi-rank sum through rvlm_allreduce_grads (two processes, one GPU each, no torch.distributed), and
+    the current-device check of the call."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    idfile = str(tmp_path / "rccl_id.bin")
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "comm_worker.py"), str(tmp_path / f"c{r}.pt"), str(r), "2",
+                               idfile], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-2000:] for o in outs)
+    for r in range(2):
+        got = torch.load(str(tmp_path / f"c{r}.pt"))
+        assert got["ok"] and got["wrong_dev_rc"] == L.RVLM_ERR_STATE, got
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])

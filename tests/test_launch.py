@@ -86,3 +86,19 @@ def test_bench_refuses_without_a_gpu():
         pytest.skip("CPU-container check")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True)
     assert r.returncode != 0 and "MI355X" in (r.stderr + r.stdout)
+
+
+def test_rehearsal_lets_ranks_share_a_device():
+    """RVLM_BENCH_REHEARSAL=gloo: N ranks on fewer GPUs, so that the world > 1 branch of bench.py can
+    run on a 1-GPU box; without the switch the same request stays an error."""
+    env = {"RVLM_BENCH_REHEARSAL": "gloo"}
+    p = plan_launch(2, ARGV, env, visible_devices=1, port=29556)
+    assert p.role == "spawn" and p.world == 2 and p.env["RVLM_BENCH_REHEARSAL"] == "gloo"
+    r = plan_launch(2, ARGV, dict(env, WORLD_SIZE="2", RANK="1", LOCAL_RANK="1"), visible_devices=1)
+    assert r.role == "rank" and r.world == 2
+    with pytest.raises(LaunchError):
+        plan_launch(2, ARGV, env, visible_devices=0)            # a rehearsal still needs a GPU
+    with pytest.raises(LaunchError):
+        plan_launch(2, ARGV, {"RVLM_BENCH_REHEARSAL": "mpi"}, visible_devices=2)
+    with pytest.raises(LaunchError):
+        plan_launch(2, ARGV, {}, visible_devices=1)
