@@ -158,6 +158,9 @@ __device__ __forceinline__ f32x16 zero16() {
 }
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#ifndef RVLM_ATTN_BWD_VARIANT
+#define RVLM_ATTN_BWD_VARIANT 0
+#endif
 // raw v_exp_f32 (2^x): arguments here are <= ~6 and results below 2^-126 may flush to 0, which is what
 // softmax wants; exp2f() would wrap every call in denormal-range fix-ups (~6 VALU instead of 1)
 #define EXP2(x) __builtin_amdgcn_exp2f(x)
@@ -875,15 +878,44 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
     };
     for (int qt = 0; qt < NT; ++qt) {
         f32x16 s = zero16(), dp = zero16();
+        // Round 5: the tile's 32 lse / D values (8 x 16 B per lane, two distinct addresses per instruction: broadcasts) are
+        // requested HERE, in front of the S / dP MFMAs.  hipcc placed each of the eight reads directly in front of its four
+        // exp / dS evaluations, followed by its own s_waitcnt lgkmcnt(0): eight exposed LDS round trips (~100+ cycles each
+        // with eight waves on the LDS) in the middle of the softmax arithmetic of every tile and wave - a third of the
+        // 3.0 k cycles a tile took.  The sched_barrier pins them; the MFMA phase (>= 256 cycles) covers their latency, and
+        // the 32 registers are free at this point of the step (dO^T / Q^T / dS fragments are not live yet).
+#if RVLM_ATTN_BWD_VARIANT >= 1
+        float4 lq4[4], dq4[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            lq4[g] = *(const float4*)(Ls + qt * 32 + 8 * g + 4 * hi);
+            dq4[g] = *(const float4*)(Ds + qt * 32 + 8 * g + 4 * hi);
+        }
+#if RVLM_ATTN_BWD_VARIANT >= 2     // ... and the eight row-major Q / dO fragments of the step in one batch behind them
+        bf16x8 qfr[4], dfr[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) { qfr[kk] = frag_rm(Qt, qt * 32, fo.rm[kk]); dfr[kk] = frag_rm(Dt, qt * 32, fo.rm[kk]); }
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
+#if RVLM_ATTN_BWD_VARIANT >= 2
+            s = MFMA(qfr[kk], kf[kk], s);
+            dp = MFMA(dfr[kk], vf[kk], dp);
+#else
             s = MFMA(frag_rm(Qt, qt * 32, fo.rm[kk]), kf[kk], s);      // S[q][key]: lane <-> key, regs <-> q
             dp = MFMA(frag_rm(Dt, qt * 32, fo.rm[kk]), vf[kk], dp);    // dP[q][key]
+#endif
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
+#if RVLM_ATTN_BWD_VARIANT >= 1
+            const float4 lq = lq4[g], dq = dq4[g];
+#else
             const float4 lq = *(const float4*)(Ls + qt * 32 + 8 * g + 4 * hi);
             const float4 dq = *(const float4*)(Ds + qt * 32 + 8 * g + 4 * hi);
+#endif
             const float lqa[4] = {lq.x, lq.y, lq.z, lq.w};
             const float dqa[4] = {dq.x, dq.y, dq.z, dq.w};
 #pragma unroll

@@ -263,23 +263,26 @@ template <>
 int attention_fwd<bf16_t>(rvlm_vit* h, hipStream_t s, const void* qkv, void* o, float* lse, int B) {
     return attn_fwd_bf16((const bf16_t*)qkv, 3 * h->W, (bf16_t*)o, h->W, lse, B, h->H, h->S, s);
 }
+// fp32 mode: the score matrices are materialised as [B, H, S, Sld] with Sld = round_up(S, 4) and zero pad columns (never
+// written), so that every product that contracts over or runs along the key dimension of S = 257 takes 16-byte operand loads
+// on the fp32 matrix-pipe tiles (GemmF32::pad4); round 5: the unaligned scalar-load form ran the attention core at 26 TFLOP/s.
 static int attn_scores_f32(rvlm_vit* h, hipStream_t s, const float* qkv, int B) {
-    const int S = h->S, W = h->W, H = h->H;
+    const int S = h->S, W = h->W, H = h->H, Sld = (int)round_up(S, 4);
     GemmF32 g;  // scores = 0.125 * Q K^T
     g.A = qkv; g.sam = 3 * W; g.sak = 1; g.sab1 = (long)S * 3 * W; g.sab2 = 64;
     g.B = qkv + W; g.sbn = 3 * W; g.sbk = 1; g.sbb1 = (long)S * 3 * W; g.sbb2 = 64;
-    g.C = h->scores; g.scm = S; g.scn = 1; g.scb1 = (long)H * S * S; g.scb2 = (long)S * S;
+    g.C = h->scores; g.scm = Sld; g.scn = 1; g.scb1 = (long)H * S * Sld; g.scb2 = (long)S * Sld;
     g.M = S; g.N = S; g.K = 64; g.nb1 = B; g.nb2 = H; g.alpha = 0.125f;
     int rc = gemm_f32(g, s); if (rc) return rc;
-    return softmax_rows_fwd(h->scores, (long)B * H * S, S, s);
+    return softmax_rows_fwd(h->scores, (long)B * H * S, S, Sld, s);
 }
 template <>
 int attention_fwd<float>(rvlm_vit* h, hipStream_t s, const void* qkv_, void* o, float*, int B) {
-    const int S = h->S, W = h->W, H = h->H;
+    const int S = h->S, W = h->W, H = h->H, Sld = (int)round_up(S, 4);
     const float* qkv = (const float*)qkv_;
     int rc = attn_scores_f32(h, s, qkv, B); if (rc) return rc;
     GemmF32 g;  // O = P V
-    g.A = h->scores; g.sam = S; g.sak = 1; g.sab1 = (long)H * S * S; g.sab2 = (long)S * S;
+    g.A = h->scores; g.sam = Sld; g.sak = 1; g.sab1 = (long)H * S * Sld; g.sab2 = (long)S * Sld; g.pad4 = 1;
     g.B = qkv + 2 * W; g.sbn = 1; g.sbk = 3 * W; g.sbb1 = (long)S * 3 * W; g.sbb2 = 64;
     g.C = (float*)o; g.scm = W; g.scn = 1; g.scb1 = (long)S * W; g.scb2 = 64;
     g.M = S; g.N = 64; g.K = S; g.nb1 = B; g.nb2 = H;
@@ -297,33 +300,33 @@ int attention_bwd<bf16_t>(rvlm_vit* h, hipStream_t s, const void* qkv, const voi
 template <>
 int attention_bwd<float>(rvlm_vit* h, hipStream_t s, const void* qkv_, const void*, const void* d_o_,
                          const float*, void* dqkv_, int B) {
-    const int S = h->S, W = h->W, H = h->H;
+    const int S = h->S, W = h->W, H = h->H, Sld = (int)round_up(S, 4);
     const float* qkv = (const float*)qkv_;
     const float* d_o = (const float*)d_o_;
     float* dqkv = (float*)dqkv_;
     int rc = attn_scores_f32(h, s, qkv, B); if (rc) return rc;  // recompute P
-    const long bs1 = (long)H * S * S, bs2 = (long)S * S, qs1 = (long)S * 3 * W, os1 = (long)S * W;
+    const long bs1 = (long)H * S * Sld, bs2 = (long)S * Sld, qs1 = (long)S * 3 * W, os1 = (long)S * W;
     GemmF32 g;  // dP = dO V^T
     g.A = d_o; g.sam = W; g.sak = 1; g.sab1 = os1; g.sab2 = 64;
     g.B = qkv + 2 * W; g.sbn = 3 * W; g.sbk = 1; g.sbb1 = qs1; g.sbb2 = 64;
-    g.C = h->dscores; g.scm = S; g.scn = 1; g.scb1 = bs1; g.scb2 = bs2;
+    g.C = h->dscores; g.scm = Sld; g.scn = 1; g.scb1 = bs1; g.scb2 = bs2;
     g.M = S; g.N = S; g.K = 64; g.nb1 = B; g.nb2 = H;
     if ((rc = gemm_f32(g, s))) return rc;
-    if ((rc = softmax_rows_bwd(h->scores, h->dscores, (long)B * H * S, S, 0.125f, s))) return rc;
+    if ((rc = softmax_rows_bwd(h->scores, h->dscores, (long)B * H * S, S, Sld, 0.125f, s))) return rc;
     GemmF32 q;  // dQ = dS K
-    q.A = h->dscores; q.sam = S; q.sak = 1; q.sab1 = bs1; q.sab2 = bs2;
+    q.A = h->dscores; q.sam = Sld; q.sak = 1; q.sab1 = bs1; q.sab2 = bs2; q.pad4 = 1;
     q.B = qkv + W; q.sbn = 1; q.sbk = 3 * W; q.sbb1 = qs1; q.sbb2 = 64;
     q.C = dqkv; q.scm = 3 * W; q.scn = 1; q.scb1 = qs1; q.scb2 = 64;
     q.M = S; q.N = 64; q.K = S; q.nb1 = B; q.nb2 = H;
     if ((rc = gemm_f32(q, s))) return rc;
     GemmF32 k;  // dK = dS^T Q
-    k.A = h->dscores; k.sam = 1; k.sak = S; k.sab1 = bs1; k.sab2 = bs2;
+    k.A = h->dscores; k.sam = 1; k.sak = Sld; k.sab1 = bs1; k.sab2 = bs2; k.pad4 = 1;
     k.B = qkv; k.sbn = 1; k.sbk = 3 * W; k.sbb1 = qs1; k.sbb2 = 64;
     k.C = dqkv + W; k.scm = 3 * W; k.scn = 1; k.scb1 = qs1; k.scb2 = 64;
     k.M = S; k.N = 64; k.K = S; k.nb1 = B; k.nb2 = H;
     if ((rc = gemm_f32(k, s))) return rc;
     GemmF32 v;  // dV = P^T dO
-    v.A = h->scores; v.sam = 1; v.sak = S; v.sab1 = bs1; v.sab2 = bs2;
+    v.A = h->scores; v.sam = 1; v.sak = Sld; v.sab1 = bs1; v.sab2 = bs2; v.pad4 = 1;
     v.B = d_o; v.sbn = 1; v.sbk = W; v.sbb1 = os1; v.sbb2 = 64;
     v.C = dqkv + 2 * W; v.scm = 3 * W; v.scn = 1; v.scb1 = qs1; v.scb2 = 64;
     v.M = S; v.N = 64; v.K = S; v.nb1 = B; v.nb2 = H;
@@ -885,8 +888,9 @@ extern "C" int rvlm_vit_create(const rvlm_vit_config* cfg, const rvlm_vit_weight
     ALLOC_OR_DIE(h->d_raw, (size_t)B * D * 4);
     ALLOC_OR_DIE(h->d_pooled, (size_t)B * W * 4);
     if (!h->bf16) {
-        ALLOC_OR_DIE(h->scores, (size_t)B * h->H * S * S * 4);
-        ALLOC_OR_DIE(h->dscores, (size_t)B * h->H * S * S * 4);
+        // [B, H, S, round_up(S, 4)], zero-initialised: the pad columns are never written (attn_scores_f32)
+        ALLOC_OR_DIE(h->scores, (size_t)B * h->H * S * round_up(S, 4) * 4);
+        ALLOC_OR_DIE(h->dscores, (size_t)B * h->H * S * round_up(S, 4) * 4);
     } else { h->scores = h->dscores = nullptr; }
     h->trainable = cfg->trainable > 0;
     h->tokens = h->dtok = nullptr; h->tA = h->tB = nullptr;

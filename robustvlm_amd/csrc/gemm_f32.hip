@@ -173,10 +173,14 @@ __global__ void __launch_bounds__(256) gemm_f32_mfma_kernel(GemmF32 p, int vec_a
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
     const bool va = vec_a != 0, vb = vec_b != 0;     // (kernel arguments: wave-uniform branches)
+    // loader bounds: exact, or rounded up to 4 along the operand's contiguous dimension when its padding is readable
+    // (GemmF32::pad4: zeros along k; along the rows the extra rows only feed outputs that are never stored)
+    const int Ka = (A_KC && (p.pad4 & 1)) ? ((p.K + 3) & ~3) : p.K, Ma = (!A_KC && (p.pad4 & 1)) ? ((p.M + 3) & ~3) : p.M;
+    const int Kb = (B_KC && (p.pad4 & 2)) ? ((p.K + 3) & ~3) : p.K, Nb = (!B_KC && (p.pad4 & 2)) ? ((p.N + 3) & ~3) : p.N;
     F32TileLoader<BM, A_KC> la;
     F32TileLoader<BN, B_KC> lb;
-    la.load(A, p.sam, p.sak, m0, p.M, 0, p.K, tid, va);
-    lb.load(Bm, p.sbn, p.sbk, n0, p.N, 0, p.K, tid, vb);
+    la.load(A, p.sam, p.sak, m0, Ma, 0, Ka, tid, va);
+    lb.load(Bm, p.sbn, p.sbk, n0, Nb, 0, Kb, tid, vb);
     la.store(As[0], tid);
     lb.store(Bs[0], tid);
     __syncthreads();
@@ -184,8 +188,8 @@ __global__ void __launch_bounds__(256) gemm_f32_mfma_kernel(GemmF32 p, int vec_a
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) {
-            la.load(A, p.sam, p.sak, m0, p.M, (kt + 1) * BK, p.K, tid, va);
-            lb.load(Bm, p.sbn, p.sbk, n0, p.N, (kt + 1) * BK, p.K, tid, vb);
+            la.load(A, p.sam, p.sak, m0, Ma, (kt + 1) * BK, Ka, tid, va);
+            lb.load(Bm, p.sbn, p.sbk, n0, Nb, (kt + 1) * BK, Kb, tid, vb);
         }
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {     // k increases: the sum order of every output element is k = 0, 1, 2, ...
@@ -253,10 +257,10 @@ static void launch_f32_mfma(const GemmF32& p, bool akc, bool bkc, bool va, bool 
 
 // 16-byte accesses to one operand: contiguous along k (kc) or along its rows, every other stride, the batch offsets and
 // the base a multiple of 4 floats, and the contiguous extent a multiple of 4 (a chunk is then all inside or all outside)
-static bool f32_vec_ok(const float* base, bool kc, long s_row, long s_k, long sb1, long sb2, int nrows, int K) {
+static bool f32_vec_ok(const float* base, bool kc, long s_row, long s_k, long sb1, long sb2, int nrows, int K, bool pad) {
     if (((uintptr_t)base & 15) || (sb1 & 3) || (sb2 & 3)) return false;
-    if (kc) return s_k == 1 && !(s_row & 3) && !(K & 3);
-    return s_row == 1 && !(s_k & 3) && !(nrows & 3);
+    if (kc) return s_k == 1 && !(s_row & 3) && (pad || !(K & 3));
+    return s_row == 1 && !(s_k & 3) && (pad || !(nrows & 3));
 }
 
 // ---- few-row problems (the projection head: M = batch).  The 64x64-tile kernel gives them a couple of dozen
@@ -357,8 +361,8 @@ int gemm_f32(const GemmF32& p, hipStream_t s) {
     if (!g_f32_valu) {
         // matrix-pipe tiles: the tile shape with the least padded volume, the larger one on a tie if it still gives
         // every CU a workgroup (S = 257 attention products: 64-row tiles pad to 320, 128-row tiles to 384)
-        const bool va = f32_vec_ok(p.A, akc, p.sam, p.sak, p.sab1, p.sab2, p.M, p.K);
-        const bool vb = f32_vec_ok(p.B, bkc, p.sbn, p.sbk, p.sbb1, p.sbb2, p.N, p.K);
+        const bool va = f32_vec_ok(p.A, akc, p.sam, p.sak, p.sab1, p.sab2, p.M, p.K, p.pad4 & 1);
+        const bool vb = f32_vec_ok(p.B, bkc, p.sbn, p.sbk, p.sbb1, p.sbb2, p.N, p.K, p.pad4 & 2);
         const long nb = (long)p.nb1 * p.nb2;
         auto vol = [&](int bm, int bn) { return (long)cdiv(p.M, bm) * bm * ((long)cdiv(p.N, bn) * bn); };
         auto wgs = [&](int bm, int bn) { return (long)cdiv(p.M, bm) * cdiv(p.N, bn) * nb; };

@@ -22,6 +22,10 @@ struct GemmF32 {
     const float* dact_h = nullptr;     // optional: multiply by act'(dact_h[m,n]) (layout of C)
     int dact_kind = RVLM_ACT_QUICK_GELU;
     const float* residual = nullptr;   // optional: + residual[m,n] (layout of C)
+    // bit 0 (A) / bit 1 (B): along its contiguous dimension the operand is READABLE up to the next multiple of 4 elements,
+    // and where that dimension is k the padding holds zeros (the engine's [.., S, round_up(S, 4)] score matrices): lets the
+    // S = 257 attention products of the fp32 mode use 16-byte loads
+    int pad4 = 0;
 };
 int gemm_f32(const GemmF32& p, hipStream_t s);
 void gemm_f32_set_valu(int on);   // test hook: 1 = the VALU fmaf-chain tiles instead of the fp32 MFMA tiles
@@ -121,9 +125,9 @@ int l2_normalize_bwd(const float* d_out, const float* e_raw, const float* inv_no
 // ---------------------------------------------------------------------------------------------
 // Softmax rows for the fp32 attention path (scores materialised): in place
 // ---------------------------------------------------------------------------------------------
-int softmax_rows_fwd(float* s, long rows, int cols, hipStream_t st);
+int softmax_rows_fwd(float* s, long rows, int cols, int ld, hipStream_t st);   // rows of `cols` values, `ld` floats apart
 // ds = p * (dp - sum_j p_j dp_j) * scale, in place over dp
-int softmax_rows_bwd(const float* p, float* dp, long rows, int cols, float scale, hipStream_t st);
+int softmax_rows_bwd(const float* p, float* dp, long rows, int cols, int ld, float scale, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------
 // bf16 flash attention (head_dim 64), qkv packed [M, 3W] bf16 (q | k | v), tokens of image b at

@@ -574,11 +574,11 @@ int l2_normalize_bwd(const float* d_out, const float* e_raw, const float* inv_no
 // =============================================================================================
 // Softmax over rows (fp32 attention path, scores materialised), one wave per row, in place
 // =============================================================================================
-__global__ void __launch_bounds__(256) softmax_fwd_kernel(float* __restrict__ s, long rows, int cols) {
+__global__ void __launch_bounds__(256) softmax_fwd_kernel(float* __restrict__ s, long rows, int cols, int ld) {
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
-    float* r = s + row * cols;
+    float* r = s + row * ld;
     float m = -INFINITY;
     for (int c = lane; c < cols; c += 64) m = fmaxf(m, r[c]);
     m = wave_max(m);
@@ -588,25 +588,25 @@ __global__ void __launch_bounds__(256) softmax_fwd_kernel(float* __restrict__ s,
     for (int c = lane; c < cols; c += 64) r[c] = r[c] / sum;
 }
 __global__ void __launch_bounds__(256)
-softmax_bwd_kernel(const float* __restrict__ p, float* __restrict__ dp, long rows, int cols,
+softmax_bwd_kernel(const float* __restrict__ p, float* __restrict__ dp, long rows, int cols, int ld,
                    float scale) {
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
-    const float* pr = p + row * cols;
-    float* dr = dp + row * cols;
+    const float* pr = p + row * ld;
+    float* dr = dp + row * ld;
     float dot = 0.0f;
     for (int c = lane; c < cols; c += 64) dot = fmaf(pr[c], dr[c], dot);
     dot = wave_sum(dot);
     for (int c = lane; c < cols; c += 64) dr[c] = pr[c] * (dr[c] - dot) * scale;
 }
-int softmax_rows_fwd(float* s, long rows, int cols, hipStream_t st) {
-    hipLaunchKernelGGL(softmax_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, s, rows, cols);
+int softmax_rows_fwd(float* s, long rows, int cols, int ld, hipStream_t st) {
+    hipLaunchKernelGGL(softmax_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, s, rows, cols, ld);
     RVLM_CHECK_LAUNCH();
     return RVLM_OK;
 }
-int softmax_rows_bwd(const float* p, float* dp, long rows, int cols, float scale, hipStream_t st) {
-    hipLaunchKernelGGL(softmax_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, p, dp, rows, cols,
+int softmax_rows_bwd(const float* p, float* dp, long rows, int cols, int ld, float scale, hipStream_t st) {
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, p, dp, rows, cols, ld,
                        scale);
     RVLM_CHECK_LAUNCH();
     return RVLM_OK;

