@@ -255,24 +255,15 @@ attn_fwd_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict__ o,
 // MFMA block); the odd query (row S-1) is split over the waves - wave w evaluates it against key tile w - and the NK
 // partial (max, sum, O) triples are merged through 2 KiB of LDS.
 // =============================================================================================
-template <int NK>
-__global__ void __launch_bounds__(NK * 64, 4)    // 4 waves per SIMD = two 8-wave workgroups per CU (128 VGPRs)
-attn_fwd_odd_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict__ o, long ldo,
-                    float* __restrict__ lse2, int H, long W, float scale_log2, AttnLayout lay) {
-    constexpr int S = 32 * NK + 1, Sp = 32 * NK + 32;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Kt = smem;
-    char* Vt = smem + (size_t)Sp * 128;
-    float* mrg = (float*)(smem + (size_t)Sp * 256);     // [NK][66]: m, sum, O[64] of the odd query per key tile; then NK x 32
-                                                          // bf16: p of the odd query, staged into B-operand order
-    const int b = blockIdx.x / H, h = blockIdx.x % H;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+// One (image, head) of the S = 32 NK + 1 forward with K and V staged in LDS (Kt / Vt) - shared by the one-workgroup-per-head
+// kernel and the persistent double-buffered one.  PRE: the wave's own query fragments were requested by the caller
+// (qf_pre); otherwise they are loaded here.  Ends with the workgroup barrier + wave 0's merge of the odd query.
+template <int NK, bool PRE>
+__device__ __forceinline__ void attn_fwd_odd_head(const char* Kt, const char* Vt, float* mrg, const bf16_t* base, long ld,
+                                                  bf16_t* obase, long ldo, float* lse_bh, float scale_log2, int lane, int w,
+                                                  const bf16x8 (&qf_pre)[4], const bf16x8 (&qo_pre)[4]) {
+    constexpr int S = 32 * NK + 1;
     const int l31 = lane & 31, hi = lane >> 5;
-    const bf16_t* base = qkv + (long)b * lay.qkv_b + (long)h * lay.qkv_h;   // (W = element offset from Q to K, K to V)
-    stage_tile(Kt, base + W, ld, S, Sp, w, NK, lane);
-    stage_tile(Vt, base + 2 * W, ld, S, Sp, w, NK, lane);
-    __syncthreads();
-
     const FragOffs fo = make_offs(lane);
     constexpr float RESCALE_THR = 6.0f;
     // row S-1 = 32 NK of a tile: swz_key(row) == 0, i.e. its chunks are not swizzled
@@ -338,7 +329,7 @@ attn_fwd_odd_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict_
         const int q = w * 32 + l31;
         bf16x8 qf[4];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) qf[kk] = frag_global(base, ld, q, kk, lane);
+        for (int kk = 0; kk < 4; ++kk) qf[kk] = PRE ? qf_pre[kk] : frag_global(base, ld, q, kk, lane);
         f32x16 oacc[2] = {zero16(), zero16()};
         float m = -INFINITY, l = 0.0f;
 #pragma unroll 1
@@ -346,7 +337,7 @@ attn_fwd_odd_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict_
         odd_key(qf, m, l, oacc);
         const float ltot = l + __shfl_xor(l, 32, 64);
         const float inv = 1.0f / ltot;
-        bf16_t* orow = o + (long)b * lay.o_b + (long)h * lay.o_h + (long)q * ldo;
+        bf16_t* orow = obase + (long)q * ldo;
         // A lane holds 4 consecutive d per (dt, g) and its partner lane ^ 32 the next 4: v_permlane32_swap pairs the two
         // 8-byte halves of the even chunk on the lower lanes and of the odd chunk on the upper lanes, so that the row leaves
         // as four 16-byte stores per lane instead of eight 8-byte ones (the store tail of this kernel is issue-bound).
@@ -370,14 +361,14 @@ attn_fwd_odd_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict_
                 const u32x4v out = {r0[0], r1[0], r0[1], r1[1]};
                 *(u32x4v*)(orow + dt * 32 + 16 * pr + 8 * hi) = out;
             }
-        if (hi == 0 && lse2) lse2[((long)b * H + h) * Sp + q] = m + log2f(ltot);
+        if (hi == 0 && lse_bh) lse_bh[q] = m + log2f(ltot);
     }
     {   // ---- the odd query against key tile w, in the TRANSPOSED orientation: S = q K^T has the keys on the lanes and the
         // (identical) query rows on the registers, so the softmax costs one exp per lane instead of sixteen; p goes
         // through 64 B of LDS into the B-operand layout of the P.V product ----
         bf16x8 qf[4];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) qf[kk] = frag_global(base, ld, S - 1, kk, lane);
+        for (int kk = 0; kk < 4; ++kk) qf[kk] = PRE ? qo_pre[kk] : frag_global(base, ld, S - 1, kk, lane);
         f32x16 st = zero16();
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) st = MFMA(qf[kk], frag_rm(Kt, w * 32, fo.rm[kk]), st);
@@ -425,8 +416,96 @@ attn_fwd_odd_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict_
             L = fmaf(mrg[i * 66 + 1], c, L);
             O = fmaf(mrg[i * 66 + 2 + lane], c, O);
         }
-        o[(long)b * lay.o_b + (long)h * lay.o_h + (long)(S - 1) * ldo + lane] = (bf16_t)(O / L);
-        if (lane == 0 && lse2) lse2[((long)b * H + h) * Sp + S - 1] = M + log2f(L);
+        obase[(long)(S - 1) * ldo + lane] = (bf16_t)(O / L);
+        if (lane == 0 && lse_bh) lse_bh[S - 1] = M + log2f(L);
+    }
+}
+
+template <int NK>
+__global__ void __launch_bounds__(NK * 64, 4)    // 4 waves per SIMD = two 8-wave workgroups per CU (128 VGPRs)
+attn_fwd_odd_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict__ o, long ldo,
+                    float* __restrict__ lse2, int H, long W, float scale_log2, AttnLayout lay) {
+    constexpr int S = 32 * NK + 1, Sp = 32 * NK + 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Kt = smem;
+    char* Vt = smem + (size_t)Sp * 128;
+    float* mrg = (float*)(smem + (size_t)Sp * 256);     // [NK][66]: m, sum, O[64] of the odd query per key tile; then NK x 32
+                                                          // bf16: p of the odd query, staged into B-operand order
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const bf16_t* base = qkv + (long)b * lay.qkv_b + (long)h * lay.qkv_h;   // (W = element offset from Q to K, K to V)
+    stage_tile(Kt, base + W, ld, S, Sp, w, NK, lane);
+    stage_tile(Vt, base + 2 * W, ld, S, Sp, w, NK, lane);
+    __syncthreads();
+    const bf16x8 none[4] = {};
+    attn_fwd_odd_head<NK, false>(Kt, Vt, mrg, base, ld, o + (long)b * lay.o_b + (long)h * lay.o_h, ldo,
+                                 lse2 ? lse2 + ((long)b * H + h) * Sp : nullptr, scale_log2, lane, w, none, none);
+}
+
+// PERSISTENT, DOUBLE-BUFFERED forward (round 5; RVLM_ATTN_FWD_PERSIST): <= 256 workgroups of NK waves (one per CU, 2 waves
+// per SIMD) walk the (image, head) pairs with TWO K / V slots in LDS (2 x 72 KiB): right after the barrier that opens head
+// i, every wave requests its share of head i + 1's K and V into the other slot (inline-asm LDS-DMA: a compiler-visible one
+// would make hipcc drain vmcnt in front of every LDS read of the slot in use) and its own query fragments into registers -
+// a head's 98 KB of HBM traffic arrives UNDER the previous head's MFMA / softmax work instead of in front of its own.  The
+// one-workgroup-per-head kernel relies on the dispatcher keeping the two workgroups of a CU out of phase for that overlap;
+// measured, a head-slot took 21 k cycles there against ~11 k of HBM time and ~6 k of issue time.
+template <int NK>
+__global__ void __launch_bounds__(NK * 64)
+attn_fwd_odd_pers_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict__ o, long ldo,
+                         float* __restrict__ lse2, int H, long W, float scale_log2, AttnLayout lay, int nbh) {
+    constexpr int S = 32 * NK + 1, Sp = 32 * NK + 32, SLOT = Sp * 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* mrg = (float*)(smem + 2 * (size_t)SLOT);
+    // next head's K and V -> slot `dst` (8 rows = 1 KiB per instruction; the swizzle rides on the per-lane source address)
+    auto stage_asm = [&](char* dst, const bf16_t* src, int w, int lane) {
+        for (int blk = w; blk < (Sp >> 3); blk += NK) {
+            const int row = blk * 8 + (lane >> 3);
+            const bf16_t* gp = src + (long)min(row, S - 1) * ld + ((lane & 7) ^ swz_key(row)) * 8;
+            const unsigned d = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_char*)(dst + blk * 1024));
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gp), "s"(d) : "memory", "m0");
+        }
+    };
+    auto head_base = [&](int bh) { return qkv + (long)(bh / H) * lay.qkv_b + (long)(bh % H) * lay.qkv_h; };
+    // (the query fragments - the wave's own tile and the odd query - are requested IN FRONT of the K / V requests: VMEM returns
+    // in order, so a load issued behind them would be handed over only after the whole next head has landed)
+    bf16x8 qf_next[4], qo_next[4];
+    {
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        const bf16_t* b0 = head_base(blockIdx.x);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            qf_next[kk] = frag_global(b0, ld, w * 32 + (lane & 31), kk, lane);
+            qo_next[kk] = frag_global(b0, ld, S - 1, kk, lane);
+        }
+        stage_asm(smem, b0 + W, w, lane);
+        stage_asm(smem + Sp * 128, b0 + 2 * W, w, lane);
+    }
+    int it = 0;
+    for (int bh = blockIdx.x; bh < nbh; bh += gridDim.x, ++it) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));       // (opaque per head: lane-derived offsets must not be hoisted across the head loop)
+        const int lane = tid & 63, w = tid >> 6;
+        char* cur = smem + (it & 1) * SLOT;
+        char* nxt = smem + ((it & 1) ^ 1) * SLOT;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this head's K / V (and the previous head's O stores)
+        __syncthreads();                                       // ... of every wave; the other slot is free now
+        bf16x8 qf[4], qo[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) { qf[kk] = qf_next[kk]; qo[kk] = qo_next[kk]; }
+        const int nb = bh + (int)gridDim.x;
+        if (nb < nbh) {
+            const bf16_t* b1 = head_base(nb);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                qf_next[kk] = frag_global(b1, ld, w * 32 + (lane & 31), kk, lane);
+                qo_next[kk] = frag_global(b1, ld, S - 1, kk, lane);
+            }
+            stage_asm(nxt, b1 + W, w, lane);
+            stage_asm(nxt + Sp * 128, b1 + 2 * W, w, lane);
+        }
+        const int b = bh / H, h = bh % H;
+        attn_fwd_odd_head<NK, true>(cur, cur + Sp * 128, mrg, head_base(bh), ld, o + (long)b * lay.o_b + (long)h * lay.o_h, ldo,
+                                    lse2 ? lse2 + ((long)b * H + h) * Sp : nullptr, scale_log2, lane, w, qf, qo);
     }
 }
 
@@ -1066,6 +1145,18 @@ int attn_fwd_bf16(const bf16_t* qkv, long ldqkv, bf16_t* o, long ldo, float* lse
     if (odd && g_use_tr && S == 257) {   // 8 waves, no padded tiles (see attn_fwd_odd_kernel)
         constexpr int NK = 8;
         const size_t lds_o = (size_t)(32 * NK + 32) * 256 + (size_t)NK * 66 * sizeof(float) + (size_t)NK * 64;
+        static int fpers = -1;
+        if (fpers < 0) { const char* e = getenv("RVLM_ATTN_FWD_PERSIST"); fpers = e ? atoi(e) : 0; }
+        if (fpers) {      // persistent workgroups, two K / V slots (see attn_fwd_odd_pers_kernel)
+            const size_t lds_p = 2 * (size_t)(32 * NK + 32) * 256 + (size_t)NK * 66 * sizeof(float) + (size_t)NK * 64;
+            if ((rc = set_lds(attn_fwd_odd_pers_kernel<NK>, lds_p))) return rc;
+            const AttnLayout lay = {(long)S * ldqkv, 64L, (long)S * ldo, 64L};
+            const int nbh = B * H;
+            hipLaunchKernelGGL((attn_fwd_odd_pers_kernel<NK>), dim3(std::min(nbh, 256)), dim3(NK * 64), lds_p, s, qkv, ldqkv, o,
+                               ldo, lse, H, (long)W, sl2, lay, nbh);
+            RVLM_CHECK_LAUNCH();
+            return RVLM_OK;
+        }
         if ((rc = set_lds(attn_fwd_odd_kernel<NK>, lds_o))) return rc;
         static int hm = -1;      // timing probe: read the same buffers as head-blocked [3][B*H][S][64] / [B*H][S][64]
         if (hm < 0) { const char* e = getenv("RVLM_ATTN_HM"); hm = e ? atoi(e) : 0; }
