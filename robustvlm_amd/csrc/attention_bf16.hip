@@ -33,15 +33,10 @@ typedef __attribute__((address_space(3))) char lds_char;
 // rows r and r + 2 - same bank parity - to land in DIFFERENT 64-B halves, i.e. row bit 1 on chunk bit 2.  Round 2 used
 // (row >> 1) & 7: every transposing read was a 2-way bank conflict (scripts/lds_bank_model.py: 16 of 40 extra LDS cycles
 // per query tile and wave; PMC: 32.5 % of the backward's LDS-active cycles in conflicts, profiles/r02_pmc_attention.json).
-#ifdef RVLM_ATTN_SWZ_R2     // A/B build with the round-2 swizzles (scripts/trip_attn_swz.sh)
-__device__ __forceinline__ int swz_key(int row) { return (row >> 1) & 7; }
-constexpr int DS_KEY_SHIFT = 2;
-#else
 __device__ __forceinline__ int swz_key(int row) {
     return (((row >> 1) & 1) << 2) | (((row >> 3) & 1) << 1) | ((row >> 2) & 1);
 }
 constexpr int DS_KEY_SHIFT = 1;
-#endif
 __device__ __forceinline__ int swz_off(int row, int chunk) {  // byte offset inside a [rows][64] bf16 tile
     return row * 128 + ((chunk ^ swz_key(row)) << 4);
 }
@@ -158,9 +153,6 @@ __device__ __forceinline__ f32x16 zero16() {
 }
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
-#ifndef RVLM_ATTN_BWD_VARIANT
-#define RVLM_ATTN_BWD_VARIANT 0
-#endif
 // raw v_exp_f32 (2^x): arguments here are <= ~6 and results below 2^-126 may flush to 0, which is what
 // softmax wants; exp2f() would wrap every call in denormal-range fix-ups (~6 VALU instead of 1)
 #define EXP2(x) __builtin_amdgcn_exp2f(x)
@@ -442,13 +434,16 @@ attn_fwd_odd_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict_
                                  lse2 ? lse2 + ((long)b * H + h) * Sp : nullptr, scale_log2, lane, w, none, none);
 }
 
+#ifdef RVLM_EXPERIMENTAL_GEMM
 // PERSISTENT, DOUBLE-BUFFERED forward (round 5; RVLM_ATTN_FWD_PERSIST): <= 256 workgroups of NK waves (one per CU, 2 waves
 // per SIMD) walk the (image, head) pairs with TWO K / V slots in LDS (2 x 72 KiB): right after the barrier that opens head
 // i, every wave requests its share of head i + 1's K and V into the other slot (inline-asm LDS-DMA: a compiler-visible one
 // would make hipcc drain vmcnt in front of every LDS read of the slot in use) and its own query fragments into registers -
-// a head's 98 KB of HBM traffic arrives UNDER the previous head's MFMA / softmax work instead of in front of its own.  The
-// one-workgroup-per-head kernel relies on the dispatcher keeping the two workgroups of a CU out of phase for that overlap;
-// measured, a head-slot took 21 k cycles there against ~11 k of HBM time and ~6 k of issue time.
+// a head's 98 KB of HBM traffic arrives UNDER the previous head's MFMA / softmax work instead of in front of its own.
+// MEASURED SLOWER (profiles/r05_attn_ab_bwd_variants_fwd_persistent.log: 90-93 us against 73-76 for the one-workgroup-per-head
+// kernel on the same box): with its traffic fully hidden the forward still needs ~24 k cycles per head at 2 waves per SIMD -
+// the kernel is bound by its per-wave dependency chains (issue), not by HBM, and the two 8-wave workgroups per CU of the
+// shipped kernel (4 waves per SIMD) are what covers them.  Kept in EXPERIMENTAL builds as the measured negative result.
 template <int NK>
 __global__ void __launch_bounds__(NK * 64)
 attn_fwd_odd_pers_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict__ o, long ldo,
@@ -508,6 +503,7 @@ attn_fwd_odd_pers_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __rest
                                     lse2 ? lse2 + ((long)b * H + h) * Sp : nullptr, scale_log2, lane, w, qf, qo);
     }
 }
+#endif
 
 // =============================================================================================
 // backward prep: D[b,h,q] = sum_d dO[q,d] * O[q,d]
@@ -961,40 +957,26 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
         // requested HERE, in front of the S / dP MFMAs.  hipcc placed each of the eight reads directly in front of its four
         // exp / dS evaluations, followed by its own s_waitcnt lgkmcnt(0): eight exposed LDS round trips (~100+ cycles each
         // with eight waves on the LDS) in the middle of the softmax arithmetic of every tile and wave - a third of the
-        // 3.0 k cycles a tile took.  The sched_barrier pins them; the MFMA phase (>= 256 cycles) covers their latency, and
-        // the 32 registers are free at this point of the step (dO^T / Q^T / dS fragments are not live yet).
-#if RVLM_ATTN_BWD_VARIANT >= 1
+        // 3.0 k cycles a tile took?  Measured (profiles/r05_attn_ab_bwd_variants_fwd_persistent.log, same box, three
+        // alternations): tile loop 27.3 k -> 25.5 k cycles per head (-6 %), kernel 199-203 -> 191-199 us.  The sched_barrier pins
+        // them; the MFMA phase (>= 256 cycles) covers their latency, and the 32 registers are free at this point of the step
+        // (dO^T / Q^T / dS fragments are not live yet).  Also requesting the step's eight row-major Q / dO fragments in one batch
+        // behind them measured no better (196-201 us): removed.
         float4 lq4[4], dq4[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             lq4[g] = *(const float4*)(Ls + qt * 32 + 8 * g + 4 * hi);
             dq4[g] = *(const float4*)(Ds + qt * 32 + 8 * g + 4 * hi);
         }
-#if RVLM_ATTN_BWD_VARIANT >= 2     // ... and the eight row-major Q / dO fragments of the step in one batch behind them
-        bf16x8 qfr[4], dfr[4];
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) { qfr[kk] = frag_rm(Qt, qt * 32, fo.rm[kk]); dfr[kk] = frag_rm(Dt, qt * 32, fo.rm[kk]); }
-#endif
         __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-#if RVLM_ATTN_BWD_VARIANT >= 2
-            s = MFMA(qfr[kk], kf[kk], s);
-            dp = MFMA(dfr[kk], vf[kk], dp);
-#else
             s = MFMA(frag_rm(Qt, qt * 32, fo.rm[kk]), kf[kk], s);      // S[q][key]: lane <-> key, regs <-> q
             dp = MFMA(frag_rm(Dt, qt * 32, fo.rm[kk]), vf[kk], dp);    // dP[q][key]
-#endif
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-#if RVLM_ATTN_BWD_VARIANT >= 1
             const float4 lq = lq4[g], dq = dq4[g];
-#else
-            const float4 lq = *(const float4*)(Ls + qt * 32 + 8 * g + 4 * hi);
-            const float4 dq = *(const float4*)(Ds + qt * 32 + 8 * g + 4 * hi);
-#endif
             const float lqa[4] = {lq.x, lq.y, lq.z, lq.w};
             const float dqa[4] = {dq.x, dq.y, dq.z, dq.w};
 #pragma unroll
@@ -1145,6 +1127,7 @@ int attn_fwd_bf16(const bf16_t* qkv, long ldqkv, bf16_t* o, long ldo, float* lse
     if (odd && g_use_tr && S == 257) {   // 8 waves, no padded tiles (see attn_fwd_odd_kernel)
         constexpr int NK = 8;
         const size_t lds_o = (size_t)(32 * NK + 32) * 256 + (size_t)NK * 66 * sizeof(float) + (size_t)NK * 64;
+#ifdef RVLM_EXPERIMENTAL_GEMM
         static int fpers = -1;
         if (fpers < 0) { const char* e = getenv("RVLM_ATTN_FWD_PERSIST"); fpers = e ? atoi(e) : 0; }
         if (fpers) {      // persistent workgroups, two K / V slots (see attn_fwd_odd_pers_kernel)
@@ -1157,6 +1140,7 @@ int attn_fwd_bf16(const bf16_t* qkv, long ldqkv, bf16_t* o, long ldo, float* lse
             RVLM_CHECK_LAUNCH();
             return RVLM_OK;
         }
+#endif
         if ((rc = set_lds(attn_fwd_odd_kernel<NK>, lds_o))) return rc;
         static int hm = -1;      // timing probe: read the same buffers as head-blocked [3][B*H][S][64] / [B*H][S][64]
         if (hm < 0) { const char* e = getenv("RVLM_ATTN_HM"); hm = e ? atoi(e) : 0; }

@@ -1,4 +1,5 @@
-// bf16 MFMA GEMM for gfx950, PERSISTENT 256x256 variant ("256p", 8 waves x 128x64 wave tiles).
+// bf16 MFMA GEMM for gfx950, PERSISTENT 256x256 variant ("256p", 8 waves x 128x64 wave tiles) - THE FILE WITH EVERY A/B ARM
+// (make EXPERIMENTAL=1 builds it INSTEAD of ../gemm_bf16_256p.hip, which is the measured form cut out of this one in round 5).
 //
 // Why: with one 256x256 workgroup per CU and one tile per workgroup, every CU of the chip runs its pipeline fill and
 // its epilogue at the same moment.  Measured on the encoder's shapes (M = 32 896, K = 1024) the per-tile fixed cost
@@ -14,7 +15,7 @@
 //     vmcnt (the A half's youngest stage stays in flight).
 //   * the two waves of a SIMD take opposite roles in the operand traffic: waves 4-7 request all of B right after the
 //     barrier, waves 0-3 all of A at the end of their step, so one of them issues MFMAs while the other waits in the
-//     texture queue (role split below; +4-6 % on every shape over the lockstep form).
+//     texture queue (see SPLIT below; +4-6 % on every shape over the lockstep form).
 //   * epilogue = wave-private LDS transpose (in the B slot the tile's last K-step freed, through inline-asm DS ops so
 //     that hipcc does not drain the operand stream) -> full-line 16-B-per-lane buffer stores; fp32 residual / h_pre
 //     are read in the same coalesced pattern, prefetched four 32x32 sub-tiles ahead; bias joins the accumulators
@@ -23,20 +24,32 @@
 //     (nothing lane-dependent is recomputed or spilled around the tile loop).
 //
 // Requirements: M % 256 == 0 rows handled here, N % 256 == 0, K % 128 == 0, all byte extents < 2 GiB.
-#include "kernels.h"
-#include "gemm_epilogue.h"
-#include "gemm_persist.h"
-#include "gemm_strip.h"
+#include "../kernels.h"
+#include "../gemm_epilogue.h"
+#include "../gemm_persist.h"
+#include "../gemm_strip.h"
 #include <type_traits>
 
+#ifndef RVLM_M16_LAST_PHASE_INPLACE
+#define RVLM_M16_LAST_PHASE_INPLACE 1
+#endif
+#ifndef RVLM_M16_SIDE_DEPTH
+#define RVLM_M16_SIDE_DEPTH 2        // side-input prefetch slots of the 16x16x32 form (4 in the 32x32x16 form), see SIDE_DEPTH below
+#endif
+#ifndef RVLM_GEMM_M16_DEFAULT
+#define RVLM_GEMM_M16_DEFAULT 1      // the shipped MFMA shape since round 4: v_mfma_f32_16x16x32_bf16 (0: 32x32x16, EXPERIMENTAL builds)
+#endif
 
-// THIS FILE HOLDS THE MEASURED FORM ONLY (round 5): split roles, fragment reads between the MFMAs, the v_mfma_f32_16x16x32_bf16
-// tile phase, two side-input slots, in-place last phase.  Every A/B arm it was measured against - the 32x32x16 shape, the
-// lockstep and grouped-read schedules, the ablation / wait-sum / timeline instantiations, start stagger, K rotation, static
-// priority, the register-path operand stream - lives in experimental/gemm_bf16_256p_abl.hip, which `make EXPERIMENTAL=1` builds
-// INSTEAD of this file (librvlm_exp.so).  The production kernels of the two files are the same instruction streams (the
-// assembly of the nine instantiations was diffed when this file was cut).
 namespace rvlm {
+
+// Knobs that were measured neutral or worse (start stagger, K rotation, static wave priority: DESIGN.md section 3, rounds 2-3)
+// and the ablation instantiations exist in `make EXPERIMENTAL=1` builds only; in the shipped library they are
+// compile-time off - no kernel argument, branch or environment switch of theirs is live.
+#ifdef RVLM_EXPERIMENTAL_GEMM
+constexpr bool P_KNOBS = true;
+#else
+constexpr bool P_KNOBS = false;
+#endif
 
 // Contraction-major form: both transposing reads of one fragment - tile t (its pair index XORed into the per-lane base + slot
 // address `base`) of the 32-deep slice ks.  (A namespace-scope function: as a lambda called from the kernel's other lambdas it
@@ -54,44 +67,62 @@ static __device__ __forceinline__ void tr_frag(unsigned base, int t, int ks, i32
     out = i32x4{lo[0], lo[1], hi2[0], hi2[1]};
 }
 
-// FORM = 8192 (the tile phase's MFMA shape v_mfma_f32_16x16x32_bf16: kept in the kernel's NAME so that the rocprofv3 rows of
-// rounds 4 and 5 compare) | 4096 (fp32 outputs stored nt: K >= 2048) | 16384 (contraction-major operands, "TN", below)
-template <int EPI, int ACT, int FORM>
+template <int EPI, int ACT, int ABL>
 __global__ void __launch_bounds__(512)
 gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
-    static_assert((FORM & ~(4096 | 16384)) == 8192, "gemm_bf16_nt_256p_kernel: unknown form");
     // 160 KiB: A ring 3 x 32 KiB | B ring 2 x 32 KiB (the B slot a tile's last K-step frees doubles as the
     // epilogue staging buffer, 4 KiB per wave)
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const int ntiles = tiles_m * tiles_n;
     constexpr bool OUT_F32 = (EPI == EPI_F32_RESID || EPI == EPI_F32);
-    // Role split inside a K-step.  A `buffer_load ... lds` holds its wave until the CU's texture queue takes it (~15 cycles per
-    // 1-KB piece, queue shared by all 8 waves), and a waiting wave issues no MFMAs.  With every wave requesting 4 A + 4 B
+    // Role split inside a K-step (production; ABL & 256 restores the lockstep form it replaced, kept as the measured
+    // baseline).  A `buffer_load ... lds` holds its wave until the CU's texture queue takes it (~15 cycles per 1-KB
+    // piece, queue shared by all 8 waves), and a waiting wave issues no MFMAs.  With every wave requesting 4 A + 4 B
     // pieces right after the barrier, both waves of each SIMD sat in that queue together: ~890 cycles per K-step with
     // the matrix pipe idle (per-wave s_memtime sums, profiles/r02_gemm_gemm_waits*.log).  Here one half of the
     // workgroup requests ALL of B right after the barrier and the other half ALL of A at the END of its step, so on
     // every SIMD one wave is in its MFMAs while its partner is in the queue.  The B half is waves 4-7: the
     // second-dispatched wave of a SIMD loses MFMA arbitration to its partner anyway, so its early stall costs least
-    // (the other assignment measured +1-2 % against +4-6 %).
-    // MFMA shape (round 4): the wave tile (128 x 64) is 8 x 4 tiles of v_mfma_f32_16x16x32_bf16 (rounds 1-3: 4 x 2 of
-    // v_mfma_f32_32x32x16_bf16) - same FLOPs, LDS fragment bytes and accumulator count per K-step, half the accumulator traffic per
+    // (ABL & 512 swaps the halves: measured +1-2 % against +4-6 %).
+#ifdef RVLM_GEMM_LOCKSTEP            // A/B build of the whole library with the schedule this round started from (scripts/trip_r2s.sh)
+    constexpr bool SPLIT = false;
+#else
+    constexpr bool SPLIT = (ABL & 256) == 0 && (ABL & 8) == 0;   // (the register-path experiment keeps the lockstep form)
+#endif
+    constexpr bool SWAP = (ABL & 512) == 0;
+    // MFMA shape (round 4).  ABL & 8192: the wave tile (128 x 64) is 8 x 4 tiles of v_mfma_f32_16x16x32_bf16 instead of 4 x 2 of
+    // v_mfma_f32_32x32x16_bf16 - same FLOPs, LDS fragment bytes and accumulator count per K-step, half the accumulator traffic per
     // FLOP inside the matrix pipe.  A register-only probe of the two instruction streams under the socket power cap
-    // (profiles/r04_mfma_shape_power.log) holds 2 169 against 1 919 TFLOP/s (2.17 vs 1.93 GHz at ~1.33 kW).  A K-step is
-    // 2 slices of 32 x 2 halves of 4 m-tiles = 4 phases of 16 MFMAs; accumulator layout:
+    // (profiles/r04_mfma_shape_power.log) holds 2 169 against 1 919 TFLOP/s (2.17 vs 1.93 GHz at ~1.33 kW).  A K-step is then
+    // 2 slices of 32 x 2 halves of 4 m-tiles = 4 phases of 16 MFMAs (the 32x32 form: 4 slices of 8 MFMAs); accumulator layout:
     // tile (mt, nt), lane (i16 = lane & 15, G = lane >> 4) holds row m = 16 mt + i16, columns n = 16 nt + 4 G + {0..3}.
-    // Operand layout (round 4, the weight-gradient GEMM of the training step).  FORM & 16384 ("TN"): both operands are stored
+    constexpr bool M16 = (ABL & 8192) != 0;
+    // Operand layout (round 4, the weight-gradient GEMM of the training step).  ABL & 16384 ("TN"): both operands are stored
     // CONTRACTION-major - A = dY[k][m] (ld = lda), Bw = X[k][n] (ld = ldb), k = token - and C[m][n] = sum_k A[k][m] Bw[k][n] is
     // computed from them as they lie: a stage's LDS image is [64 k][256 rows] (512-B k-rows, the 32-B pairs of a k-row XORed with
     // f(k) = (k & 3) | ((k >> 3) & 1) << 2), filled by the same 16-B-per-lane DMA (one instruction = 2 k-rows x 512 B, fully
     // coalesced) and read through ds_read_b64_tr_b16 (2 per fragment: a 16-lane group gathers [4 k][16 rows] -> lane = row, 4 k
     // each), so the token-chunk transposes the NT form needs in front (9 ms per training step) are gone.  Batched form: batch b =
-    // k-rows [b K, (b+1) K) (zero beyond k_rows: buffer range check), output rows [b batch_m_rows, ...).  
-    constexpr bool TN = (FORM & 16384) != 0;
-    constexpr bool NT_STORE = (FORM & 4096) != 0;
-    constexpr int NPIECE = 8;      // DMA pieces per wave and operand half
-    // Fragment reads go out BETWEEN the MFMAs of the previous phase (one ds_read_b128 behind each of its first MFMAs): with the
-    // role split each wave runs alone on its SIMD while its partner sits in the texture queue or at the barrier, and every
-    // non-MFMA issue slot between groups is then pipe idle time.
+    // k-rows [b K, (b+1) K) (zero beyond k_rows: buffer range check), output rows [b batch_m_rows, ...).  M16, SPLIT roles only.
+    constexpr bool TN = (ABL & 16384) != 0;
+    static_assert(!TN || (M16 && (ABL & (256 | 8)) == 0), "TN: 16x16x32 split-role form only");
+    constexpr int NPIECE = SPLIT ? 8 : 4;      // DMA pieces per wave and operand half
+    // Fragment reads between the MFMAs of the previous k-slice (2 ds_read_b128 after each of its first three MFMAs)
+    // instead of 6 in a row between two groups of 8 MFMAs: with the role split each wave runs alone on its SIMD while
+    // its partner sits in the texture queue or at the barrier, and every non-MFMA issue slot between groups is then
+    // pipe idle time.  ABL & 1024 restores the grouped form.
+#ifdef RVLM_GEMM_LOCKSTEP
+    constexpr bool FINE = false;
+#else
+    constexpr bool FINE = (ABL & 1024) == 0;
+#endif
+    // phase offset (performance only, RVLM_GEMM_STAGGER, default off): with every workgroup in lockstep the epilogues' HBM
+    // bursts coincide chip-wide.  It gained 3 % on the fc2 dgrad under the lockstep schedule and costs it 4 % under the
+    // split-role one; neutral to slightly negative for the other epilogues (profiles/r02_gemm_knobs_split.log)
+    if (P_KNOBS && (p.stagger & 255) > 0) {
+        const int phase = (blockIdx.x >> 3) & ((p.stagger >> 8) & 255);   // phases per XCD (blockIdx & 7 = XCD): mask in the high bits
+        for (int i = 0; i < (p.stagger & 255) * phase; ++i) __builtin_amdgcn_s_sleep(127);
+    }
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -104,11 +135,14 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
     // 65.7 -> 60.7 ms, fc2 forward 60.2 -> 57.2; every second workgroup of an XCD instead: 262.5; one XCD of eight: 261.4
     const int sf_mod = (p.stagger >> 16) & 127;
     const int sf_id = ((p.stagger >> 16) & 128) ? ((int)blockIdx.x & 7) : ((int)blockIdx.x >> 3);   // +128: whole XCDs instead
-    const bool strip_first = sf_mod >= 2 && (sf_id % sf_mod) == sf_mod - 1 && m_total > p.M;
+    const bool strip_first = sf_mod >= 2 && (sf_id % sf_mod) == sf_mod - 1 && (ABL & 15) == 0 && m_total > p.M;
     if (strip_first) {
         strip_tail<EPI, ACT>(p, p.M, m_total, lds, w, lane);
         __syncthreads();      // the reduce buffer overlaps the first ring slots
     }
+    const int l31 = lane & 31, hi = lane >> 5;
+    // experiment (MI355X_MICROARCH.md, two waves per SIMD, item 4): static priority for the second-dispatched half
+    if (P_KNOBS && p.wave_prio > 0 && w >= 4) __builtin_amdgcn_s_setprio(1);
     const int lda = (int)p.lda, ldb = (int)p.ldb, ldo = (int)p.ldo;   // byte offsets fit 31 bits (host check)
 
     // buffer descriptors (wave-uniform, built from kernel arguments only): every global access below is
@@ -137,12 +171,19 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
         n0 = __builtin_amdgcn_readfirstlane(((t % group_size) / gm) * P_N);
     };
     const int nk = p.K / P_K;
+    // experiment (RVLM_GEMM_KROT): the workgroups of an XCD walk K from different start offsets, so that at any moment
+    // their operand requests fall on different k-columns of the panels they share (the sum order of a tile rotates with it)
+    int k0 = 0;
+    if (!P_KNOBS) k0 = 0;
+    else if (p.krot > 0) k0 = (((int)blockIdx.x >> 3) % p.krot) * (nk >= p.krot ? nk / p.krot : 1) % nk;
+    else if (p.krot < 0) k0 = (((int)blockIdx.x >> 3) % (-p.krot)) % nk;
+    k0 = __builtin_amdgcn_readfirstlane(k0);
     const int ntw = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // tiles of this workgroup
 
     // ---- operand streams.  Stage g (global K-step counter over all tiles of this workgroup) has its A half in A
     // slot g % 3 and its B half in B slot g % 2; A runs three stages ahead of the MFMAs, B two.  One DMA instruction
-    // moves 8 rows x 128 B.  Waves 4-7 request the B half (wave w rows [64(w&3), +64) = 8 pieces), waves
-    // 0-3 the A half likewise.  Row of piece j:
+    // moves 8 rows x 128 B.  Split roles: waves 4-7 request the B half (wave w rows [64(w&3), +64) = 8 pieces), waves
+    // 0-3 the A half likewise; lockstep form: wave w requests rows [32w, 32w+32) of both halves.  Row of piece j:
     // first row + 8j + (lane>>3); its 16-B chunk (lane&7) holds logical chunk (lane&7) ^ ((row>>1)&7), which only
     // depends on the parity of j.
     int a_loff[2], b_loff[2];
@@ -152,7 +193,7 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
         a_loff[jp] = ((lane >> 3) * lda + clog * 8) * 2;
         b_loff[jp] = ((lane >> 3) * ldb + clog * 8) * 2;
     }
-    const int wrow = (w & 3) * 64;     // first row (of each 256-row half) this wave requests
+    const int wrow = SPLIT ? (w & 3) * 64 : w * 32;     // first row (of each 256-row half) this wave requests
     // TN: wave (w & 3) = 2 b + r1 requests k-rows 32 a + 16 a' + 8 b + 4 c + 2 r1 + {0, 1} (piece j = 4 a + 2 a' + c; lanes 0-31 the
     // even row, 32-63 the odd one), so f(k) = (lane >> 5) | (w & 3) << 1 is one constant per lane: slot chunk z = lane & 31 of a
     // k-row holds logical 16-B chunk (((z >> 1) ^ f) << 1) | (z & 1) (the XOR stays inside the 256-B bank row: f < 8)
@@ -181,19 +222,26 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
         a_soff = RVLM_A_TILE_OFF(m0);
         b_soff = RVLM_B_TILE_OFF(m0, n0);
     }
-    // The tile loop exists twice, once per role (ROLE 1 = A half, 2 = B half): a wave picks its copy once, so inside the loop
-    // the role is a compile-time fact and costs no branch.
+    // experiment (ABL & 8): the same operand stream as plain buffer_load_dwordx4 into registers (folded into a sink one
+    // K-step later) - compares the VGPR return path of the texture unit with the LDS-DMA path
+    u32x4 pendA[4], pendB[4], sink = {0u, 0u, 0u, 0u};
+    if (ABL & 8) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { pendA[j] = sink; pendB[j] = sink; }
+    }
+    // The tile loop exists twice, once per role (ROLE 1 = A half, 2 = B half; 0 = lockstep form, every wave both): a wave
+    // picks its copy once, so inside the loop the role is a compile-time fact and costs no branch.
     auto run = [&](auto role_c) __attribute__((always_inline)) {
     constexpr int ROLE = decltype(role_c)::value;
     constexpr bool own_a = ROLE != 2, own_b = ROLE != 1;
     // one DMA piece (8 rows x 128 B per wave instruction) of the next A / B stage, and the cursor step behind its last
     auto a_piece = [&](int j) __attribute__((always_inline)) {
-        if (!own_a || a_ti >= ntw) return;
+        if ((ABL & 1) || !own_a || a_ti >= ntw) return;
         __attribute__((address_space(3))) char* dst =
             (__attribute__((address_space(3))) char*)lds + (a_slot * PA_SLOT + stage_wave_off);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
             a_rs, (lds_ptr_t)(dst + RVLM_PIECE_LDS(j)), 16, a_loff[j & 1],
-            __builtin_amdgcn_readfirstlane(a_soff + RVLM_PIECE_GOFF(j, a_kt, lda)), 0, 0);
+            __builtin_amdgcn_readfirstlane(a_soff + RVLM_PIECE_GOFF(j, (a_kt + k0 >= nk ? a_kt + k0 - nk : a_kt + k0), lda)), 0, 0);
     };
     auto a_advance = [&]() __attribute__((always_inline)) -> bool {
         if (a_ti >= ntw) return false;
@@ -209,12 +257,12 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
         return true;
     };
     auto b_piece = [&](int j) __attribute__((always_inline)) {
-        if (!own_b || b_ti >= ntw) return;
+        if ((ABL & 1) || !own_b || b_ti >= ntw) return;
         __attribute__((address_space(3))) char* dst =
             (__attribute__((address_space(3))) char*)lds + (PB_BASE + b_slot * PB_SLOT + stage_wave_off);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
             b_rs, (lds_ptr_t)(dst + RVLM_PIECE_LDS(j)), 16, b_loff[j & 1],
-            __builtin_amdgcn_readfirstlane(b_soff + RVLM_PIECE_GOFF(j, b_kt, ldb)), 0, 0);
+            __builtin_amdgcn_readfirstlane(b_soff + RVLM_PIECE_GOFF(j, (b_kt + k0 >= nk ? b_kt + k0 - nk : b_kt + k0), ldb)), 0, 0);
     };
     auto b_advance = [&]() __attribute__((always_inline)) -> bool {
         if (b_ti >= ntw) return false;
@@ -230,31 +278,67 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
         return true;
     };
     auto issue_a = [&]() -> bool {     // a whole stage in one burst
+        if (ABL & 8) {
+            if (a_ti >= ntw) return false;
 #pragma unroll
-        for (int j = 0; j < NPIECE; ++j) a_piece(j);
+            for (int j = 0; j < 4; ++j) {
+                sink ^= pendA[j];
+                pendA[j] = __builtin_amdgcn_raw_buffer_load_b128(
+                    a_rs, a_loff[j & 1], __builtin_amdgcn_readfirstlane(a_soff + (a_kt + k0 >= nk ? a_kt + k0 - nk : a_kt + k0) * (P_K * 2) + j * 16 * lda), 0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NPIECE; ++j) a_piece(j);
+        }
         return a_advance();
     };
     auto issue_b = [&]() -> bool {
+        if (ABL & 8) {
+            if (b_ti >= ntw) return false;
 #pragma unroll
-        for (int j = 0; j < NPIECE; ++j) b_piece(j);
+            for (int j = 0; j < 4; ++j) {
+                sink ^= pendB[j];
+                pendB[j] = __builtin_amdgcn_raw_buffer_load_b128(
+                    b_rs, b_loff[j & 1], __builtin_amdgcn_readfirstlane(b_soff + (b_kt + k0 >= nk ? b_kt + k0 - nk : b_kt + k0) * (P_K * 2) + j * 16 * ldb), 0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NPIECE; ++j) b_piece(j);
+        }
         return b_advance();
     };
 
-    // ---- fragment addresses = per-lane part (fa16, by k-slice) + ring slot offset.  The slot offsets are kept
-    // opaque to the optimiser: otherwise it precomputes every (slot, slice, operand) sum into VGPRs that stay live over the
+    // ---- fragment addresses = per-lane part (fa / fb, by k-slice) + ring slot offset.  The slot offsets are kept
+    // opaque to the optimiser: otherwise it precomputes every (slot, kk, operand) sum into VGPRs that stay live over the
     // whole tile loop (and spill around it).
+    const int swz = (l31 >> 1) & 7;
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+    unsigned fa[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) fa[kk] = lds_base + (wm * 128 + l31) * 128 + (((kk * 2 + hi) ^ swz) << 4);
     const int ab_delta = PB_BASE + (wn * 64 - wm * 128) * 128;   // B row block of this wave relative to its A rows
     int ca_slot = 0, cb_slot = 0;                                 // slots of the stage being consumed
+    auto load_frags = [&](int sa, int sb, int kk, i32x4 (&a)[4], i32x4 (&b)[2]) {
+        if (ABL & 4) return;
+        int oa = sa * PA_SLOT, ob = sb * PB_SLOT + ab_delta;
+        asm volatile("" : "+s"(oa), "+s"(ob));
+        const unsigned aa = fa[kk] + oa, bb = fa[kk] + ob;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(a[0]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(a[1]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(a[2]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(a[3]) : "v"(aa));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(b[0]) : "v"(bb));
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(b[1]) : "v"(bb));
+    };
 
-    // lane (i16, G) reads row (row block) + 16 t + i16, logical 16-B chunk 4 ks + G of the 32-deep slice ks; the ring's
+    // M16: lane (i16, G) reads row (row block) + 16 t + i16, logical 16-B chunk 4 ks + G of the 32-deep slice ks; the ring's
     // swizzle key (row >> 1) & 7 only depends on i16.  (Conflict-free under ds_read_b128's 4 x 16 lane groups: every group sees
     // each (row parity, chunk) pair once - checked by hand for the four groups.)
     const int i16 = lane & 15, G = lane >> 4;
     unsigned fa16[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) fa16[ks] = lds_base + (wm * 128 + i16) * 128 + (((ks * 4 + G) ^ ((i16 >> 1) & 7)) << 4);
-    f32x4 acc16[8][4];
+    f32x4 acc16[M16 ? 8 : 1][M16 ? 4 : 1];
     // TN: lane (i16, G) of a fragment of slice ks holds row (tile) + i16, k = 32 ks + 8 G + 0..7 = two transposing reads (k-rows
     // 32 ks + 8 G + 4 hh + (i16 >> 2), hh = 0 / 1: +2048 B), each lane pointing at the 8 bytes (i16 & 3) of its k-row's 32-B
     // pair p ^ f(k), p = the tile's pair index (A: 8 wm + t, B: 4 wn + nt), f(k) = (i16 >> 2) | (G & 1) << 2 - independent of
@@ -265,6 +349,7 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
     const unsigned trB = lds_base + PB_BASE + (tr_lane ^ (wn * 128));
     // X fragments (activation rows) of m-tiles 4 h .. 4 h + 3 of slice ks
     auto load_x16 = [&](int sa, int ks, int h, i32x4 (&x)[4]) __attribute__((always_inline)) {
+        if (ABL & 4) return;
         int oa = sa * PA_SLOT;
         asm volatile("" : "+s"(oa));
         if (TN) {
@@ -280,6 +365,7 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
     };
     // W fragments (weight rows) of the wave's 4 n-tiles of slice ks
     auto load_w16 = [&](int sb, int ks, i32x4 (&wf)[4]) __attribute__((always_inline)) {
+        if (ABL & 4) return;
         int ob = sb * PB_SLOT + (TN ? 0 : ab_delta);
         asm volatile("" : "+s"(ob));
         if (TN) {
@@ -305,10 +391,11 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
         for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                acc16[4 * h + q][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                    __builtin_bit_cast(bf16x8, wf[nt]), __builtin_bit_cast(bf16x8, x[q]), acc16[4 * h + q][nt], 0, 0, 0);
+                if (!(ABL & 2))
+                    acc16[M16 ? 4 * h + q : 0][M16 ? nt : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, wf[nt]), __builtin_bit_cast(bf16x8, x[q]), acc16[M16 ? 4 * h + q : 0][M16 ? nt : 0], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (loads) {
+                if (loads && !(ABL & 4)) {
                     // fragment read r of the next phase (X: 0..3, W: 4..7) goes out behind MFMA r of this one
                     const int r = q * 4 + nt;
                     if (TN) {            // both transposing reads of a fragment behind one MFMA
@@ -328,10 +415,61 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
             }
     };
 
+    f32x16 acc[M16 ? 1 : 4][M16 ? 1 : 2];
+    auto mma = [&](const i32x4 (&a)[4], const i32x4 (&b)[2]) {
+        if (ABL & 2) return;
+#ifdef RVLM_MFMA_PRIO
+        __builtin_amdgcn_s_setprio(RVLM_MFMA_PRIO);                   // experiment: MFMA groups at raised wave priority
+#endif
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[M16 ? 0 : i][M16 ? 0 : j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                    __builtin_bit_cast(bf16x8, b[j]), __builtin_bit_cast(bf16x8, a[i]), acc[M16 ? 0 : i][M16 ? 0 : j], 0, 0, 0);
+#ifdef RVLM_MFMA_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+    };
+    // 8 MFMAs of one k-slice (fragments a, b) with the 6 fragment reads of slice kk of stage (sa, sb) into (na, nb)
+    // issued between them
+    auto mma_lf = [&](const i32x4 (&a)[4], const i32x4 (&b)[2], int sa, int sb, int kk, i32x4 (&na)[4], i32x4 (&nb)[2])
+                      __attribute__((always_inline)) {
+        int oa = sa * PA_SLOT, ob = sb * PB_SLOT + ab_delta;
+        asm volatile("" : "+s"(oa), "+s"(ob));
+        const unsigned aa = fa[kk] + oa, bb = fa[kk] + ob;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (!(ABL & 2))
+                    acc[M16 ? 0 : i][M16 ? 0 : j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        __builtin_bit_cast(bf16x8, b[j]), __builtin_bit_cast(bf16x8, a[i]), acc[M16 ? 0 : i][M16 ? 0 : j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(ABL & 4)) {
+                    if (i == 0 && j == 0) {
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(nb[0]) : "v"(bb));
+                        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(nb[1]) : "v"(bb));
+                    } else if (i == 0 && j == 1) {
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(na[0]) : "v"(aa));
+                        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(na[1]) : "v"(aa));
+                    } else if (i == 1 && j == 0) {
+                        asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(na[2]) : "v"(aa));
+                        asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(na[3]) : "v"(aa));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    };
     // zero the accumulators of the 32 x 32 sub-tile (mi, ni) of the wave tile
     auto init_acc = [&](int mi, int ni) {
+        if (M16) {
 #pragma unroll
-        for (int pc = 0; pc < 4; ++pc) acc16[2 * mi + (pc >> 1)][2 * ni + (pc & 1)] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            for (int pc = 0; pc < 4; ++pc) acc16[M16 ? 2 * mi + (pc >> 1) : 0][M16 ? 2 * ni + (pc & 1) : 0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[M16 ? 0 : mi][M16 ? 0 : ni][e] = 0.0f;
+        }
     };
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) { init_acc(mi, 0); init_acc(mi, 1); }
@@ -340,71 +478,151 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
     issue_a(); issue_b();
     issue_a(); issue_b();
     bool a_ahead = issue_a();       // was the A half of stage g+2 requested at the previous barrier?
-    // (B half: 16 pieces, all needed; A half: 24, the 8 of stage 2 may stay in flight)
-    if (own_a && a_ahead) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (SPLIT) {                    // (B half: 16 pieces, all needed; A half: 24, the 8 of stage 2 may stay in flight)
+        if (own_a && a_ahead) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (a_ahead) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // (a single tile with two K-steps)
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 
-    i32x4 a0[4], a1[4];          // X fragments of the current / next phase
-    i32x4 w0[4], w1[4];          // W fragments of the current / next 32-deep slice
+    i32x4 a0[4], b0[2], a1[4], b1[2];
+    i32x4 w0[4], w1[4];          // M16: W fragments of the current / next 32-deep slice (a0 / a1 hold the X fragments of a phase)
 
     auto stamp = [&](int ti, int k) {   // optional per-tile timeline (test hook rvlm_k_gemm_set_trace), wave 0 only
-        if (p.trace && w == 0 && ti < 7) {
+        if (!(ABL & (128 | 2048)) && p.trace && w == 0 && ti < 7) {
             const unsigned long long t = __builtin_amdgcn_s_memtime();
             if (lane == 0) p.trace[((long)blockIdx.x * 8 + ti) * 4 + k] = t;
         }
     };
-    if (p.trace && w == 0 && lane == 0) {   // clock calibration: s_memtime vs the constant 100 MHz s_memrealtime
+    if (!(ABL & (128 | 2048)) && p.trace && w == 0 && lane == 0) {   // clock calibration: s_memtime vs the constant 100 MHz s_memrealtime
         p.trace[((long)blockIdx.x * 8 + 7) * 4 + 0] = __builtin_amdgcn_s_memtime();
         p.trace[((long)blockIdx.x * 8 + 7) * 4 + 1] = __builtin_amdgcn_s_memrealtime();
     }
 
+    unsigned long long wt_vm = 0, wt_bar = 0, wt_dma = 0, wt_mark = 0;
+    unsigned long long tl[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // (ABL & 2048) stamps: barrier passed, B requested, slice-3 MFMAs
+    int gstep = 0;                                          // issued, slices 0 / 1 / 2, A requested, operands landed
+    const unsigned long long wt_begin = (ABL & 128) ? __builtin_amdgcn_s_memtime() : 0ull;
     for (int ti = 0; ti < ntw; ++ti) {
         int m0, n0;
         tile_origin(blockIdx.x + ti * gridDim.x, m0, n0);
         const bool last_tile = (ti + 1 == ntw);
         stamp(ti, 0);
-        load_x16(ca_slot, 0, 0, a0); load_w16(cb_slot, 0, w0);
+        if (M16) { load_x16(ca_slot, 0, 0, a0); load_w16(cb_slot, 0, w0); }
+        else load_frags(ca_slot, cb_slot, 0, a0, b0);
 
         // One K-step.  At its barrier the next stage has landed for every wave and every wave is done reading this
         // stage, whose two slots are refilled right away: B of stage g+2, then A of stage g+3 (in that order: the
-        // next step may leave exactly the youngest pieces, the A half, in flight).
+        // next step may leave exactly the 4 youngest pieces, the A half, in flight).
         auto k_step = [&](bool first_of_tile, bool last_of_tile) {
             const int na_slot = (ca_slot == 2) ? 0 : ca_slot + 1, nb_slot = cb_slot ^ 1;
-            // phases 0 - 2 of the K-step (slice 0 half 0, slice 0 half 1, slice 1 half 0); phase 3 runs behind the barrier
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            mma16_phase(a0, w0, 0, true, ca_slot, cb_slot, 0, 1, a1, w1);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            mma16_phase(a1, w0, 1, true, ca_slot, cb_slot, 1, 0, a0, w1);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            mma16_phase(a0, w1, 0, true, ca_slot, cb_slot, 1, 1, a1, w0);
-            // the A half requests the stage for the slot freed at the PREVIOUS barrier (nothing is free yet in the
-            // very first step); its 8 youngest pieces may stay in flight, the B half waits for all of its own
-            a_ahead = (first_of_tile && ti == 0) ? false : issue_a();
-            if (own_a && a_ahead) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            if (M16) {
+                // phases 0 - 2 of the K-step (slice 0 half 0, slice 0 half 1, slice 1 half 0); phase 3 runs behind the barrier
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                mma16_phase(a0, w0, 0, true, ca_slot, cb_slot, 0, 1, a1, w1);
+                if (ABL & 2048) tl[3] = __builtin_amdgcn_s_memtime();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                mma16_phase(a1, w0, 1, true, ca_slot, cb_slot, 1, 0, a0, w1);
+                if (ABL & 2048) tl[4] = __builtin_amdgcn_s_memtime();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                mma16_phase(a0, w1, 0, true, ca_slot, cb_slot, 1, 1, a1, w0);
+                if (ABL & 2048) tl[5] = __builtin_amdgcn_s_memtime();
+            } else if (FINE) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                mma_lf(a0, b0, ca_slot, cb_slot, 1, a1, b1);
+                if (ABL & 2048) tl[3] = __builtin_amdgcn_s_memtime();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                mma_lf(a1, b1, ca_slot, cb_slot, 2, a0, b0);
+                if (ABL & 2048) tl[4] = __builtin_amdgcn_s_memtime();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                mma_lf(a0, b0, ca_slot, cb_slot, 3, a1, b1);
+                if (ABL & 2048) tl[5] = __builtin_amdgcn_s_memtime();
+            } else {
+                load_frags(ca_slot, cb_slot, 1, a1, b1);
+                asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                mma(a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                load_frags(ca_slot, cb_slot, 2, a0, b0);
+                asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                mma(a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+                load_frags(ca_slot, cb_slot, 3, a1, b1);
+                asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                mma(a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // first step of a later tile: the B half of the next stage was requested AFTER the epilogue's stores
+            unsigned long long tw0 = 0, tw1 = 0;
+            if (ABL & 128) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tw0 = __builtin_amdgcn_s_memtime(); }
+            if (SPLIT) {
+                // the A half requests the stage for the slot freed at the PREVIOUS barrier (nothing is free yet in the
+                // very first step); its 8 youngest pieces may stay in flight, the B half waits for all of its own
+                a_ahead = (first_of_tile && ti == 0) ? false : issue_a();
+                if (ABL & 2048) tl[6] = __builtin_amdgcn_s_memtime();
+                if (own_a && a_ahead) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                if (ABL & 2048) {
+                    tl[7] = __builtin_amdgcn_s_memtime();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    // timeline of K-steps 8 and 9 of the first tile, every wave of workgroup 0: [wave][step][stamp]
+                    if (p.trace && blockIdx.x == 0 && ti == 0 && (gstep == 8 || gstep == 9) && lane == 0) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) p.trace[(w * 2 + (gstep - 8)) * 8 + i] = tl[i];
+                    }
+                    ++gstep;
+                }
+            } else if (a_ahead && !(first_of_tile && ti > 0)) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if (ABL & 128) { tw1 = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
+            if (ABL & 128) {   // where a K-step's time goes (per wave, summed over the launch): operand wait, barrier wait
+                const unsigned long long tw2 = __builtin_amdgcn_s_memtime();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                wt_vm += tw1 - tw0; wt_bar += tw2 - tw1; wt_mark = tw2;
+            }
             if (first_of_tile) stamp(ti, 1);
-            // (B is deferred past the epilogue in a tile's last step: staging uses that slot; the next stage's first fragments
-            // go out among the caller's MFMAs)
-            if (!last_of_tile) issue_b();
+            if (ABL & 2048) tl[0] = __builtin_amdgcn_s_memtime();
+            if (SPLIT) {
+                // (B is deferred past the epilogue in a tile's last step: staging uses that slot)
+                if (!last_of_tile) {
+                    if (!FINE && !M16) load_frags(na_slot, nb_slot, 0, a0, b0);     // (FINE / M16: among the caller's MFMAs)
+                    issue_b();
+                }
+            } else {
+                if (!last_of_tile) issue_b();
+                a_ahead = issue_a();
+            }
+            if (ABL & 128) { wt_dma += __builtin_amdgcn_s_memtime() - wt_mark; }
+            if (ABL & 2048) tl[1] = __builtin_amdgcn_s_memtime();
+            if (!SPLIT && !FINE && !M16 && !last_of_tile) load_frags(na_slot, nb_slot, 0, a0, b0);
             ca_slot = na_slot;
             cb_slot = nb_slot;
         };
         k_step(true, false);
         __builtin_amdgcn_sched_barrier(0);
         // + the next stage's first fragments (its barrier is behind us)
-        mma16_phase(a1, w1, 1, true, ca_slot, cb_slot, 0, 0, a0, w0);
+        if (M16) mma16_phase(a1, w1, 1, true, ca_slot, cb_slot, 0, 0, a0, w0);
+        else if (FINE) mma_lf(a1, b1, ca_slot, cb_slot, 0, a0, b0);
+        else mma(a1, b1);
         __builtin_amdgcn_sched_barrier(0);
         for (int kt = 1; kt < nk - 1; ++kt) {
             k_step(false, false);
             __builtin_amdgcn_sched_barrier(0);
-            mma16_phase(a1, w1, 1, true, ca_slot, cb_slot, 0, 0, a0, w0);
+            if (M16) mma16_phase(a1, w1, 1, true, ca_slot, cb_slot, 0, 0, a0, w0);
+            else if (FINE) mma_lf(a1, b1, ca_slot, cb_slot, 0, a0, b0);
+            else mma(a1, b1);
+            if (ABL & 2048) tl[2] = __builtin_amdgcn_s_memtime();
             __builtin_amdgcn_sched_barrier(0);
         }
         const int stage_slot = cb_slot;   // B slot of the tile's last stage = epilogue staging area after its barrier
@@ -416,7 +634,7 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
         // the stores (VMEM returns in order).  ~20 VALU per tile instead.
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
-        const int i16 = lane_e & 15, G = lane_e >> 4;
+        const int l31 = lane_e & 31, hi = lane_e >> 5, i16 = lane_e & 15, G = lane_e >> 4;
         // lane offsets of the epilogue's coalesced accesses (bytes); one instruction = 8 rows (16 for the 64-B rows)
         const int st16_loff = ((lane_e >> 3) * ldo + (lane_e & 7) * 8) * 2;   // bf16: 128 B (64 columns) per row
         const int st32_loff = ((lane_e >> 3) * ldo + (lane_e & 7) * 4) * 4;   // fp32: 128 B (32 columns) per row
@@ -428,19 +646,20 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {  // (a null bias has a zero-length descriptor: out-of-range loads return 0)
-                if (g & 1) continue;            // bv[ni][g], g even = the 4 columns of n-tile 2 ni + (g >> 1); 4 vectors, not 8
+                if (M16 && (g & 1)) continue;            // M16: bv[ni][g], g even = the 4 columns of n-tile 2 ni + (g >> 1); 4 vectors, not 8
                 bv[ni][g] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
-                    bias_rs, G * 16, __builtin_amdgcn_readfirstlane((n0 + wn * 64 + (2 * ni + (g >> 1)) * 16) * 4), 0));
+                    bias_rs, M16 ? G * 16 : hi * 16,
+                    __builtin_amdgcn_readfirstlane((n0 + wn * 64 + (M16 ? (2 * ni + (g >> 1)) * 16 : ni * 32 + 8 * g)) * 4), 0));
             }
         // Side input of the epilogue (fp32 residual / bf16 h_pre), read in the SAME coalesced pattern as the output is
         // stored (after the LDS transpose) and prefetched SIDE_DEPTH 32x32 sub-tiles ahead: sub-tile s = 2*mi + ni lives
         // in side[s % SIDE_DEPTH].  The first ones are requested under the last MFMAs of the tile.
         const int m_base = m0 + wm * 128, n_base = n0 + wn * 64;
-        // (2 slots.  Before the tile's last phase accumulated in place hipcc parked five of the
+        // (M16: 2 slots.  Before the tile's last phase accumulated in place (RVLM_M16_LAST_PHASE_INPLACE) hipcc parked five of the
         // twelve side loads of 4 slots in scratch, each behind its own s_waitcnt vmcnt(0) - an HBM round trip apiece, per tile;
         // with the in-place phase nothing spills at any depth and 2 / 3 / 4 slots measure within 0.3 % of each other end to end
         // (278.0 / 277.5 / 277.4 img/s on one box, profiles/r04_ab_mfma16_inplace.log): the shallowest one ships)
-        constexpr int SIDE_DEPTH = 2;
+        constexpr int SIDE_DEPTH = M16 ? RVLM_M16_SIDE_DEPTH : 4;
         u32x4 side[SIDE_DEPTH][4];
         auto load_side = [&](int sub) {
             if (EPI == EPI_F32_RESID) {    // sub = 2*mi + ni: 32 rows x 128 B, 4 loads of 8 rows
@@ -459,7 +678,8 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
         if (EPI == EPI_F32_RESID) load_side(0);                            // a0/b0 are dead
         if (EPI == EPI_BF16_DACT) { load_side(0); load_side(1); }
         __builtin_amdgcn_sched_barrier(0);
-        {
+        if (M16) {
+#if RVLM_M16_LAST_PHASE_INPLACE
             // The tile's LAST phase (no fragment reads) sits in a loop of (opaque) trip count 1: the accumulators are then
             // loop-carried and the MFMAs accumulate in place, as in the K loop.  As straight-line code hipcc gave every result of
             // the phase fresh registers (D != C, 64 of them over the phase) right where the epilogue's side-input prefetch wants
@@ -469,16 +689,31 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
             asm volatile("" : "+s"(once));
 #pragma unroll 1
             for (int rep = 0; rep < once; ++rep) mma16_phase(a1, w1, 1, false, 0, 0, 0, 0, a0, w0);
-        }
+#else
+            mma16_phase(a1, w1, 1, false, 0, 0, 0, 0, a0, w0);
+#endif
+        } else mma(a1, b1);
         __builtin_amdgcn_sched_barrier(0);
         // bias joins the accumulators here, so that its registers are free for the side-input prefetch
+        if (M16) {
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt)
+            for (int mt = 0; mt < 8; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const float4 bq = bv[nt >> 1][(nt & 1) * 2];
-                acc16[mt][nt] += f32x4{bq.x, bq.y, bq.z, bq.w};
-            }
+                for (int nt = 0; nt < 4; ++nt) {
+                    const float4 bq = bv[nt >> 1][(nt & 1) * 2];
+                    acc16[M16 ? mt : 0][M16 ? nt : 0] += f32x4{bq.x, bq.y, bq.z, bq.w};
+                }
+        } else {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    acc[M16 ? 0 : mi][M16 ? 0 : ni][g * 4 + 0] += bv[ni][g].x; acc[M16 ? 0 : mi][M16 ? 0 : ni][g * 4 + 1] += bv[ni][g].y;
+                    acc[M16 ? 0 : mi][M16 ? 0 : ni][g * 4 + 2] += bv[ni][g].z; acc[M16 ? 0 : mi][M16 ? 0 : ni][g * 4 + 3] += bv[ni][g].w;
+                }
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (EPI == EPI_F32_RESID) {
 #pragma unroll
@@ -492,23 +727,30 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
 
         // ---- epilogue of (m0, n0): staging through the freed B slot, accumulators re-zeroed sub-tile by sub-tile ----
         const unsigned ebuf = lds_base + PB_BASE + stage_slot * PB_SLOT + w * P_EPI_WAVE;
-        // staging write addresses: piece pc = (a, b) of a 32 x 32 sub-tile is accumulator tile (2 mi + a, 2 ni + b), row 16 a + i16
-        // (128-B rows), columns 16 b + 4 G .. + 3, i.e. 4-column chunk 4 b + G; chunk index = (constant per piece) ^ (lane part),
-        // keys of row & 15 = i16.  (The staged layouts are those of the 32x32x16 form of rounds 1-3: element (row, col) of the
-        // 32-row block lands at the same LDS address, so the read-back and store side below did not change with the MFMA shape.)
-        const unsigned w16n_pre = ebuf + i16 * 128 + ((G ^ i16) << 3);                // bf16: 8-B chunk ^ (row & 15)
-        const unsigned wpn_pre = ebuf + i16 * 128 + ((G ^ pair_key(i16)) << 3);       // activation pair: see pair_key()
-        const unsigned w32n_pre = ebuf + i16 * 128 + ((G ^ (i16 & 7)) << 4);          // fp32: 16-B chunk ^ (row & 7)
-        // piece pc of sub-tile (mi, ni): its 4 values and its staging addresses
-        auto piece = [&](int mi, int ni, int pc) -> f32x4 { return acc16[2 * mi + (pc >> 1)][2 * ni + (pc & 1)]; };
+        // staging write addresses: row l31 (128-B rows); chunk index = (constant per register group) ^ (lane part)
+        const unsigned w16_pre = ebuf + l31 * 128 + ((hi ^ (l31 & 15)) << 3);   // bf16: 8-B chunk (ni*8 + 2g + hi) ^ (row & 15)
+        const unsigned wp_pre = ebuf + l31 * 128 + ((hi ^ pair_key(l31)) << 3);     // activation pair: see pair_key()
+        const unsigned w32_pre = ebuf + l31 * 128 + ((hi ^ (l31 & 7)) << 4);    // fp32: 16-B chunk (2g + hi) ^ (row & 7)
+        // M16: the SAME staged layouts (element (row, col) of the 32-row block lands at the same LDS address, so the read-back
+        // and store side below is shared): piece pc = (a, b) of a 32 x 32 sub-tile is accumulator tile (2 mi + a, 2 ni + b),
+        // row 16 a + i16, columns 16 b + 4 G .. + 3, i.e. 4-column chunk 4 b + G (row & 15 = i16: the keys only need i16)
+        const unsigned w16n_pre = ebuf + i16 * 128 + ((G ^ i16) << 3);
+        const unsigned wpn_pre = ebuf + i16 * 128 + ((G ^ pair_key(i16)) << 3);
+        const unsigned w32n_pre = ebuf + i16 * 128 + ((G ^ (i16 & 7)) << 4);
+        // piece pc (g in the 32x32 form) of sub-tile (mi, ni): its 4 values and its staging addresses
+        auto piece = [&](int mi, int ni, int pc) -> f32x4 {
+            if (M16) return acc16[M16 ? 2 * mi + (pc >> 1) : 0][M16 ? 2 * ni + (pc & 1) : 0];
+            return f32x4{acc[M16 ? 0 : mi][M16 ? 0 : ni][pc * 4 + 0], acc[M16 ? 0 : mi][M16 ? 0 : ni][pc * 4 + 1],
+                         acc[M16 ? 0 : mi][M16 ? 0 : ni][pc * 4 + 2], acc[M16 ? 0 : mi][M16 ? 0 : ni][pc * 4 + 3]};
+        };
         auto w16_addr = [&](int ni, int pc) -> unsigned {      // bf16, 64-column rows
-            return (w16n_pre ^ ((ni * 8 + 4 * (pc & 1)) << 3)) + (pc >> 1) * 2048;
+            return M16 ? (w16n_pre ^ ((ni * 8 + 4 * (pc & 1)) << 3)) + (pc >> 1) * 2048 : w16_pre ^ ((ni * 8 + 2 * pc) << 3);
         };
         auto wp_addr = [&](int which, int pc) -> unsigned {    // activation pair: which = 0 act', 1 act
-            return (wpn_pre ^ ((which * 8 + 4 * (pc & 1)) << 3)) + (pc >> 1) * 2048;
+            return M16 ? (wpn_pre ^ ((which * 8 + 4 * (pc & 1)) << 3)) + (pc >> 1) * 2048 : wp_pre ^ ((which * 8 + 2 * pc) << 3);
         };
         auto w32_addr = [&](int pc) -> unsigned {              // fp32, 32-column rows
-            return (w32n_pre ^ ((pc & 1) << 6)) + (pc >> 1) * 2048;
+            return M16 ? (w32n_pre ^ ((pc & 1) << 6)) + (pc >> 1) * 2048 : w32_pre ^ (pc << 5);
         };
         const unsigned r16_a = ebuf + r0 * 128 + (((lane_e & 7) ^ (r0 >> 1)) << 4);       // bf16, it even
         const unsigned r16_b = ebuf + r0 * 128 + (((lane_e & 7) ^ (r0 >> 1) ^ 4) << 4);   // bf16, it odd ((row & 15) >> 1 flips bit 2)
@@ -637,7 +879,7 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
                                 const float4 r = __builtin_bit_cast(float4, side[sub % SIDE_DEPTH][it]);
                                 t[it] = __builtin_bit_cast(u32x4, make_float4(x.x + r.x, x.y + r.y, x.z + r.z, x.w + r.w));
                             }
-                            if (NT_STORE) store16<2>(t[it], o_rs, st32_loff, so + it * 32 * ldo);   // K >= 2048: large operand set
+                            if (ABL & 4096) store16<2>(t[it], o_rs, st32_loff, so + it * 32 * ldo);   // K >= 2048: large operand set
                             else store16(t[it], o_rs, st32_loff, so + it * 32 * ldo);
                         }
                     }
@@ -654,13 +896,23 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
             issue_b();
         }
     }
+    if ((ABL & 128) && p.trace && lane == 0) {   // [workgroup][wave]{operand wait, barrier wait, DMA issue, tile loop total}
+        unsigned long long* t = p.trace + ((long)blockIdx.x * 8 + w) * 4;
+        t[0] = wt_vm; t[1] = wt_bar; t[2] = wt_dma; t[3] = __builtin_amdgcn_s_memtime() - wt_begin;
+    }
     };
-    if (w >= 4) run(std::integral_constant<int, 2>{});
+    if (!SPLIT) run(std::integral_constant<int, 0>{});
+    else if ((w < 4) != SWAP) run(std::integral_constant<int, 2>{});
     else run(std::integral_constant<int, 1>{});
-    if (m_total > p.M && !strip_first) strip_tail<EPI, ACT>(p, p.M, m_total, lds, w, lane);
-    if (p.trace && w == 0 && lane == 0) {
+    if ((ABL & 15) == 0 && m_total > p.M && !strip_first) strip_tail<EPI, ACT>(p, p.M, m_total, lds, w, lane);
+    if (!(ABL & (128 | 2048)) && p.trace && w == 0 && lane == 0) {
         p.trace[((long)blockIdx.x * 8 + 7) * 4 + 2] = __builtin_amdgcn_s_memtime();
         p.trace[((long)blockIdx.x * 8 + 7) * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+    }
+    if (ABL & 8) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sink ^= pendA[j] ^ pendB[j];
+        if (sink.x == 0x12345678u && sink.y == 0x9abcdef0u && sink.z == sink.w) store16(sink, o_rs, 0, 0);
     }
 }
 
@@ -670,38 +922,94 @@ gemm_bf16_nt_256p_kernel(GemmBf16 p, int tiles_m, int tiles_n, int m_total) {
 #undef RVLM_PIECE_LDS
 #undef RVLM_PIECE_GOFF
 
-// (the test hooks of the A/B arms: no-ops here - the shipped library instantiates the measured form only)
 int g_persist_ablate = 0;
-void gemm_set_ablate(int) { g_persist_ablate = 0; }
-bool gemm_has_ablate() { return false; }
+// (shipped library: the ablation kernels are not instantiated - any value other than 0 is ignored)
+void gemm_set_ablate(int v) { g_persist_ablate = P_KNOBS ? v : 0; }
+bool gemm_has_ablate() { return P_KNOBS; }
 unsigned long long* g_persist_trace = nullptr;   // [256 workgroups][8 tiles][4 stamps] or null
 void gemm_set_trace(unsigned long long* ptr) { g_persist_trace = ptr; }
-void gemm_set_m16(int) {}
-bool gemm_has_m32() { return false; }
 
-template <int EPI, int ACT, int FORM>
-static int launch_256p_form(const GemmBf16& p, int tiles_m, int tiles_n, int m_total, hipStream_t s) {
+// MFMA shape of the tile phase: 1 = v_mfma_f32_16x16x32_bf16 (RVLM_GEMM_M16; rvlm_k_gemm_set_m16 for same-process A/Bs)
+static int g_m16 = -1;
+static bool gemm_m16() {
+#ifdef RVLM_EXPERIMENTAL_GEMM
+    if (g_m16 < 0) { const char* e = getenv("RVLM_GEMM_M16"); g_m16 = e ? atoi(e) : RVLM_GEMM_M16_DEFAULT; }
+    return g_m16 != 0;
+#else
+    return true;       // the shipped library instantiates the measured form only
+#endif
+}
+
+void gemm_set_m16(int v) { g_m16 = v; }
+bool gemm_has_m32() { return P_KNOBS; }
+
+template <int EPI, int ACT, int ABL>
+static int launch_256p_abl(const GemmBf16& p, int tiles_m, int tiles_n, int m_total, hipStream_t s) {
     static unsigned long long attr_devices = 0;
     const int lds_bytes = 3 * PA_SLOT + 2 * PB_SLOT;
     RVLM_ONCE_PER_DEVICE(attr_devices, {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_nt_256p_kernel<EPI, ACT, FORM>,
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_nt_256p_kernel<EPI, ACT, ABL>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return fail(RVLM_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
     });
-    const int grid = std::min(tiles_m * tiles_n, 256);
+    int max_wg = 256;
+#ifdef RVLM_EXPERIMENTAL_GEMM      // experiment: fewer workgroups than CUs (two half-batch pipelines side by side, scripts/two_stream_probe.py)
+    static int e_max_wg = -1;
+    if (e_max_wg < 0) { const char* e = getenv("RVLM_GEMM_MAX_WG"); e_max_wg = e ? std::max(8, atoi(e)) : 256; }
+    max_wg = e_max_wg;
+#endif
+    const int grid = std::min(tiles_m * tiles_n, max_wg);
     GemmBf16 q = p;
     q.trace = g_persist_trace;
-    hipLaunchKernelGGL((gemm_bf16_nt_256p_kernel<EPI, ACT, FORM>), dim3(grid), dim3(512), lds_bytes, s, q, tiles_m, tiles_n, m_total);
+    hipLaunchKernelGGL((gemm_bf16_nt_256p_kernel<EPI, ACT, ABL>), dim3(grid), dim3(512), lds_bytes, s, q, tiles_m, tiles_n, m_total);
     RVLM_CHECK_LAUNCH();
     return RVLM_OK;
 }
 template <int EPI, int ACT>
 static int launch_256p_act(const GemmBf16& p, int tiles_m, int tiles_n, int m_total, hipStream_t s) {
-    if constexpr (EPI == EPI_F32_RESID) {
-        // fp32 output stored nt from K = 2048 on (profiles/r03_ab_nt_threshold.log)
-        if (p.K >= 2048) return launch_256p_form<EPI, ACT, 4096 | 8192>(p, tiles_m, tiles_n, m_total, s);
+#ifdef RVLM_EXPERIMENTAL_GEMM
+    if constexpr (EPI == EPI_BF16) {   // the timing experiments exist for the plain epilogue only
+        switch (g_persist_ablate) {
+            case 1: return launch_256p_abl<EPI, ACT, 1>(p, tiles_m, tiles_n, m_total, s);
+            case 2: return launch_256p_abl<EPI, ACT, 2>(p, tiles_m, tiles_n, m_total, s);
+            case 4: return launch_256p_abl<EPI, ACT, 4>(p, tiles_m, tiles_n, m_total, s);
+            case 5: return launch_256p_abl<EPI, ACT, 5>(p, tiles_m, tiles_n, m_total, s);
+            case 6: return launch_256p_abl<EPI, ACT, 6>(p, tiles_m, tiles_n, m_total, s);
+            case 128: return launch_256p_abl<EPI, ACT, 128>(p, tiles_m, tiles_n, m_total, s);
+            case 129: return launch_256p_abl<EPI, ACT, 129>(p, tiles_m, tiles_n, m_total, s);
+            case 132: return launch_256p_abl<EPI, ACT, 132>(p, tiles_m, tiles_n, m_total, s);
+            case 133: return launch_256p_abl<EPI, ACT, 133>(p, tiles_m, tiles_n, m_total, s);
+            case 256: return launch_256p_abl<EPI, ACT, 256>(p, tiles_m, tiles_n, m_total, s);
+            case 384: return launch_256p_abl<EPI, ACT, 384>(p, tiles_m, tiles_n, m_total, s);
+            case 512: return launch_256p_abl<EPI, ACT, 512>(p, tiles_m, tiles_n, m_total, s);
+            case 1024: return launch_256p_abl<EPI, ACT, 1024>(p, tiles_m, tiles_n, m_total, s);
+            case 2048: return launch_256p_abl<EPI, ACT, 2048>(p, tiles_m, tiles_n, m_total, s);
+            case 2053: return launch_256p_abl<EPI, ACT, 2053>(p, tiles_m, tiles_n, m_total, s);
+            case 1152: return launch_256p_abl<EPI, ACT, 1152>(p, tiles_m, tiles_n, m_total, s);
+            case 14: return launch_256p_abl<EPI, ACT, 14>(p, tiles_m, tiles_n, m_total, s);
+            case 12: return launch_256p_abl<EPI, ACT, 12>(p, tiles_m, tiles_n, m_total, s);
+            default: break;
+        }
     }
-    return launch_256p_form<EPI, ACT, 8192>(p, tiles_m, tiles_n, m_total, s);
+#endif
+    if constexpr (EPI == EPI_F32_RESID) {
+#ifdef RVLM_EXPERIMENTAL_GEMM           // evidence for DESIGN.md: the fp32 + residual epilogue with the MFMAs removed
+        if (g_persist_ablate == 2) return launch_256p_abl<EPI, ACT, 2>(p, tiles_m, tiles_n, m_total, s);
+#endif
+        // fp32 output stored nt from K = 2048 on (profiles/r03_ab_nt_threshold.log; EXPERIMENTAL builds: RVLM_GEMM_NT_K, 0 = never)
+        static int nt_k = -1;
+        if (nt_k < 0) { const char* e = P_KNOBS ? getenv("RVLM_GEMM_NT_K") : nullptr; nt_k = e ? atoi(e) : 2048; }
+        if (nt_k > 0 && p.K >= nt_k && g_persist_ablate == 0) {
+#ifdef RVLM_EXPERIMENTAL_GEMM
+            if (!gemm_m16()) return launch_256p_abl<EPI, ACT, 4096>(p, tiles_m, tiles_n, m_total, s);
+#endif
+            return launch_256p_abl<EPI, ACT, 4096 | 8192>(p, tiles_m, tiles_n, m_total, s);
+        }
+    }
+#ifdef RVLM_EXPERIMENTAL_GEMM            // the 32x32x16 form of the tile phase (rounds 1-3) is the A/B arm now
+    if (!gemm_m16() || g_persist_ablate != 0) return launch_256p_abl<EPI, ACT, 0>(p, tiles_m, tiles_n, m_total, s);
+#endif
+    return launch_256p_abl<EPI, ACT, 8192>(p, tiles_m, tiles_n, m_total, s);
 }
 template <int EPI>
 static int launch_256p(const GemmBf16& p, int tiles_m, int tiles_n, int m_total, hipStream_t s) {
@@ -726,7 +1034,7 @@ int gemm_bf16_nt_256p(const GemmBf16& p, int* rows_done, hipStream_t s) {
             (long)(p.M / p.batch_m_rows) * p.K * std::max(p.lda, p.ldb) * 2 >= lim) return RVLM_OK;
         GemmBf16 q = p;
         q.stagger = 0; q.wave_prio = 0; q.krot = 0; q.group_m = 4;
-        int rc = launch_256p_form<EPI_F32, RVLM_ACT_QUICK_GELU, 8192 | 16384>(q, p.M / P_M, p.N / P_N, p.M, s);
+        int rc = launch_256p_abl<EPI_F32, RVLM_ACT_QUICK_GELU, 8192 | 16384>(q, p.M / P_M, p.N / P_N, p.M, s);
         if (rc) return rc;
         *rows_done = p.M;
         return RVLM_OK;
@@ -746,9 +1054,26 @@ int gemm_bf16_nt_256p(const GemmBf16& p, int* rows_done, hipStream_t s) {
     if (tail_on < 0) { const char* e = getenv("RVLM_GEMM_TAIL"); tail_on = e ? atoi(e) : 1; }
     // the measured settings of the schedule (same-box A/Bs of round 3): the workgroups of every second
     // XCD take their remainder-row unit first (130), tile-order groups of 4 m-tiles
-    q.stagger = (130 & 255) << 16; q.wave_prio = 0; q.krot = 0;
-    q.group_m = 4;
-    const bool tail = tail_on && p.batch_m_rows == 0 && p.M > q.M;
+    int strip_first = 130, group_m = 4;
+    q.stagger = 0; q.wave_prio = 0; q.krot = 0;
+#ifdef RVLM_EXPERIMENTAL_GEMM
+    // experiments: start stagger (gained 3 % on the fc2 dgrad under the lockstep schedule, costs it 4 % under the split-role
+    // one, profiles/r02_gemm_knobs_split.log), static priority, K rotation, other strip-first / group sizes
+    static int stagger = -1, stagger_mask = -1, stagger_ph = -1, e_strip_first = -1, e_group_m = -1, wave_prio = -1, krot = -999;
+    if (stagger < 0) { const char* e = getenv("RVLM_GEMM_STAGGER"); stagger = e ? atoi(e) : 0; }
+    if (stagger_mask < 0) { const char* e = getenv("RVLM_GEMM_STAGGER_EPI"); stagger_mask = e ? atoi(e) : 8; }   // bit e: epilogue kind e
+    if (stagger_ph < 0) { const char* e = getenv("RVLM_GEMM_STAGGER_PH"); stagger_ph = e ? atoi(e) : 3; }         // phase mask: 3 = 4 phases
+    if (((stagger_mask >> q.epi) & 1) && stagger > 0) q.stagger = (stagger & 255) | (stagger_ph << 8);
+    if (e_strip_first < 0) { const char* e = getenv("RVLM_GEMM_STRIP_FIRST"); e_strip_first = e ? atoi(e) : strip_first; }
+    if (e_group_m < 0) { const char* e = getenv("RVLM_GEMM_GROUP_M"); e_group_m = e ? std::max(1, atoi(e)) : group_m; }
+    if (wave_prio < 0) { const char* e = getenv("RVLM_GEMM_PRIO"); wave_prio = e ? atoi(e) : 0; }
+    if (krot == -999) { const char* e = getenv("RVLM_GEMM_KROT"); krot = e ? atoi(e) : 0; }
+    strip_first = e_strip_first; group_m = e_group_m;
+    q.wave_prio = wave_prio; q.krot = krot;
+#endif
+    q.stagger |= (strip_first & 255) << 16;
+    q.group_m = group_m;
+    const bool tail = tail_on && (g_persist_ablate & 15) == 0 && p.batch_m_rows == 0 && p.M > q.M;
     const int m_total = tail ? p.M : q.M;
     int rc;
     switch (q.epi) {

@@ -6,7 +6,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 exe = os.path.join(root, "scripts", "probes", "gemm_power_split_probe.bin")
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 4.0
 for rep in range(int(sys.argv[2]) if len(sys.argv) > 2 else 2):
-    for kind in (0, 1, 2, 3):
+    for kind in ((0, 1, 2, 3) if os.environ.get('PROBE_KINDS') is None else tuple(int(k) for k in os.environ['PROBE_KINDS'].split(','))):
         samples, stop = [], False
         def sampler():
             while not stop:
