@@ -51,7 +51,7 @@ struct rvlm_vit {
     // backward scratch
     float* dres;  void* dres_lp;  void* d_o;  void* dqkv;  void* dh;  void* d_ln;  void* d_patch;
     float* dA0;   float* dsum;   float *d_raw, *d_pooled;
-    float *scores, *dscores;   // fp32 mode [B,H,S,S]
+    float* dscores;            // fp32 mode: dP / dS of one block [B, H, S, round_up(S, 4)] (the probabilities live in lse[l])
     float* splitk_scratch;     // fp32 slabs of the split-K few-row GEMMs (+ weight-gradient GEMMs when trainable)
     size_t splitk_bytes = 0;
     // class-token tail (bf16 mode): in the last block only the class token's row is live downstream of the attention
@@ -266,23 +266,26 @@ int attention_fwd<bf16_t>(rvlm_vit* h, hipStream_t s, const void* qkv, void* o, 
 // fp32 mode: the score matrices are materialised as [B, H, S, Sld] with Sld = round_up(S, 4) and zero pad columns (never
 // written), so that every product that contracts over or runs along the key dimension of S = 257 takes 16-byte operand loads
 // on the fp32 matrix-pipe tiles (GemmF32::pad4); round 5: the unaligned scalar-load form ran the attention core at 26 TFLOP/s.
-static int attn_scores_f32(rvlm_vit* h, hipStream_t s, const float* qkv, int B) {
+// P = softmax(0.125 Q K^T) of one block into `P` ([B, H, S, Sld]): the block's slot of rvlm_vit::lse, which in fp32 mode holds
+// the probabilities themselves - the backward reads them back instead of recomputing scores + softmax (round 5: 13 GB for
+// ViT-L/14 at B = 128 of 288, one batched GEMM + one softmax pass less per block and backward)
+static int attn_scores_f32(rvlm_vit* h, hipStream_t s, const float* qkv, float* P, int B) {
     const int S = h->S, W = h->W, H = h->H, Sld = (int)round_up(S, 4);
     GemmF32 g;  // scores = 0.125 * Q K^T
     g.A = qkv; g.sam = 3 * W; g.sak = 1; g.sab1 = (long)S * 3 * W; g.sab2 = 64;
     g.B = qkv + W; g.sbn = 3 * W; g.sbk = 1; g.sbb1 = (long)S * 3 * W; g.sbb2 = 64;
-    g.C = h->scores; g.scm = Sld; g.scn = 1; g.scb1 = (long)H * S * Sld; g.scb2 = (long)S * Sld;
+    g.C = P; g.scm = Sld; g.scn = 1; g.scb1 = (long)H * S * Sld; g.scb2 = (long)S * Sld;
     g.M = S; g.N = S; g.K = 64; g.nb1 = B; g.nb2 = H; g.alpha = 0.125f;
     int rc = gemm_f32(g, s); if (rc) return rc;
-    return softmax_rows_fwd(h->scores, (long)B * H * S, S, Sld, s);
+    return softmax_rows_fwd(P, (long)B * H * S, S, Sld, s);
 }
 template <>
-int attention_fwd<float>(rvlm_vit* h, hipStream_t s, const void* qkv_, void* o, float*, int B) {
+int attention_fwd<float>(rvlm_vit* h, hipStream_t s, const void* qkv_, void* o, float* P, int B) {
     const int S = h->S, W = h->W, H = h->H, Sld = (int)round_up(S, 4);
     const float* qkv = (const float*)qkv_;
-    int rc = attn_scores_f32(h, s, qkv, B); if (rc) return rc;
+    int rc = attn_scores_f32(h, s, qkv, P, B); if (rc) return rc;
     GemmF32 g;  // O = P V
-    g.A = h->scores; g.sam = Sld; g.sak = 1; g.sab1 = (long)H * S * Sld; g.sab2 = (long)S * Sld; g.pad4 = 1;
+    g.A = P; g.sam = Sld; g.sak = 1; g.sab1 = (long)H * S * Sld; g.sab2 = (long)S * Sld; g.pad4 = 1;
     g.B = qkv + 2 * W; g.sbn = 1; g.sbk = 3 * W; g.sbb1 = (long)S * 3 * W; g.sbb2 = 64;
     g.C = (float*)o; g.scm = W; g.scn = 1; g.scb1 = (long)S * W; g.scb2 = 64;
     g.M = S; g.N = 64; g.K = S; g.nb1 = B; g.nb2 = H;
@@ -299,12 +302,12 @@ int attention_bwd<bf16_t>(rvlm_vit* h, hipStream_t s, const void* qkv, const voi
 }
 template <>
 int attention_bwd<float>(rvlm_vit* h, hipStream_t s, const void* qkv_, const void*, const void* d_o_,
-                         const float*, void* dqkv_, int B) {
+                         const float* P, void* dqkv_, int B) {
     const int S = h->S, W = h->W, H = h->H, Sld = (int)round_up(S, 4);
     const float* qkv = (const float*)qkv_;
     const float* d_o = (const float*)d_o_;
     float* dqkv = (float*)dqkv_;
-    int rc = attn_scores_f32(h, s, qkv, B); if (rc) return rc;  // recompute P
+    int rc;                                                       // (P: kept by the forward)
     const long bs1 = (long)H * S * Sld, bs2 = (long)S * Sld, qs1 = (long)S * 3 * W, os1 = (long)S * W;
     GemmF32 g;  // dP = dO V^T
     g.A = d_o; g.sam = W; g.sak = 1; g.sab1 = os1; g.sab2 = 64;
@@ -312,7 +315,7 @@ int attention_bwd<float>(rvlm_vit* h, hipStream_t s, const void* qkv_, const voi
     g.C = h->dscores; g.scm = Sld; g.scn = 1; g.scb1 = bs1; g.scb2 = bs2;
     g.M = S; g.N = S; g.K = 64; g.nb1 = B; g.nb2 = H;
     if ((rc = gemm_f32(g, s))) return rc;
-    if ((rc = softmax_rows_bwd(h->scores, h->dscores, (long)B * H * S, S, Sld, 0.125f, s))) return rc;
+    if ((rc = softmax_rows_bwd(P, h->dscores, (long)B * H * S, S, Sld, 0.125f, s))) return rc;
     GemmF32 q;  // dQ = dS K
     q.A = h->dscores; q.sam = Sld; q.sak = 1; q.sab1 = bs1; q.sab2 = bs2; q.pad4 = 1;
     q.B = qkv + W; q.sbn = 1; q.sbk = 3 * W; q.sbb1 = qs1; q.sbb2 = 64;
@@ -326,7 +329,7 @@ int attention_bwd<float>(rvlm_vit* h, hipStream_t s, const void* qkv_, const voi
     k.M = S; k.N = 64; k.K = S; k.nb1 = B; k.nb2 = H;
     if ((rc = gemm_f32(k, s))) return rc;
     GemmF32 v;  // dV = P^T dO
-    v.A = h->scores; v.sam = 1; v.sak = Sld; v.sab1 = bs1; v.sab2 = bs2; v.pad4 = 1;
+    v.A = P; v.sam = 1; v.sak = Sld; v.sab1 = bs1; v.sab2 = bs2; v.pad4 = 1;
     v.B = d_o; v.sbn = 1; v.sbk = W; v.sbb1 = os1; v.sbb2 = 64;
     v.C = dqkv + 2 * W; v.scm = 3 * W; v.scn = 1; v.scb1 = qs1; v.scb2 = 64;
     v.M = S; v.N = 64; v.K = S; v.nb1 = B; v.nb2 = H;
@@ -869,7 +872,8 @@ extern "C" int rvlm_vit_create(const rvlm_vit_config* cfg, const rvlm_vit_weight
         }
         ALLOC_OR_DIE(h->qkv[l], Mp * 3 * W * e);
         ALLOC_OR_DIE(h->attn_o[l], Mp * W * e);
-        ALLOC_OR_DIE(h->lse[l], (size_t)B * h->H * Sp * 4);
+        // bf16: log-sum-exp rows of the flash kernels; fp32: the block's probabilities [B, H, S, round_up(S, 4)], zero pad columns
+        ALLOC_OR_DIE(h->lse[l], h->bf16 ? (size_t)B * h->H * Sp * 4 : (size_t)B * h->H * S * round_up(S, 4) * 4);
         ALLOC_OR_DIE(h->h_pre[l], Mp * 4 * W * e);
     }
     ALLOC_OR_DIE(h->g_act, Mp * 4 * W * e);
@@ -888,10 +892,9 @@ extern "C" int rvlm_vit_create(const rvlm_vit_config* cfg, const rvlm_vit_weight
     ALLOC_OR_DIE(h->d_raw, (size_t)B * D * 4);
     ALLOC_OR_DIE(h->d_pooled, (size_t)B * W * 4);
     if (!h->bf16) {
-        // [B, H, S, round_up(S, 4)], zero-initialised: the pad columns are never written (attn_scores_f32)
-        ALLOC_OR_DIE(h->scores, (size_t)B * h->H * S * round_up(S, 4) * 4);
+        // [B, H, S, round_up(S, 4)], zero-initialised: the pad columns are never written
         ALLOC_OR_DIE(h->dscores, (size_t)B * h->H * S * round_up(S, 4) * 4);
-    } else { h->scores = h->dscores = nullptr; }
+    } else { h->dscores = nullptr; }
     h->trainable = cfg->trainable > 0;
     h->tokens = h->dtok = nullptr; h->tA = h->tB = nullptr;
     {

@@ -191,17 +191,27 @@ __global__ void __launch_bounds__(256) gemm_f32_mfma_kernel(GemmF32 p, int vec_a
             la.load(A, p.sam, p.sak, m0, Ma, (kt + 1) * BK, Ka, tid, va);
             lb.load(Bm, p.sbn, p.sbk, n0, Nb, (kt + 1) * BK, Kb, tid, vb);
         }
+        // the operands of k-pair kk + 1 are requested BEFORE the MFMAs of pair kk (round 5, PMC: with read -> wait -> 4 MFMAs per
+        // pair the matrix pipe was busy 70 % of the kernel, the waves parked at s_waitcnt 17-25 % of their cycles)
+        float a[2][TM], b[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[0][i] = As[cur][hi][wm + 32 * i + l31];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[0][j] = Bs[cur][hi][wn + 32 * j + l31];
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {     // k increases: the sum order of every output element is k = 0, 1, 2, ...
-            float a[TM], b[TN];
+            if (kk + 1 < BK / 2) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = As[cur][2 * kk + hi][wm + 32 * i + l31];
+                for (int i = 0; i < TM; ++i) a[(kk + 1) & 1][i] = As[cur][2 * kk + 2 + hi][wm + 32 * i + l31];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Bs[cur][2 * kk + hi][wn + 32 * j + l31];
+                for (int j = 0; j < TN; ++j) b[(kk + 1) & 1][j] = Bs[cur][2 * kk + 2 + hi][wn + 32 * j + l31];
+            }
+            __builtin_amdgcn_sched_barrier(0);     // (hipcc otherwise sinks the requests behind the MFMAs, into the same registers)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk & 1][i], b[kk & 1][j], acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < nk) {     // the other buffer: every wave left it at the barrier that closed step kt - 1
             la.store(As[cur ^ 1], tid);
@@ -369,8 +379,33 @@ int gemm_f32(const GemmF32& p, hipStream_t s) {
         int bm = 64, bn = 64;
         if (vol(128, 64) <= vol(bm, bn) && wgs(128, 64) >= 256) { bm = 128; bn = 64; }
         if (vol(128, 128) <= vol(bm, bn) && wgs(128, 128) >= 256) { bm = 128; bn = 128; }
-        if (bm == 128 && bn == 128) launch_f32_mfma<128, 128>(p, akc, bkc, va, vb, s);
-        else if (bm == 128) launch_f32_mfma<128, 64>(p, akc, bkc, va, vb, s);
+        if (bm == 128 && bn == 128) {
+            // Tail split: 128 x 128 workgroups are resident three per CU (139 registers), i.e. the launch runs in rounds of 768
+            // equal tiles and a last round that is mostly empty costs a whole tile time - M = 32 896: the QKV projection is
+            // 8.03 rounds, the N = 1024 products 2.68.  The main launch therefore takes the largest prefix of row tiles that
+            // fills whole rounds, and the remaining rows go in 64 x 64 tiles (a quarter of the tile time, more slots).  Every
+            // output element is the same k-ordered chain under any tiling, so the split changes no bit.
+            const long slots = 3 * 256, tm = cdiv(p.M, 128), tn = cdiv(p.N, 128), tiles = tm * tn * nb;
+            const long rounds = tiles / slots, rem = tiles % slots;
+            const long tm_main = nb == 1 ? (rounds * slots) / tn : tm;
+            if (nb == 1 && rounds >= 1 && rem > 0 && rem < slots * 3 / 4 && tm_main >= 1 && tm_main < tm) {
+                GemmF32 a = p, b = p;
+                a.M = (int)(tm_main * 128);
+                const long r0 = tm_main * 128;
+                b.M = p.M - (int)r0;
+                b.A = p.A + r0 * p.sam;
+                b.C = p.C + r0 * p.scm;
+                if (p.C_pre) b.C_pre = p.C_pre + r0 * p.scm;
+                if (p.dact_h) b.dact_h = p.dact_h + r0 * p.scm;
+                if (p.residual) b.residual = p.residual + r0 * p.scm;
+                launch_f32_mfma<128, 128>(a, akc, bkc, va, vb, s);
+                RVLM_CHECK_LAUNCH();
+                const bool va_t = f32_vec_ok(b.A, akc, b.sam, b.sak, b.sab1, b.sab2, b.M, b.K, b.pad4 & 1);
+                launch_f32_mfma<64, 64>(b, akc, bkc, va_t, vb, s);
+            } else {
+                launch_f32_mfma<128, 128>(p, akc, bkc, va, vb, s);
+            }
+        } else if (bm == 128) launch_f32_mfma<128, 64>(p, akc, bkc, va, vb, s);
         else launch_f32_mfma<64, 64>(p, akc, bkc, va, vb, s);
         RVLM_CHECK_LAUNCH();
         return RVLM_OK;

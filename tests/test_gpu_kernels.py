@@ -108,6 +108,7 @@ F32_CASES = [   # M, N, K, nb, A k-contiguous, B k-contiguous
     (257, 64, 257, 6, True, False), (257, 64, 257, 6, False, False),                                  # P V / dS^T Q
     (1028, 3072, 1024, 1, True, True), (514, 1024, 4096, 1, True, False), (1285, 768, 3072, 1, True, True),
     (640, 512, 37, 1, True, True), (33, 1000, 768, 1, True, False), (300, 70, 129, 3, False, True),
+    (4224, 3072, 128, 1, True, True), (4230, 3072, 96, 1, False, True),      # > 768 tiles of 128 x 128: the tail-split dispatch
 ]
 
 
