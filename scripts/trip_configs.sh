@@ -8,3 +8,5 @@ run c5 --attack autopgd --iterations 100 --batch 256 --steps 1 --warmup 1 --no-r
 run train --mode train --steps 3 --warmup 1
 run b32 --model ViT-B-32 --steps 5 --warmup 2
 run l14_336 --model ViT-L-14-336 --batch 64 --steps 2 --warmup 1 --no-roofline
+run fp32 --precision fp32 --steps 2 --warmup 1 --no-pmc
+run mixed --precision bf16+fp32-first --steps 3 --warmup 1 --no-pmc
