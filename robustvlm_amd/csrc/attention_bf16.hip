@@ -324,6 +324,9 @@ __device__ __forceinline__ void attn_fwd_odd_head(const char* Kt, const char* Vt
         for (int kk = 0; kk < 4; ++kk) qf[kk] = PRE ? qf_pre[kk] : frag_global(base, ld, q, kk, lane);
         f32x16 oacc[2] = {zero16(), zero16()};
         float m = -INFINITY, l = 0.0f;
+        // (Two score tiles in flight - the S MFMAs of key tile kt + 1 issued in front of the softmax arithmetic of tile kt, T15 of
+        // the guide - measured SLOWER here, 75-77 against 72-74 us on one box, profiles/r05_attn_ab_fwd_two_tiles_in_flight.log: with
+        // four waves per SIMD the partner waves already fill the gaps, and the form costs 13 registers and a recomputed last tile.)
 #pragma unroll 1
         for (int kt = 0; kt < NK; ++kt) block(qf, kt, m, l, oacc);
         odd_key(qf, m, l, oacc);
