@@ -953,7 +953,7 @@ static int launch_256p_abl(const GemmBf16& p, int tiles_m, int tiles_n, int m_to
         if (e != hipSuccess) return fail(RVLM_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
     });
     int max_wg = 256;
-#ifdef RVLM_EXPERIMENTAL_GEMM      // experiment: fewer workgroups than CUs (two half-batch pipelines side by side, scripts/two_stream_probe.py)
+#ifdef RVLM_EXPERIMENTAL_GEMM      // experiment: fewer workgroups than CUs (two half-batch pipelines side by side: round 4, profiles/r04_two_stream_half_batches.log)
     static int e_max_wg = -1;
     if (e_max_wg < 0) { const char* e = getenv("RVLM_GEMM_MAX_WG"); e_max_wg = e ? std::max(8, atoi(e)) : 256; }
     max_wg = e_max_wg;
