@@ -24,7 +24,9 @@ VIT_WIDE = V.VitConfig(64, 8, 1024, 2, 16, 64)
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
-@pytest.mark.parametrize("cfg,B,norm", [(V.VIT_TINY, 4, False), (V.VIT_TINY2, 3, True), (VIT_WIDE, 8, True)])
+# (VIT_WIDE, 3): 195 tokens - fewer than the copy-free weight gradient takes: every linear goes through the transposing fallback
+# with the short leading dimension (the scratch of a W % 256 == 0 handle is sized for conv1 and this case only since round 5)
+@pytest.mark.parametrize("cfg,B,norm", [(V.VIT_TINY, 4, False), (V.VIT_TINY2, 3, True), (VIT_WIDE, 8, True), (VIT_WIDE, 3, True)])
 def test_weight_gradients_vs_autograd(cfg, B, norm, precision):
     w = V.init_weights(cfg, seed=11)
     g = torch.Generator().manual_seed(2)
