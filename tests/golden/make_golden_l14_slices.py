@@ -11,6 +11,9 @@ Needs /root/reference (read-only), so it never runs on the GPU box; only its out
 What is executed from the reference (nothing is copied into this repo):
   * ``train.pgd_train.pgd`` (train/pgd_train.py:5-68) - config 2: FARE PGD, 10 steps, eps = 4/255, on the first NP images
     of the batch tests/test_gpu_fullsize.py attacks (torch.rand seed 0, delta_0 seed 1);
+  * ``train.apgd_train.apgd_train`` (train/apgd_train.py:125-373) - config 3: TeCoA (CE on ``emb @ (100 T)``), 10 iterations, on
+    the first NP images with the labels of the test batch (randint seed 2); written to l14_slices_c3.npz
+    (``python tests/golden/make_golden_l14_slices.py c3`` makes that file alone);
   * ``autoattack.autopgd_base.APGDAttack.attack_single_run`` (autoattack/autopgd_base.py:205-451) - config 5: CE loss,
     ALL 100 iterations, on the first NA images, from a recorded start point (seed 9), labels = the model's own clean
     predictions.
@@ -37,6 +40,7 @@ sys.path.insert(0, REF)
 from oracle import vit_ref as V  # noqa: E402
 from oracle import losses_ref as Lr  # noqa: E402
 from train.pgd_train import pgd as ref_pgd  # noqa: E402
+from train.apgd_train import apgd_train as ref_apgd_train  # noqa: E402
 from autoattack.autopgd_base import APGDAttack as RefAPGDAttack  # noqa: E402
 
 NP, NA = 8, 2
@@ -44,11 +48,33 @@ EPS, STEP = 4 / 255, 1 / 255
 THREADS = int(os.environ.get("GOLDEN_THREADS", "8"))
 
 
+def config3(ref, cfg, x):
+    """The reference's apgd_train() with the TeCoA loss wrapper of the trainer (...clip.py:323-333)."""
+    t0 = time.time()
+    y = torch.randint(0, 1000, (256,), generator=torch.Generator().manual_seed(2))
+    T = torch.nn.functional.normalize(torch.randn(cfg.out_dim, 1000, generator=torch.Generator().manual_seed(3)), dim=0)
+    xc, yc = x[:NP].clone(), y[:NP].clone()
+    wrap = Lr.ComputeLossWrapperRef(None, T, "none", "ce", 100.)
+    x_adv = ref_apgd_train(ref, xc, yc, "linf", EPS, n_iter=10, loss_fn=wrap).detach()
+    with torch.no_grad():
+        ce = lambda xx: Lr.compute_loss_ref("ce", ref(xx, True), yc, None, 100., T, "none")     # noqa: E731
+        l_clean, l_adv = ce(xc), ce(x_adv)
+    print(f"apgd_train: {time.time() - t0:.0f} s, ce {l_clean.mean():.4g} -> {l_adv.mean():.4g}", flush=True)
+    path = os.path.join(ROOT, "tests", "golden", "l14_slices_c3.npz")
+    np.savez_compressed(path, n=np.int64(NP), x_adv=x_adv.numpy(), y=yc.numpy(), loss_clean=l_clean.numpy(), loss_adv=l_adv.numpy(),
+                        threads=np.int64(THREADS), torch_version=np.array(torch.__version__), weights_seed=np.int64(3),
+                        eps=np.float64(EPS))
+    print("wrote", path, os.path.getsize(path) >> 10, "KiB")
+
+
 def main():
     torch.set_num_threads(THREADS)
     cfg = V.VIT_L_14
     w = V.init_weights(cfg, seed=3)
     ref = V.ClipVisionModelRef(cfg, w).eval()
+    if len(sys.argv) > 1 and sys.argv[1] == "c3":
+        config3(ref, cfg, torch.rand(256, 3, 224, 224, generator=torch.Generator().manual_seed(0)))
+        return
     # the batch of tests/test_gpu_fullsize.py::setup (the whole 256-image tensors are drawn, then sliced)
     x = torch.rand(256, 3, 224, 224, generator=torch.Generator().manual_seed(0))
     d0 = (torch.rand(256, 3, 224, 224, generator=torch.Generator().manual_seed(1)) * 2 - 1) * EPS
@@ -90,6 +116,7 @@ def main():
     path = os.path.join(ROOT, "tests", "golden", "l14_slices.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) >> 10, "KiB")
+    config3(ref, cfg, x)
 
 
 if __name__ == "__main__":
