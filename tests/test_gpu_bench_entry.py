@@ -109,3 +109,17 @@ def test_two_rank_rehearsal_train_step_line():
     assert d["n_gpus"] == 2 and "rehearsal" in d and d["value"] > 0
     assert d["allreduce"]["world"] == 2 and "gloo" in d["allreduce"]["backend"]
     assert d["final_loss"] == d["final_loss"]        # finite
+
+
+def test_fp32_line_is_priced_against_the_fp32_matrix_peak():
+    """--precision fp32 (the reference's own precision on v_mfma_f32_32x32x2_f32): dtype, roofline peak and kernel name of the line."""
+    d = _one_line(run("--gpus", "1", "--steps", "1", "--warmup", "1", "--model", "ViT-B-32", "--batch", "8", "--precision", "fp32",
+                      "--no-cpu-baseline"))
+    assert d["dtype"] == "fp32" and d["roofline"]["peak"] == 157.3 and "gemm_f32_mfma_kernel" in d["roofline"]["kernel"]
+    assert 0 < d["roofline"]["frac"] < 1
+
+
+def test_mixed_precision_line():
+    d = _one_line(run("--gpus", "1", "--steps", "1", "--warmup", "1", "--model", "ViT-B-32", "--batch", "8", "--precision",
+                      "bf16+fp32-first", "--no-cpu-baseline"))
+    assert d["dtype"] == "bf16+fp32-first" and d["value"] > 0 and d["roofline"]["peak"] == 2500.0

@@ -649,3 +649,27 @@ def test_apgdattack_single_sample():
     with pytest.raises(AssertionError):
         R.ce(lg, y[:1])
     eng.close()
+
+
+def test_mixed_precision_engine_is_an_attack_option_only():
+    """precision='bf16+fp32-first' holds a bf16 and an fp32 handle of the same weights: gradient-free forwards come from the
+    fp32 one (bit-equal to an fp32 engine), saving forwards from the bf16 one; it refuses to be a trainable / inference-only
+    engine, and an unknown precision is a ValueError."""
+    from oracle import vit_ref as V
+    cfg = V.VIT_TINY2
+    w = {k: v.to(dev()) for k, v in V.init_weights(cfg, seed=1).items()}
+    c = R.VitConfig(cfg.image_size, cfg.patch, cfg.width, cfg.layers, cfg.heads, cfg.out_dim)
+    for kw in (dict(trainable=True), dict(inference_only=True)):
+        with pytest.raises(ValueError, match="attack-engine option"):
+            R.VitEngine(c, w, precision="bf16+fp32-first", max_batch=4, **kw)
+    with pytest.raises(ValueError, match="not supported"):
+        R.VitEngine(c, w, precision="fp16", max_batch=4)
+    mixed = R.VitEngine(c, w, precision="bf16+fp32-first", max_batch=4)
+    e32 = R.VitEngine(c, w, precision="fp32", max_batch=4)
+    e16 = R.VitEngine(c, w, precision="bf16", max_batch=4)
+    x = torch.rand(4, 3, cfg.image_size, cfg.image_size, generator=torch.Generator().manual_seed(0)).to(dev())
+    assert torch.equal(mixed.forward(x, None, False, save=False), e32.forward(x, None, False, save=False))
+    assert torch.equal(mixed.forward(x, None, False, save=True), e16.forward(x, None, False, save=True))
+    assert mixed.workspace_bytes() == e32.workspace_bytes() + e16.workspace_bytes()
+    for e in (mixed, e32, e16):
+        e.close()
