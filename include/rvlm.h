@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RVLM_VERSION 106
+#define RVLM_VERSION 107
 
 typedef void* rvlm_stream_t; /* hipStream_t */
 typedef struct rvlm_vit rvlm_vit;
@@ -234,6 +234,10 @@ int rvlm_apgd_select(float* x_adv, float* grad, float* x_best, float* grad_best,
 /* APGDAttack random start (autopgd_base.py:210-214,180-183): x + eps * t / (max_b|t| + 1e-12). */
 int rvlm_linf_random_start(const float* x, const float* t, float eps, size_t n_per_sample, int B,
                            float* x_adv, rvlm_stream_t stream);
+/* Its L2 form (autopgd_base.py:184-185,215-218): x + eps * t / (|t|_2 + 1e-12), t ~ N(0, 1) drawn by the caller (the reference
+ * draws it on the CPU generator); the norm is a deterministic fp32 sum in the kernel's own order. */
+int rvlm_l2_random_start(const float* x, const float* t, float eps, size_t n_per_sample, int B, float* x_adv,
+                         rvlm_stream_t stream);
 /* Square Attack, L-inf: one query of SquareAttack.attack_single_run (autoattack/square.py:256-263).  Candidates of the
  * n_active still-robust images idx[a] (int64 indices into x / x_best [*, C, H, W]), written compactly to x_new
  * [n_active, C, H, W]:  clamp(min(max(x_best + window, x - eps), x + eps), 0, 1), window = 2*eps*sign[c] on rows
@@ -372,7 +376,8 @@ int rvlm_version(void);   /* = RVLM_VERSION.  101: rvlm_loss_spec.y_target, rvlm
                            * rvlm_pgd_l2_update, rvlm_pgd_run_norm, rvlm_apgd_l2_step, rvlm_apgd_run_norm,
                            * rvlm_project_perturbation, rvlm_normalize_grad; 104: rvlm_preproc_run_batch, rvlm_ce_logits takes B = 1,
                            * rvlm_vit_backward_params_stages refuses out-of-order stages; 105: rvlm_apgd_controller_rho,
-                           * rvlm_vit_set_apgd_rho, rvlm_comm_* / rvlm_allreduce_grads; 106: rvlm_pgd_run_mixed, fp32 mode on v_mfma_f32_32x32x2_f32 */
+                           * rvlm_vit_set_apgd_rho, rvlm_comm_* / rvlm_allreduce_grads; 106: rvlm_pgd_run_mixed, fp32 mode on v_mfma_f32_32x32x2_f32;
+                           * 107: rvlm_l2_random_start */
 
 #ifdef __cplusplus
 }

@@ -90,10 +90,13 @@ def apgd_linf_step_ref(x, x_adv, x_adv_old, grad, step, a, eps):
     return new.astype(F32), x_adv.copy()
 
 
-def apgd_l2_step_ref(x, x_adv, x_adv_old, grad, step, a, eps):
+def apgd_l2_step_ref(x, x_adv, x_adv_old, grad, step, a, eps, attack_form=False):
     """One APGD L2 step (train/apgd_train.py:231-254), with the reference's own tensor expressions (the per-sample
     norms are torch sums: ``(t ** 2).view(B, -1).sum(-1).sqrt()``, :16-20), so that the restatement is bit-equal to the
-    reference on the CPU.  ``step`` is [B,1,1,1] fp32.  Returns (x_adv_new, x_adv_old_new)."""
+    reference on the CPU.  ``step`` is [B,1,1,1] fp32.  Returns (x_adv_new, x_adv_old_new).
+    ``attack_form``: APGDAttack's spelling of the same step (autoattack/autopgd_base.py:343-351) - the gradient step is
+    ``step * normalize(grad)`` = step * (g / (|g| + 1e-12)) where apgd_train writes (step * g) / (|g| + 1e-12): one fp32
+    rounding apart."""
     xt, xa, xo, g = (torch.from_numpy(np.ascontiguousarray(t)) for t in (x, x_adv, x_adv_old, grad))
     st = torch.from_numpy(np.ascontiguousarray(step))
 
@@ -101,7 +104,7 @@ def apgd_l2_step_ref(x, x_adv, x_adv_old, grad, step, a, eps):
         return (t ** 2).view(t.shape[0], -1).sum(-1).sqrt().view(-1, *[1] * (t.dim() - 1))
 
     grad2 = xa - xo
-    x1 = xa + st * g / (l2n(g) + 1e-12)
+    x1 = xa + st * (g / (l2n(g) + 1e-12)) if attack_form else xa + st * g / (l2n(g) + 1e-12)
     x1 = torch.clamp(xt + (x1 - xt) / (l2n(x1 - xt) + 1e-12) * torch.min(eps * torch.ones_like(xt), l2n(x1 - xt)), 0.0, 1.0)
     x1 = xa + (x1 - xa) * a + grad2 * (1 - a)
     x1 = torch.clamp(xt + (x1 - xt) / (l2n(x1 - xt) + 1e-12) * torch.min(eps * torch.ones_like(xt), l2n(x1 - xt)), 0.0, 1.0)
@@ -257,15 +260,16 @@ def apgd_train_ref(model, x, y, norm, eps, n_iter=10, use_rs=False, loss_fn=None
 
 
 # --------------------------------------------------------------------------------------------------
-# APGDAttack (autoattack/autopgd_base.py, Linf + CE)
+# APGDAttack (autoattack/autopgd_base.py, Linf / L2; CE / DLR / targeted DLR)
 # --------------------------------------------------------------------------------------------------
 class APGDAttackRef:
     def __init__(self, predict, n_iter=100, norm="Linf", n_restarts=1, eps=None, seed=0, loss="ce",
                  eot_iter=1, rho=.75, topk=None, verbose=False, device=None, use_largereps=False,
                  is_tf_model=False, logger=None, alpha=None, use_rs=True):
-        assert norm == "Linf" and loss in ("ce", "dlr", "dlr-targeted") and eot_iter == 1 and not use_largereps \
-            and not is_tf_model, "oracle restates the Linf path with the CE / DLR / targeted-DLR losses (SURVEY.md 8(a12), 8(f3))"
+        assert norm in ("Linf", "L2") and loss in ("ce", "dlr", "dlr-targeted") and eot_iter == 1 and not use_largereps \
+            and not is_tf_model, "oracle restates the Linf / L2 paths with the CE / DLR / targeted-DLR losses (SURVEY.md 8(a12), 8(f3))"
         assert eps is not None
+        self.norm = norm
         self.model, self.n_iter, self.eps, self.n_restarts = predict, n_iter, eps, n_restarts
         self.seed, self.thr_decr, self.alpha, self.use_rs = seed, rho, alpha, use_rs
         self.loss, self.y_target = loss, None
@@ -293,6 +297,12 @@ class APGDAttackRef:
     def _random_start(self, xn):
         # autopgd_base.py:210-214 + normalize() :180-183: x + eps * t / (max|t| + 1e-12), t~U(-1,1)
         # The reference draws t on the CPU generator and moves it to the device.
+        if self.norm == "L2":
+            # :184-185, 215-218: t ~ N(0,1), x + eps * t / (|t|_2 + 1e-12), in the reference's own torch expressions
+            t = torch.randn(xn.shape)
+            xt = torch.from_numpy(xn)
+            nrm = (t ** 2).view(t.shape[0], -1).sum(-1).sqrt()
+            return (xt + self.eps * torch.ones_like(xt) * (t / (nrm.view(-1, 1, 1, 1) + 1e-12))).numpy().astype(F32)
         t = (2 * torch.rand(xn.shape) - 1).numpy().astype(F32)
         tmax = np.abs(t).reshape(t.shape[0], -1).max(1).reshape(-1, 1, 1, 1)
         return (xn + F32(self.eps) * np.ones_like(xn) * (t / (tmax + F32(1e-12)))).astype(F32)
@@ -314,8 +324,12 @@ class APGDAttackRef:
         x_adv_old = x_adv.copy()
         for i in range(self.n_iter):
             a = 0.75 if i > 0 else 1.0
-            x_adv, x_adv_old = apgd_linf_step_ref(xn, x_adv, x_adv_old, grad,
-                                                  ctl.step.reshape(B, 1, 1, 1), a, self.eps)
+            if self.norm == "L2":
+                x_adv, x_adv_old = apgd_l2_step_ref(xn, x_adv, x_adv_old, grad, ctl.step.reshape(B, 1, 1, 1), a, self.eps,
+                                                    attack_form=True)
+            else:
+                x_adv, x_adv_old = apgd_linf_step_ref(xn, x_adv, x_adv_old, grad,
+                                                      ctl.step.reshape(B, 1, 1, 1), a, self.eps)
             logits, loss_indiv, grad = _fwd_bwd(self.model, ce, x_adv, y)         # :369-386
             pred = (logits.max(1)[1] == y).numpy()
             acc = np.minimum(acc, pred)

@@ -51,7 +51,7 @@ class APGDAttackTargetedRef(APGDAttackRef):
 class AutoAttackRef:
     def __init__(self, model, norm="Linf", eps=.3, seed=None, verbose=False, attacks_to_run=(), version="custom",
                  device="cpu", alpha=None, iterations_apgd=100, use_rs=True):
-        assert norm == "Linf" and version == "custom"
+        assert norm in ("Linf", "L2") and version == "custom"   # (L2: the two APGD stages; the square stage is restated for Linf)
         self.model, self.epsilon, self.seed = model, eps, seed
         self.attacks_to_run = list(attacks_to_run)
         self.apgd = APGDAttackRef(model, n_restarts=5, n_iter=iterations_apgd, eps=eps, norm=norm, eot_iter=1, rho=.75,
@@ -60,7 +60,7 @@ class AutoAttackRef:
                                                    eot_iter=1, rho=.75, seed=seed, alpha=alpha, use_rs=use_rs)  # :47-49
         from .square_ref import SquareAttackRef
         self.square = SquareAttackRef(model, p_init=.8, n_queries=5000, eps=eps, norm=norm, n_restarts=1, seed=seed,
-                                      resc_schedule=False)                                    # :42-44
+                                      resc_schedule=False) if norm == "Linf" else None        # :42-44
 
     def get_seed(self):
         return time.time() if self.seed is None else self.seed                    # :79-80

@@ -131,6 +131,7 @@ _SIGS = {
                                    C.c_void_p, C.c_size_t, C.c_int, c_stream]),
     "rvlm_linf_random_start": (C.c_int, [c_f32p, c_f32p, C.c_float, C.c_size_t, C.c_int, c_f32p,
                                          c_stream]),
+    "rvlm_l2_random_start": (C.c_int, [c_f32p, c_f32p, C.c_float, C.c_size_t, C.c_int, c_f32p, c_stream]),
     "rvlm_pgd_run": (C.c_int, [C.c_void_p, c_f32p, c_f32p, C.c_int, C.POINTER(LossSpecC), C.c_float,
                                C.c_int, C.c_float, C.c_float, C.c_int, c_f32p, c_f32p, C.c_void_p,
                                c_stream]),

@@ -1,10 +1,13 @@
 """Drop-in ``APGDAttack`` / ``APGDAttack_targeted`` (autoattack/autopgd_base.py:89-582, 584-707) for BASELINE
-config 5: L-inf, CE / DLR / targeted-DLR losses, random start, restarts over still-correct points.
+config 5: L-inf (and L2, the other norm ``CLIP_eval/clip_robustbench.py --norm`` offers), CE / DLR / targeted-DLR losses,
+random start, restarts over still-correct points.
 
 Native routes as in apgd_train.py: fused (predict is a :class:`ClassificationModel` over the
 engine -> rvlm_apgd_run with the zero-shot head and the loss on the device) or generic (any ``predict``).
-Branches the repo's configs never select (L1 / L2 / TF adapters / use_largereps / EOT) raise NotImplementedError
-(SURVEY.md section 2, row 7).
+Branches the repo's configs never select (L1 / TF adapters / use_largereps / EOT) raise NotImplementedError
+(SURVEY.md section 2, row 7).  L2: the per-sample norms are deterministic fp32 sums in the kernels' own order, and the
+gradient step is evaluated as ``(step * g) / |g|`` (the form of train/apgd_train.py:232) where autopgd_base.py:344 writes
+``step * (g / |g|)`` - one rounding apart, below the spread of the sums themselves.
 """
 from __future__ import annotations
 
@@ -47,8 +50,9 @@ class APGDAttack():
         self.logger = logger
         self.alpha = alpha
         self.n_iter_2, self.n_iter_min, self.size_decr = apgd_schedule(self.n_iter)
-        if norm != 'Linf' or is_tf_model or use_largereps or eot_iter != 1:
-            raise NotImplementedError("native APGDAttack covers norm='Linf', eot_iter=1, torch models")
+        if norm not in ('Linf', 'L2') or is_tf_model or use_largereps or eot_iter != 1:
+            raise NotImplementedError("native APGDAttack covers norm='Linf' / 'L2', eot_iter=1, torch models")
+        self._norm_kind = 0 if norm == 'Linf' else 2
 
     def init_hyperparam(self, x):
         if self.device is None:
@@ -59,15 +63,20 @@ class APGDAttack():
             self.seed = time.time()
 
     def _random_start(self, x):
-        """x + eps * t / max|t|, t ~ U(-1,1) drawn on the CPU generator like the reference
-        (autopgd_base.py:210-214 does torch.rand(x.shape).to(device)), normalised on the device."""
+        """Linf: x + eps * t / max|t|, t ~ U(-1,1);  L2: x + eps * t / |t|_2, t ~ N(0,1).  t is drawn on the CPU generator
+        like the reference (autopgd_base.py:210-218 does torch.rand / torch.randn(x.shape).to(device)), normalised on the
+        device."""
         lib = L.load()
-        t = (2 * torch.rand(x.shape).to(x.device).detach() - 1).contiguous()
+        if self.norm == 'Linf':
+            t = (2 * torch.rand(x.shape).to(x.device).detach() - 1).contiguous()
+            fn = lib.rvlm_linf_random_start
+        else:
+            t = torch.randn(x.shape).to(x.device).detach().contiguous()
+            fn = lib.rvlm_l2_random_start
         out = torch.empty_like(x)
         B = x.shape[0]
         with torch.cuda.device(x.device):
-            L.check(lib.rvlm_linf_random_start(x.data_ptr(), t.data_ptr(), float(self.eps), x[0].numel(), B,
-                                               out.data_ptr(), L.stream_ptr()))
+            L.check(fn(x.data_ptr(), t.data_ptr(), float(self.eps), x[0].numel(), B, out.data_ptr(), L.stream_ptr()))
         return out
 
     # ---- the DLR losses for the generic (arbitrary ``predict``) route; same values as autopgd_base.py:195-201 and
@@ -109,7 +118,7 @@ class APGDAttack():
                     x[lo:hi], None if start is None else start[lo:hi], self.loss, m.text_embedding, y[lo:hi], True,
                     self.eps, self.n_iter, step0, train_variant=False, logits_from_head=True,
                     logit_scale=m.logit_scale_value, want_extra=True, y_target=None if yt is None else yt[lo:hi],
-                    rho=self.thr_decr))
+                    rho=self.thr_decr, norm_kind=self._norm_kind))
             x_best_adv, x_best, loss_best, acc = (torch.cat([p[i] for p in parts]) for i in range(4))
             return x_best, acc.bool(), loss_best, x_best_adv
         if self.loss == 'ce':
@@ -119,7 +128,7 @@ class APGDAttack():
         else:
             crit = self.dlr_loss if self.loss == 'dlr' else self.dlr_loss_targeted
         return _apgd_linf_generic(self.model, crit, x, y, self.eps, self.n_iter, step0, False, x_init=start,
-                                  rho=self.thr_decr)
+                                  rho=self.thr_decr, norm_kind=self._norm_kind)
 
     # ---- shared pieces of the two perturb() flavours --------------------------------------------------------------
     def _setup(self, x, y):

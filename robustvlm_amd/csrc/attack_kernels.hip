@@ -349,6 +349,19 @@ linf_random_start_kernel(const float* __restrict__ x, const float* __restrict__ 
     }
 }
 
+// L2 random start of APGDAttack (autopgd_base.py:184-185, 215-218): x + eps * (t / (|t|_2 + 1e-12)), t ~ N(0, 1) drawn by the
+// caller; one workgroup per sample, the norm a deterministic fp32 sum in this kernel's own order
+__global__ void __launch_bounds__(1024)
+l2_random_start_kernel(const float* __restrict__ x, const float* __restrict__ t, float eps, size_t n_per,
+                       float* __restrict__ x_adv) {
+    __shared__ float red[16];
+    const size_t base = (size_t)blockIdx.x * n_per;
+    float acc = 0.0f;
+    for (size_t j = threadIdx.x; j < n_per; j += 1024) acc = fmaf(t[base + j], t[base + j], acc);
+    const float den = sqrtf(block_sum_1024(acc, red)) + 1e-12f;
+    for (size_t j = threadIdx.x; j < n_per; j += 1024) x_adv[base + j] = x[base + j] + eps * (t[base + j] / den);
+}
+
 static inline int ew_grid(size_t n, int per_thread = 4) {
     size_t blocks = (n / per_thread + 255) / 256;
     if (blocks < 1) blocks = 1;
@@ -531,6 +544,14 @@ extern "C" int rvlm_linf_random_start(const float* x, const float* t, float eps,
     RVLM_REQUIRE(x && t && x_adv && B > 0, "rvlm_linf_random_start: bad args");
     hipLaunchKernelGGL(linf_random_start_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, t,
                        eps, n_per_sample, x_adv);
+    RVLM_CHECK_LAUNCH();
+    return RVLM_OK;
+}
+
+extern "C" int rvlm_l2_random_start(const float* x, const float* t, float eps, size_t n_per_sample, int B, float* x_adv,
+                                    rvlm_stream_t stream) {
+    RVLM_REQUIRE(x && t && x_adv && B > 0 && n_per_sample > 0, "rvlm_l2_random_start: bad args");
+    hipLaunchKernelGGL(l2_random_start_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, x, t, eps, n_per_sample, x_adv);
     RVLM_CHECK_LAUNCH();
     return RVLM_OK;
 }

@@ -415,6 +415,68 @@ def g7_autoattack():
             out[f"{tag}_robust_after_ce"] = (clf(xa1).max(1)[1] == yy).numpy()
     save("autoattack_tiny.npz", **out)
 
+# ------------------------------------------------------------------ G10: the L2 norm of APGDAttack / AutoAttack (--norm l2)
+def g10_autopgd_l2():
+    """``CLIP_eval/clip_robustbench.py --norm l2``: APGDAttack(norm='L2').perturb (CE, two restarts: gaussian random start
+    scaled to the L2 sphere, the L2 step of autopgd_base.py:343-351) and AutoAttack(norm='L2', version='custom',
+    ['apgd-ce', 'apgd-t']) on the tiny ViT + 10-class head of g4 / g7.  eps chosen so that some points fall and some
+    survive."""
+    from autoattack import AutoAttack as RefAutoAttack
+    cfg = vit_ref.VIT_TINY
+    w = init_weights(cfg, seed=3)
+    g = torch.Generator().manual_seed(44)
+    B = 6
+    pool = torch.rand(96, 3, cfg.image_size, cfg.image_size, generator=g)
+    T = torch.randn(cfg.out_dim, 10, generator=g)
+    T = T / T.norm(dim=0, keepdim=True)
+    clf = vit_ref.ClassificationModelRef(cfg, w, T, 100.0).eval()
+    # Points whose clean top-2 margin is moderate.  With logits = 100 cos(e, t) most random images are classified with a
+    # margin beyond ~16.6, where the fp32 cross-entropy is exactly 0 and its gradient is rounding noise IN THE REFERENCE ITSELF
+    # (z_y - logsumexp rounds to 0 or to one ulp of ~50, either of which swamps the 1e-8 softmax terms): two correct fp32
+    # implementations then walk different L2 trajectories, and a golden vector there pins nothing.  (The L-inf goldens
+    # compare sign patterns and live with it.)
+    with torch.no_grad():
+        top2 = clf(pool).topk(2, dim=1).values
+    margin = top2[:, 0] - top2[:, 1]
+    keep = ((margin > 0.5) & (margin < 6.0)).nonzero().squeeze(1)[:B]
+    assert keep.numel() == B, keep
+    x = pool[keep].clone()
+    with torch.no_grad():
+        y = clf(x).max(1)[1]
+    y[0] = (y[0] + 1) % 10            # one sample starts misclassified (never attacked)
+    seen = []
+
+    def predict(v):
+        seen.append(v.detach().clone())
+        return clf(v)
+
+    eps = float(os.environ.get("G10_EPS", "0.1"))
+    out = dict(x=x.numpy(), y=y.numpy(), T=T.numpy(), eps=np.float64(eps), n_iter=np.int64(12), weights_seed=np.int64(3),
+               weights_sha256=np.array(weights_digest(w)), clean_margin=margin[keep].numpy())
+    print("clean margins", margin[keep].numpy())
+    atk = RefAPGDAttack(predict, n_iter=12, norm="L2", n_restarts=2, eps=eps, seed=0, loss="ce", device="cpu", use_rs=True)
+    adv = atk.perturb(x.clone(), y.clone())
+    with torch.no_grad():
+        rob = (clf(adv).max(1)[1] == y).numpy()
+    out.update(adv=adv.detach().numpy(), first_start=seen[1].numpy(), n_model_calls=np.int64(len(seen)), robust=rob)
+    print("apgd-ce L2: robust", rob, "|adv - x|_2", (adv.detach() - x).flatten(1).norm(dim=1).numpy())
+    seen.clear()
+    aa = RefAutoAttack(predict, norm="L2", eps=eps, seed=0, verbose=False, version="custom",
+                       attacks_to_run=["apgd-ce", "apgd-t"], device="cpu", iterations_apgd=8, use_rs=True)
+    aa.apgd.n_restarts = 1
+    aa.apgd_targeted.n_target_classes = 3
+    yy = y.clone()
+    with torch.no_grad():
+        yy = clf(x).max(1)[1]         # AutoAttack over the model's own predictions: every point starts robust
+    x_adv, y_adv = aa.run_standard_evaluation(x.clone(), yy.clone(), bs=4, return_labels=True)
+    with torch.no_grad():
+        rob_aa = (clf(x_adv).max(1)[1] == yy).numpy()
+    print("AutoAttack L2: robust", rob_aa)
+    out.update(aa_y=yy.numpy(), aa_x_adv=x_adv.detach().numpy(), aa_y_adv=y_adv.numpy(), aa_robust=rob_aa,
+               aa_n_model_calls=np.int64(len(seen)), aa_n_iter=np.int64(8), aa_n_target_classes=np.int64(3), aa_bs=np.int64(4))
+    save("autopgd_tiny_l2.npz", **out)
+
+
 # ------------------------------------------------------------------ G9: Square Attack (section 8(f) rank 3, black-box route)
 def g9_square():
     """SquareAttack(L-inf).perturb and AutoAttack(version='custom', ['square']).run_standard_evaluation of the
@@ -510,8 +572,9 @@ def g8_preprocess():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
     fns = dict(g1=g1_pgd_elementwise, g2=g2_apgd_controller, g3=g3_tiny_vit_attacks,
-               g4=g4_autopgd, g5=g5_vit_vs_hf, g6=g6_losses, g7=g7_autoattack, g8=g8_preprocess, g9=g9_square)
+               g4=g4_autopgd, g5=g5_vit_vs_hf, g6=g6_losses, g7=g7_autoattack, g8=g8_preprocess, g9=g9_square,
+               g10=g10_autopgd_l2)
     for k in which:
         fns[k]()

@@ -238,6 +238,54 @@ def test_autoattack_fused_vs_reference_golden(tag):
     eng.close()
 
 
+def test_apgdattack_and_autoattack_l2_vs_reference_golden():
+    """``--norm l2`` of CLIP_eval/clip_robustbench.py: APGDAttack(norm='L2') (rvlm_l2_random_start + the L2 step inside
+    rvlm_apgd_run_norm) and AutoAttack(norm='L2', ['apgd-ce', 'apgd-t']) on the fp32 engine + head, fused and generic
+    routes, against what the reference produced on the same seeded model (tests/golden/autopgd_tiny_l2.npz).  The L2 path is
+    continuous (no sign()): the comparison is by distance, tolerance = fp32 encoder differences carried through 12 steps.
+    The golden's points have clean margins of 0.8 - 2.4: where the fp32 cross-entropy is saturated (margin > ~16.6, loss exactly
+    0) its gradient is rounding noise in the reference itself and no fp32 implementation reproduces another."""
+    z = load_golden("autopgd_tiny_l2.npz")
+    cfg = V.VIT_TINY
+    w = V.init_weights(cfg, seed=int(z["weights_seed"]))
+    eng = make_engine(cfg, w, "fp32")
+    clf = R.ClassificationModel(eng, torch.from_numpy(z["T"]).to(dev())).eval()
+    x, y = torch.from_numpy(z["x"]).to(dev()), torch.from_numpy(z["y"]).to(dev())
+    eps, n_iter = float(z["eps"]), int(z["n_iter"])
+    # the random start alone: same CPU generator draw as the reference, normalised on the device
+    atk = R.APGDAttack(clf, n_iter=n_iter, norm="L2", n_restarts=2, eps=eps, seed=0, loss="ce", use_rs=True)
+    torch.random.manual_seed(0)
+    todo = (clf(x).max(1)[1] == y).nonzero().squeeze(1)
+    start = atk._random_start(x[todo]).clamp(0, 1).cpu().numpy()
+    assert np.abs(start - z["first_start"]).max() < 1e-6
+
+    class Plain(torch.nn.Module):          # not a ClassificationModel: the generic route (autograd + rvlm_apgd_l2_step)
+        def forward(self, v):
+            return clf(v)
+    for name, model in (("fused", clf), ("generic", Plain().eval())):
+        atk = R.APGDAttack(model, n_iter=n_iter, norm="L2", n_restarts=2, eps=eps, seed=0, loss="ce", use_rs=True)
+        adv = atk.perturb(x.clone(), y.clone())
+        with torch.no_grad():
+            robust = (clf(adv).max(1)[1] == y).cpu().numpy()
+        assert np.array_equal(robust, z["robust"]), name
+        assert float((adv - x).flatten(1).norm(dim=1).max()) <= eps * (1 + 1e-5)
+        assert np.abs(adv.cpu().numpy() - z["adv"]).max() < 2e-5, (name, np.abs(adv.cpu().numpy() - z["adv"]).max())   # measured 2.4e-7
+    aa = R.AutoAttack(clf, norm="L2", eps=eps, seed=0, verbose=False, version="custom", attacks_to_run=["apgd-ce", "apgd-t"],
+                      device=dev(), iterations_apgd=int(z["aa_n_iter"]), use_rs=True)
+    aa.apgd.n_restarts = 1
+    aa.apgd_targeted.n_target_classes = int(z["aa_n_target_classes"])
+    ya0 = torch.from_numpy(z["aa_y"]).to(dev())
+    x_adv, y_adv = aa.run_standard_evaluation(x.clone(), ya0.clone(), bs=int(z["aa_bs"]), return_labels=True)
+    with torch.no_grad():
+        robust = (clf(x_adv).max(1)[1] == ya0).cpu().numpy()
+    assert np.array_equal(robust, z["aa_robust"])
+    assert np.array_equal(y_adv.cpu().numpy(), z["aa_y_adv"])
+    assert np.abs(x_adv.cpu().numpy() - z["aa_x_adv"]).max() < 2e-5
+    with pytest.raises(NotImplementedError):
+        R.APGDAttack(clf, norm="L1", eps=eps)
+    eng.close()
+
+
 def test_full_size_properties_vit_l14_bf16():
     """BASELINE config 2 shape (ViT-L/14, bf16, 10-step PGD, eps=4/255) at a batch the test box runs in
     seconds: size-independent properties - determinism, ||delta||_inf = float32(eps), range, loss goes

@@ -164,6 +164,41 @@ def test_autopgd_rho_bit_exact(tag):
     assert not np.array_equal(other.numpy(), z["adv"])          # the parameter matters on this input
 
 
+def test_autopgd_and_autoattack_l2_bit_exact():
+    """The L2 norm of APGDAttack / AutoAttack (``clip_robustbench.py --norm l2``; autopgd_base.py:184-185,215-218,343-351):
+    gaussian random start on the L2 sphere, the L2 step in APGDAttack's spelling, two restarts; then the two APGD stages
+    of AutoAttack(version='custom').  Against what the reference produced (tests/golden/autopgd_tiny_l2.npz, g10)."""
+    from oracle import autoattack_ref as AA
+    z = load_golden("autopgd_tiny_l2.npz")
+    cfg = V.VIT_TINY
+    w = V.init_weights(cfg, seed=int(z["weights_seed"]))
+    assert weights_digest(w) == str(z["weights_sha256"])
+    clf = V.ClassificationModelRef(cfg, w, torch.from_numpy(z["T"]), 100.0).eval()
+    seen = []
+
+    def predict(v):
+        seen.append(v.detach().clone())
+        return clf(v)
+
+    x = torch.from_numpy(z["x"])
+    atk = A.APGDAttackRef(predict, n_iter=int(z["n_iter"]), norm="L2", n_restarts=2, eps=float(z["eps"]), seed=0,
+                          loss="ce", use_rs=True)
+    adv = atk.perturb(x, torch.from_numpy(z["y"]))
+    assert np.array_equal(seen[1].numpy(), z["first_start"])
+    assert len(seen) == int(z["n_model_calls"])
+    assert np.array_equal(adv.numpy(), z["adv"])
+    assert 0 < z["robust"].sum() < len(z["robust"])                 # the radius separates the points
+    assert float((adv - x).flatten(1).norm(dim=1).max()) <= float(z["eps"]) * (1 + 1e-5)
+    seen.clear()
+    aa = AA.AutoAttackRef(predict, norm="L2", eps=float(z["eps"]), seed=0, version="custom",
+                          attacks_to_run=["apgd-ce", "apgd-t"], iterations_apgd=int(z["aa_n_iter"]), use_rs=True)
+    aa.apgd.n_restarts = 1
+    aa.apgd_targeted.n_target_classes = int(z["aa_n_target_classes"])
+    xa, ya = aa.run_standard_evaluation(x, torch.from_numpy(z["aa_y"]), bs=int(z["aa_bs"]), return_labels=True)
+    assert len(seen) == int(z["aa_n_model_calls"])
+    assert np.array_equal(xa.numpy(), z["aa_x_adv"]) and np.array_equal(ya.numpy(), z["aa_y_adv"])
+
+
 # ------------------------------------------------------------------ section 8(f) rank 3: AutoAttack orchestration
 def test_dlr_losses_bit_exact():
     z = load_golden("dlr_losses.npz")
