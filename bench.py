@@ -50,6 +50,9 @@ def parse():
                     help="pgd: BASELINE configs 2/4 (FARE); apgd: config 3 (TeCoA apgd_train); autopgd: config 5 "
                          "(APGDAttack CE on the zero-shot head, use --iterations 100 --batch 256); square: the black-box "
                          "route (SquareAttack, --iterations = queries; forward passes only)")
+    ap.add_argument("--norm", default="linf", choices=["linf", "l2"],
+                    help="threat model of pgd / apgd / autopgd (the --norm of the reference's trainer and of CLIP_eval/clip_robustbench.py); "
+                         "linf: eps = 4/255 (the headline); l2: eps = 3.0, PGD step eps/4")
     ap.add_argument("--mode", default="attack", choices=["attack", "train"],
                     help="attack (default, the BASELINE metric): one pgd()/apgd call per step; train: one full "
                          "FARE/TeCoA optimizer step per step (e0 + attack + fwd + wgrad backward + grad all-reduce + AdamW)")
@@ -439,15 +442,18 @@ def main():
     seeds = {"x": 0 + 1000 * rank, "delta0": 1 + 1000 * rank, "y": 2 + 1000 * rank}
     g = torch.Generator(device=dev).manual_seed(seeds["x"])
     x = torch.rand(B, 3, cfg.image_size, cfg.image_size, generator=g, device=dev)
-    eps, stepsize = 4 / 255, 1 / 255
-    d0 = (torch.rand(x.shape, generator=torch.Generator(device=dev).manual_seed(seeds["delta0"]), device=dev) * 2 - 1) * eps
+    eps, stepsize = (4 / 255, 1 / 255) if args.norm == "linf" else (3.0, 0.75)
+    eps_txt = "4/255" if args.norm == "linf" else "3.0 (L2)"
+    if args.norm != "linf" and args.attack == "square":
+        raise SystemExit("--attack square is L-inf only")
+    d0 = (torch.rand(x.shape, generator=torch.Generator(device=dev).manual_seed(seeds["delta0"]), device=dev) * 2 - 1) * (4 / 255)
     y = torch.randint(0, 1000, (B,), generator=torch.Generator(device=dev).manual_seed(seeds["y"]), device=dev)
     e0 = model(x, args.attack == "apgd")                        # embedding_orig (…clip.py:296-297)
     if args.attack == "pgd":
         wrap = R.ComputeLossWrapper(e0, None, "mean", "l2", 100.)
 
         def step():
-            return R.pgd(model, wrap, x, y, "linf", eps, args.iterations, stepsize, False,
+            return R.pgd(model, wrap, x, y, args.norm, eps, args.iterations, stepsize, False,
                          perturbation=d0, mode="max")
     elif args.attack == "apgd":
         T = torch.randn(cfg.out_dim, 1000, generator=g, device=dev)
@@ -455,7 +461,7 @@ def main():
         wrap = R.ComputeLossWrapper(e0, T, "none", "ce", 100.)
 
         def step():
-            return R.apgd_train(model, x, y, "linf", eps, n_iter=args.iterations, loss_fn=wrap)
+            return R.apgd_train(model, x, y, args.norm, eps, n_iter=args.iterations, loss_fn=wrap)
     elif args.attack == "square":
         T = torch.randn(cfg.out_dim, 1000, generator=g, device=dev)
         T = T / T.norm(dim=0, keepdim=True)
@@ -473,8 +479,8 @@ def main():
         clf = R.ClassificationModel(eng, T).eval()
         with torch.no_grad():
             y = clf(x).max(1)[1]           # attack the clean predictions: every sample starts "correct"
-        atk = R.APGDAttack(clf, n_iter=args.iterations, norm="Linf", n_restarts=1, eps=eps, seed=0, loss="ce",
-                           alpha=2.0, use_rs=True)
+        atk = R.APGDAttack(clf, n_iter=args.iterations, norm="Linf" if args.norm == "linf" else "L2", n_restarts=1, eps=eps, seed=0,
+                           loss="ce", alpha=2.0, use_rs=True)
 
         def step():
             return atk.perturb(x, y)
@@ -515,15 +521,18 @@ def main():
         per_rank_s = [float(v.item()) for v in allt]
         el = max(per_rank_s)                                 # the job is as slow as its slowest rank
     barrier()
-    assert float((out - x).abs().max()) <= 4 / 255 + 1e-6, "perturbation left the eps ball"
+    if args.norm == "linf":
+        assert float((out - x).abs().max()) <= 4 / 255 + 1e-6, "perturbation left the eps ball"
+    else:
+        assert float((out - x).flatten(1).norm(dim=1).max()) <= eps * (1 + 1e-5), "perturbation left the L2 eps ball"
 
     res = None
     if rank == 0:
         value = world * B * args.steps / el
         res = {
             "metric": "adversarial images/sec (ViT-L/14, 10-step PGD eps=4/255)"
-                      if (args.model == "ViT-L-14" and args.attack == "pgd" and args.iterations == 10)
-                      else f"adversarial images/sec ({args.model}, {args.iterations}-step {args.attack})",
+                      if (args.model == "ViT-L-14" and args.attack == "pgd" and args.iterations == 10 and args.norm == "linf")
+                      else f"adversarial images/sec ({args.model}, {args.iterations}-step {args.attack}{'' if args.norm == 'linf' else ', L2'})",
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
@@ -532,15 +541,16 @@ def main():
             "ms_per_step_median": 0.5 * (step_ms[(len(step_ms) - 1) // 2] + step_ms[len(step_ms) // 2]),
             "ms_per_step_min": step_ms[0], "ms_per_step_max": step_ms[-1],
             "value_median_call": B * 1e3 / (0.5 * (step_ms[(len(step_ms) - 1) // 2] + step_ms[len(step_ms) // 2])) * world,
-            "config": {"workload": (f"{'FARE' if args.attack == 'pgd' else 'TeCoA-CE'} {args.attack.upper()} {args.iterations}-step eps=4/255 on {args.model} "
+            "config": {"workload": (f"{'FARE' if args.attack == 'pgd' else 'TeCoA-CE'} {args.attack.upper()} {args.iterations}-step eps={eps_txt} on {args.model} "
                                     f"{args.precision}, batch={B} per GPU, 224x224x3 synthetic, seeded random-init weights "
-                                    f"({_baseline_config_name(args.attack, world, B)})")
+                                    f"({_baseline_config_name(args.attack, world, B) if args.norm == 'linf' else 'the L2 threat model of the same entry points; no BASELINE config'})")
                                    if args.attack != "square" else
                                    (f"black-box SquareAttack, {args.iterations} queries, eps=4/255 on {args.model} {args.precision} + "
                                     f"1000-class zero-shot head, batch={B} per GPU (clip_robustbench.py --blackbox_only route; "
                                     f"forward passes only, samples leave the batch once fooled)"),
                        "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world} (no data-path collective)",
                        "loss": "l2/mean" if args.attack == "pgd" else "margin" if args.attack == "square" else "ce/none",
+                       "norm": args.norm,
                        "input_seeds": {**seeds, "generator": "torch device generator, rank 0 (rank r: + 1000 r)"}},
             # pgd: I x (fwd+bwd); apgd_train: (I+1) fwd + I bwd; APGDAttack: (I+2) fwd + (I+1) bwd  ~ I+1 pairs;
             # square: at most I + 3 forwards (0.49 of a pair each; fewer once samples are fooled)
@@ -601,7 +611,8 @@ def main():
         # HBM-side traffic comes from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE cannot be
         # read from inside this process); the committed measurement of this same command is reported.
         traffic, traffic_src, pmc = None, None, None
-        headline = args.model == "ViT-L-14" and args.batch == 128 and args.precision == "bf16" and args.attack == "pgd"
+        headline = (args.model == "ViT-L-14" and args.batch == 128 and args.precision == "bf16" and args.attack == "pgd"
+                    and args.norm == "linf")
         pmc_error = None
         if headline and world == 1 and not args.no_pmc and not os.environ.get("RVLM_BENCH_CHILD"):
             try:

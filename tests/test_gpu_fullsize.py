@@ -245,6 +245,62 @@ def test_config5_apgd_ce_100_b256(setup):
     assert same_acc
 
 
+def test_l2_threat_model_at_full_size(setup):
+    """The L2 entry points (pgd / apgd_train / APGDAttack with norm = l2: the --norm l2 of the reference's trainer and of
+    clip_robustbench.py) on ViT-L/14 bf16 at B = 32: size-independent properties - the L2 ball, the image range, determinism,
+    loss up / accuracy not up, and the per-sample property the data-parallel path relies on (a batch run as two halves
+    lands on the same points up to the encoder's batch-shape dependence)."""
+    s = setup
+    B, eps = 32, 3.0          # (a usual ImageNet L2 radius; the L-inf ball of 4/255 reaches |delta|_2 = 6.1 on 224 x 224 x 3)
+    x, d0 = s["x"][:B].to(dev()), s["d0"][:B].to(dev())
+    y, T = s["y"][:B].to(dev()), s["T"].to(dev())
+    model = R.ClipVisionModel(s["eng"]).eval()
+
+    def in_ball(xa):
+        assert float((xa - x).flatten(1).norm(dim=1).max()) <= eps * (1 + 1e-5)
+        assert float(xa.min()) >= 0.0 and float(xa.max()) <= 1.0
+    with torch.no_grad():
+        e0 = model(x, False)
+    wrap = R.ComputeLossWrapper(e0, None, "mean", "l2", 100.)
+    run = lambda lo, hi, w: R.pgd(model, w, x[lo:hi], None, "l2", eps, 10, eps / 4, False, perturbation=d0[lo:hi], mode="max")   # noqa: E731
+    xa = run(0, B, wrap)
+    in_ball(xa)
+    assert torch.equal(xa, run(0, B, wrap))
+    with torch.no_grad():
+        l_start = ((model(x + d0, False) - e0) ** 2).sum(1)
+        l_end = ((model(xa, False) - e0) ** 2).sum(1)
+    assert bool((l_end > l_start).all())
+    halves = torch.cat([run(0, B // 2, R.ComputeLossWrapper(e0[:B // 2], None, "mean", "l2", 100.)),
+                        run(B // 2, B, R.ComputeLossWrapper(e0[B // 2:], None, "mean", "l2", 100.))])
+    # images whose token rows sit in full 256-row GEMM tiles in both runs come out bit-identical; the one or two whose rows fall into
+    # the remainder-row phase (a different K split) start from a different bf16 rounding of FARE's noise-limited first gradient
+    rel_each = (halves - xa).flatten(1).norm(dim=1) / eps
+    rel_pgd, same_pgd = float(rel_each.max()), float((rel_each < 1e-3).float().mean())
+    # TeCoA apgd_train(norm='l2')
+    wce = R.ComputeLossWrapper(None, T, "none", "ce", 100.)
+    xt = R.apgd_train(model, x, y, "l2", eps, n_iter=10, loss_fn=wce)
+    in_ball(xt)
+    assert torch.equal(xt, R.apgd_train(model, x, y, "l2", eps, n_iter=10, loss_fn=wce))
+    with torch.no_grad():
+        assert float(wce(model(xt, True), y).mean()) > float(wce(model(x, True), y).mean())
+    # APGDAttack(norm='L2') on the zero-shot head, labels = the clean predictions
+    clf = R.ClassificationModel(s["eng"], T).eval()
+    with torch.no_grad():
+        yc = clf(x).argmax(1)
+    kw = dict(n_iter=20, norm="L2", n_restarts=1, eps=eps, seed=0, loss="ce", device=dev())
+    xe = R.APGDAttack(clf, **kw).perturb(x, yc)
+    in_ball(xe)
+    assert torch.equal(xe, R.APGDAttack(clf, **kw).perturb(x, yc))
+    with torch.no_grad():
+        acc_adv = float((clf(xe).argmax(1) == yc).float().mean())
+        assert bool((R.ce(clf(xe), yc, "none") >= R.ce(clf(x), yc, "none") - 1e-3).all())
+    record("l2_threat_model_b32", pgd_halves_vs_whole_rel_l2_max=rel_pgd, pgd_halves_vs_whole_images_equal=same_pgd,
+           apgdattack_l2_acc_adv=acc_adv,
+           pgd_loss_end_over_start=float(l_end.mean() / l_start.mean()))
+    assert same_pgd >= 0.8 and rel_pgd < 1.0, (same_pgd, rel_pgd)
+    assert acc_adv < 1.0
+
+
 def _oracle_pgd_trajectory(ref, xc, dc, e0c, iterations=10):
     """oracle pgd_ref on a slice with its per-iteration gradients, and the iterates delta_0 .. delta_{I-1} it evaluated
     them at (replayed from the traced gradients with the oracle's own update)."""
