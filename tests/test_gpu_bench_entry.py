@@ -123,3 +123,12 @@ def test_mixed_precision_line():
     d = _one_line(run("--gpus", "1", "--steps", "1", "--warmup", "1", "--model", "ViT-B-32", "--batch", "8", "--precision",
                       "bf16+fp32-first", "--no-cpu-baseline"))
     assert d["dtype"] == "bf16+fp32-first" and d["value"] > 0 and d["roofline"]["peak"] == 2500.0
+
+
+@pytest.mark.parametrize("attack", ["pgd", "apgd", "autopgd"])
+def test_l2_norm_lines(attack):
+    """--norm l2: the three entry points under the L2 threat model; the line names it and is not labelled as a BASELINE config."""
+    d = _one_line(run("--gpus", "1", "--steps", "1", "--warmup", "1", "--model", "ViT-B-32", "--batch", "8", "--attack", attack,
+                      "--norm", "l2", "--no-cpu-baseline"))
+    assert d["config"]["norm"] == "l2" and "L2" in d["metric"] and "BASELINE configs" not in d["config"]["workload"]
+    assert d["value"] > 0
