@@ -29,30 +29,34 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+from benchlib import ClockSampler, bind_rank_to_numa, hbm_classes, host_cpu_info, pmc_in_run  # noqa: E402  (untimed measurement helpers)
 
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_F32_MFMA_TFLOPS = 157.3   # fp32-input MFMA (= the fp32 vector peak), same guide: --precision fp32 runs are priced against it
 FLOP_PER_IMG_ITER = {"ViT-L-14": 330.545e9, "ViT-B-32": 17.728e9}   # SURVEY.md Appendix C (fwd + input-bwd)
 
 
-def parse():
+HEADLINE_MODELS = ("ViT-L-14", "ViT-B-32")      # the models BASELINE.json's configs name (B/32: configs[0] through the HIP path)
+
+
+def parse(extra=None):
+    """Options of the headline harness: BASELINE configs 2/4 (pgd), 3 (apgd), 5 (autopgd) and the training step.  Everything no
+    BASELINE config asks for (the L2 threat model, SquareAttack, other models) is added by scripts/bench_extra.py through
+    `extra` - this file alone cannot run them."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--model", default="ViT-L-14")
+    ap.add_argument("--model", default="ViT-L-14", choices=list(HEADLINE_MODELS) + list(getattr(extra, "MODELS", ())))
     ap.add_argument("--batch", type=int, default=128, help="images per GPU per step")
     ap.add_argument("--iterations", type=int, default=10)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16+fp32-first"],
                     help="bf16: the throughput path (headline); fp32: the reference's own precision on the fp32 matrix-pipe tiles; "
                          "bf16+fp32-first: pgd with its first iteration (and the clean embedding) in fp32")
-    ap.add_argument("--attack", default="pgd", choices=["pgd", "apgd", "autopgd", "square"],
+    ap.add_argument("--attack", default="pgd", choices=["pgd", "apgd", "autopgd"] + list(getattr(extra, "ATTACKS", ())),
                     help="pgd: BASELINE configs 2/4 (FARE); apgd: config 3 (TeCoA apgd_train); autopgd: config 5 "
-                         "(APGDAttack CE on the zero-shot head, use --iterations 100 --batch 256); square: the black-box "
-                         "route (SquareAttack, --iterations = queries; forward passes only)")
-    ap.add_argument("--norm", default="linf", choices=["linf", "l2"],
-                    help="threat model of pgd / apgd / autopgd (the --norm of the reference's trainer and of CLIP_eval/clip_robustbench.py); "
-                         "linf: eps = 4/255 (the headline); l2: eps = 3.0, PGD step eps/4")
+                         "(APGDAttack CE on the zero-shot head, use --iterations 100 --batch 256)")
     ap.add_argument("--mode", default="attack", choices=["attack", "train"],
                     help="attack (default, the BASELINE metric): one pgd()/apgd call per step; train: one full "
                          "FARE/TeCoA optimizer step per step (e0 + attack + fwd + wgrad backward + grad all-reduce + AdamW)")
@@ -64,28 +68,12 @@ def parse():
     ap.add_argument("--no-pmc", action="store_true",
                     help="skip the in-run rocprofv3 --pmc passes (fabric traffic, matrix-pipe busy): roofline.traffic / "
                          "pmc_in_pipeline then come from the committed profiles/ files, flagged measured_in_run: false")
-    return ap.parse_args()
-
-
-def host_cpu_info():
-    """(model string, physical cores, hardware threads) of this host from /proc/cpuinfo."""
-    model, cores = "unknown", set()
-    try:
-        phys = core = None
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name") and model == "unknown":
-                model = line.split(":", 1)[1].strip()
-            elif line.startswith("physical id"):
-                phys = line.split(":", 1)[1].strip()
-            elif line.startswith("core id"):
-                core = line.split(":", 1)[1].strip()
-            elif not line.strip():
-                if phys is not None and core is not None:
-                    cores.add((phys, core))
-                phys = core = None
-    except OSError:
-        pass
-    return model, (len(cores) or (os.cpu_count() or 1)), os.cpu_count() or 1
+    if extra is not None:
+        extra.add_arguments(ap)
+    args = ap.parse_args()
+    if not hasattr(args, "norm"):
+        args.norm = "linf"
+    return args
 
 
 def cpu_baseline(iterations_full=10, l14_sample=True):
@@ -155,110 +143,14 @@ def cpu_baseline(iterations_full=10, l14_sample=True):
 
 REHEARSAL_NOTE = ("RVLM_BENCH_REHEARSAL=gloo: the ranks of this job share GPU(s) and meet over gloo - the line proves the "
                   "world > 1 code path (self-launch, process group, barriers, gather of per-rank times), it is NOT a measurement")
-PEAK_HBM_TBPS = 8.0         # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md (6.3 TB/s achievable)
-
-
-def hbm_classes(prof: dict, cfg, B: int, traffic: dict | None = None) -> dict:
-    """Roofline objects of the HBM-bound kernel classes of one profiled pgd() call; `traffic` (bytes per launch, fabric side:
-    2 x FETCH_SIZE + WRITE_SIZE of the in-run PMC passes) when it was measured, else null."""
-    S = (cfg.image_size // cfg.patch) ** 2 + 1
-    per_launch = {"attn_fwd": 4.0 * B * cfg.heads * S * 64 * 2, "attn_bwd": 8.0 * B * cfg.heads * S * 64 * 2}
-    out = {}
-    for k in ("attn_fwd", "attn_bwd", "layernorm_fwd", "layernorm_bwd"):
-        v = prof.get(k)
-        if not v or v["ms"] <= 0 or not v["launches"]:
-            continue
-        nbytes = per_launch[k] * v["launches"] if k in per_launch else v["bytes"]
-        tbps = nbytes / (v["ms"] * 1e-3) / 1e12
-        out[k] = {"bound": "hbm", "achieved": tbps, "peak": PEAK_HBM_TBPS, "unit": "TB/s", "frac": tbps / PEAK_HBM_TBPS,
-                  "bytes_per_launch": nbytes / v["launches"], "avg_launch_us": 1e3 * v["ms"] / v["launches"],
-                  "launches": v["launches"], "ms_per_step": round(v["ms"], 3),
-                  "traffic": (traffic or {}).get(k)}
-    return out
-
-
-def pmc_in_run(argv_child, timeout_s=240):
-    """`roofline.traffic` and the in-pipeline matrix-pipe figures measured IN THIS RUN, on this box and build: PMC counters cannot
-    be read from inside the process, so rank 0 runs this same script under `rocprofv3 --pmc` as a child (one counter group per
-    pass, --kernel-trace only - no sys/hip/hsa trace domains next to --pmc; the child times one pgd() call + the e0 forward,
-    --no-roofline --no-cpu-baseline --no-pmc) while the parent's stream is idle, and sums the counters per kernel like
-    scripts/pmc_traffic.sh / pmc_pipeline.sh.  FETCH_SIZE is DOUBLED (MI355X_MICROARCH.md, HBM section: gfx950 reports half the
-    bytes of wide coalesced reads), both counters are KiB.  Returns (traffic_bytes_per_gemm_launch, info, pmc) or raises."""
-    import collections
-    import csv
-    import glob
-    import re
-    import shutil
-    import subprocess
-    import tempfile
-    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
-    if not os.path.exists(exe):
-        raise RuntimeError("rocprofv3 not found")
-    passes = [("FETCH_SIZE",), ("WRITE_SIZE",),
-              ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE")]
-    agg = collections.defaultdict(lambda: collections.defaultdict(float))
-    launches = collections.Counter()
-    t_begin = time.time()
-    root = tempfile.mkdtemp(prefix="rvlm_pmc_", dir="/tmp")
-    try:
-        for i, ctrs in enumerate(passes):
-            out = os.path.join(root, f"p{i}")
-            os.makedirs(out)
-            env = dict(os.environ, TMPDIR="/tmp", RVLM_BENCH_CHILD="1")
-            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_PORT", "RVLM_SELF_LAUNCHED"):
-                env.pop(k, None)
-            cmd = [exe, "--pmc", *ctrs, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "pmc", "--",
-                   sys.executable, os.path.join(ROOT, "bench.py"), *argv_child]
-            left = timeout_s - (time.time() - t_begin)
-            if left < 20:
-                raise RuntimeError("time budget of the PMC passes exhausted")
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=left)
-            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
-            if r.returncode != 0 or not files:
-                raise RuntimeError(f"rocprofv3 pass {ctrs[0]} failed (rc {r.returncode}): {(r.stderr or r.stdout)[-300:]}")
-            for f in files:
-                for row in csv.DictReader(open(f)):
-                    k = re.sub(r"^rvlm::", "", re.sub(r"\(.*", "", row["Kernel_Name"]).replace("void ", "").strip())
-                    agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
-                    if row["Counter_Name"] == "FETCH_SIZE":
-                        launches[k] += 1
-    finally:
-        shutil.rmtree(root, ignore_errors=True)
-    gemm = {k: v for k, v in agg.items() if "gemm_bf16" in k or "splitk_reduce" in k}
-    logical = sum(launches[k] for k in gemm if "256p" in k)
-    if not logical:
-        raise RuntimeError("no persistent-GEMM launches in the counter files")
-    total = sum((2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024.0 for v in gemm.values())
-    info = {"measured_in_run": True, "seconds": round(time.time() - t_begin, 1), "gemm_logical_launches": logical,
-            "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over a child run of this script (one pgd() call + the e0 forward) on "
-                   "this box; bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB summed over every bf16 GEMM kernel / persistent-kernel "
-                   "launches; fabric side: Infinity-Cache hits included (profiles/r04_pmc_l2.json separates them by read latency)"}
-    tot_active = sum(v.get("GRBM_GUI_ACTIVE", 0.0) for v in agg.values()) or 1.0
-    pmc = {"measured_in_run": True, "source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT "
-                                              "SQ_LDS_IDX_ACTIVE pass over the same child run",
-           "mfma_busy": {}, "lds_conflict_share": {}}
-    for k, v in sorted(agg.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0.0)):
-        if v.get("GRBM_GUI_ACTIVE", 0.0) < 0.004 * tot_active:
-            continue
-        if "SQ_VALU_MFMA_BUSY_CYCLES" in v:
-            pmc["mfma_busy"][k] = round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (v["GRBM_GUI_ACTIVE"] / 8.0), 4)
-        if v.get("SQ_LDS_IDX_ACTIVE"):
-            pmc["lds_conflict_share"][k] = round(v.get("SQ_LDS_BANK_CONFLICT", 0.0) / v["SQ_LDS_IDX_ACTIVE"], 4)
-    # fabric-side bytes per launch of the HBM-bound classes, from the same two passes (for roofline.hbm_classes[*].traffic)
-    cls = {"attn_fwd": "attn_fwd_odd_kernel", "attn_bwd": "attn_bwd_fused_kernel", "layernorm_fwd": "layernorm_fwd8_kernel",
-           "layernorm_bwd": "layernorm_bwd8_kernel"}
-    pmc["hbm_class_traffic"] = {}
-    for name, pat in cls.items():
-        ks = [k for k in agg if pat in k and launches[k]]
-        if ks:
-            n = sum(launches[k] for k in ks)
-            pmc["hbm_class_traffic"][name] = round(sum((2.0 * agg[k].get("FETCH_SIZE", 0.0) + agg[k].get("WRITE_SIZE", 0.0)) * 1024.0 for k in ks) / n)
-    return round(total / logical), info, pmc
-
-
-def _baseline_config_name(attack: str, world: int, per_gpu_batch: int) -> str:
+def _baseline_config_name(attack: str, world: int, per_gpu_batch: int, model: str = "ViT-L-14") -> str:
     """Which BASELINE.json `configs` entry a run is: [1] one GPU, [3] = the same 128 images per GPU on 8 GPUs
     (global batch 1024); 2 / 4 GPUs are the intermediate points of the 1/2/4/8 curve of that same per-GPU workload."""
+    if model == "ViT-B-32":
+        return ("BASELINE configs[0]'s problem through the HIP path" if attack == "pgd" and per_gpu_batch == 8 and world == 1
+                else "ViT-B/32: the model of BASELINE configs[0], not its batch / attack")
+    if model != "ViT-L-14":
+        return "no BASELINE config names this model"
     if attack == "apgd":
         return "BASELINE configs[2]" + ("" if world == 1 else f" per GPU x {world}")
     if attack != "pgd":
@@ -315,85 +207,30 @@ def bench_train(args, R, cfg, sd, dev, dist, world, rank, coll_dev=None, rehears
         dist.destroy_process_group()
 
 
-class ClockSampler:
-    """Shader clock / socket power of one GPU while the timed region runs: `rocm-smi --showclocks --showpower` polled from
-    a thread (~10 Hz; each call costs the HOST ~60 ms, nothing on the GPU) - run over extra, untimed calls of the workload.  The 2.5 PFLOP/s peak assumes 2.4 GHz; under the
-    ~1.4 kW socket cap a dense MFMA loop holds 1.7-1.9 GHz, so `roofline.frac` is also reported against
-    the peak at the clock the chip actually held."""
-
-    def __init__(self, device_index: int):
-        import threading
-        self.dev, self.samples, self.stop, self.thread = device_index, [], False, None
-        self._threading = threading
-
-    def _run(self):
-        import re
-        import subprocess
-        while not self.stop:
-            try:
-                o = subprocess.run(["rocm-smi", "-d", str(self.dev), "--showpower", "--showclocks"], capture_output=True,
-                                   text=True, timeout=5).stdout
-                p = re.search(r"Power \(W\):\s*([\d.]+)", o)
-                c = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", o)
-                if c:
-                    self.samples.append((float(p.group(1)) if p else -1.0, int(c.group(1))))
-            except Exception:
-                pass
-            time.sleep(0.03)
-
-    def __enter__(self):
-        self.thread = self._threading.Thread(target=self._run, daemon=True)
-        self.thread.start()
-        return self
-
-    def __exit__(self, *a):
-        self.stop = True
-        self.thread.join(timeout=10)
-
-    def summary(self):
-        cs = [c for _, c in self.samples if c > 0]
-        ps = [p for p, _ in self.samples if p > 0]
-        if not cs:
-            return None
-        return {"sclk_mhz_mean": sum(cs) / len(cs), "sclk_mhz_min": min(cs), "sclk_mhz_max": max(cs), "samples": len(cs),
-                "socket_power_w_mean": (sum(ps) / len(ps)) if ps else None,
-                "source": "rocm-smi --showclocks --showpower polled during up to 3 extra pgd() calls AFTER the timed region "
-                          "(the timed region itself runs without a poller)"}
-
-
-def bind_rank_to_numa(local_rank: int, local_world: int):
-    """One process per GPU on a 2-socket host: keep each rank's host threads (launch loop, RCCL proxy) on the cores of
-    its GPU's NUMA node - sysfs numa_node of the GPU's PCI function when readable, else an even split of the cores.
-    Returns a description for the JSON line."""
-    if local_world <= 1:
-        return None
+def in_kernel_clock(step, dev):
+    """Effective shader clock INSIDE the GEMM launches of one more step: the persistent kernel's trace hook makes wave 0 of every
+    workgroup stamp s_memtime (shader clock) and s_memrealtime (constant 100 MHz) at its start and end."""
     try:
-        node = -1
-        p = torch.cuda.get_device_properties(local_rank)
-        bdf = f"{getattr(p, 'pci_domain_id', 0):04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
-        path = f"/sys/bus/pci/devices/{bdf}/numa_node"
-        if os.path.exists(path):
-            node = int(open(path).read().strip())
-        cpus = None
-        if node >= 0 and os.path.exists(f"/sys/devices/system/node/node{node}/cpulist"):
-            cpus = set()
-            for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
-                a, _, b = part.partition("-")
-                cpus.update(range(int(a), int(b or a) + 1))
-            how = f"numa node {node} of {bdf}"
-        if not cpus:
-            n = os.cpu_count() or 1
-            per = max(n // local_world, 1)
-            cpus = set(range(local_rank * per, min(n, (local_rank + 1) * per)))
-            how = f"even split ({per} cpus per rank)"
-        os.sched_setaffinity(0, cpus)
-        return f"{len(cpus)} cpus, {how}"
-    except Exception as e:                      # affinity is a performance hint only
-        return f"unbound ({type(e).__name__})"
+        from robustvlm_amd import _lib as L
+        tr = torch.zeros(256 * 8 * 4, dtype=torch.int64, device=dev)
+        L.load().rvlm_k_gemm_set_trace(tr.data_ptr())
+        step()
+        torch.cuda.synchronize()
+        L.load().rvlm_k_gemm_set_trace(None)
+        t = tr.view(256, 8, 4)[:, 7, :].double()          # [wg][memtime0, realtime0, memtime1, realtime1] of the LAST launch
+        ok = (t[:, 3] > t[:, 1]) & (t[:, 2] > t[:, 0])
+        if bool(ok.any()):
+            mhz = ((t[ok, 2] - t[ok, 0]) / (t[ok, 3] - t[ok, 1]) * 100.0)
+            return {"sclk_mhz_effective": float(mhz.mean()), "workgroups": int(ok.sum()),
+                    "source": "s_memtime / s_memrealtime stamps of the last persistent-GEMM launch of a pgd() call "
+                              "(rvlm_k_gemm_set_trace)"}
+        return None
+    except Exception as e:                     # measurement aid only
+        return {"error": f"{type(e).__name__}: {e}"}
 
 
-def main():
-    args = parse()
+def main(extra=None):
+    args = parse(extra)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
     # `python bench.py --gpus N` without a launcher creates its N ranks itself (and exits with their exit code);
@@ -442,48 +279,44 @@ def main():
     seeds = {"x": 0 + 1000 * rank, "delta0": 1 + 1000 * rank, "y": 2 + 1000 * rank}
     g = torch.Generator(device=dev).manual_seed(seeds["x"])
     x = torch.rand(B, 3, cfg.image_size, cfg.image_size, generator=g, device=dev)
-    eps, stepsize = (4 / 255, 1 / 255) if args.norm == "linf" else (3.0, 0.75)
-    eps_txt = "4/255" if args.norm == "linf" else "3.0 (L2)"
-    if args.norm != "linf" and args.attack == "square":
-        raise SystemExit("--attack square is L-inf only")
+    eps, stepsize, eps_txt = 4 / 255, 1 / 255, "4/255"
     d0 = (torch.rand(x.shape, generator=torch.Generator(device=dev).manual_seed(seeds["delta0"]), device=dev) * 2 - 1) * (4 / 255)
     y = torch.randint(0, 1000, (B,), generator=torch.Generator(device=dev).manual_seed(seeds["y"]), device=dev)
     e0 = model(x, args.attack == "apgd")                        # embedding_orig (…clip.py:296-297)
-    if args.attack == "pgd":
+    # pairs of (forward + input backward) one step runs, for whole_loop_tflops: pgd I; apgd_train (I+1) fwd + I bwd;
+    # APGDAttack (I+2) fwd + (I+1) bwd ~ I + 1.5
+    pairs = {"pgd": args.iterations, "apgd": args.iterations + 0.5, "autopgd": args.iterations + 1.5}.get(args.attack)
+    workload, loss_name = None, "l2/mean" if args.attack == "pgd" else "ce/none"
+    in_ball = lambda out: float((out - x).abs().max()) <= 4 / 255 + 1e-6        # noqa: E731
+    if extra is not None and extra.handles(args):
+        # a workload no BASELINE config names (scripts/bench_extra.py): same harness, its own step / labels
+        step, workload, loss_name, pairs, in_ball = extra.make_step(args, R, eng, model, cfg, x, y, d0, e0, g, dev)
+    elif args.attack == "pgd":
         wrap = R.ComputeLossWrapper(e0, None, "mean", "l2", 100.)
 
         def step():
-            return R.pgd(model, wrap, x, y, args.norm, eps, args.iterations, stepsize, False,
-                         perturbation=d0, mode="max")
+            return R.pgd(model, wrap, x, y, "linf", eps, args.iterations, stepsize, False, perturbation=d0, mode="max")
     elif args.attack == "apgd":
         T = torch.randn(cfg.out_dim, 1000, generator=g, device=dev)
         T = T / T.norm(dim=0, keepdim=True)
         wrap = R.ComputeLossWrapper(e0, T, "none", "ce", 100.)
 
         def step():
-            return R.apgd_train(model, x, y, args.norm, eps, n_iter=args.iterations, loss_fn=wrap)
-    elif args.attack == "square":
-        T = torch.randn(cfg.out_dim, 1000, generator=g, device=dev)
-        T = T / T.norm(dim=0, keepdim=True)
-        clf = R.ClassificationModel(eng, T).eval()
-        with torch.no_grad():
-            y = clf(x).max(1)[1]
-        atk = R.SquareAttack(clf, norm="Linf", n_queries=args.iterations, eps=eps, p_init=.8, n_restarts=1, seed=0,
-                             resc_schedule=False)
-
-        def step():
-            return atk.perturb(x, y)
+            return R.apgd_train(model, x, y, "linf", eps, n_iter=args.iterations, loss_fn=wrap)
     else:
         T = torch.randn(cfg.out_dim, 1000, generator=g, device=dev)
         T = T / T.norm(dim=0, keepdim=True)
         clf = R.ClassificationModel(eng, T).eval()
         with torch.no_grad():
             y = clf(x).max(1)[1]           # attack the clean predictions: every sample starts "correct"
-        atk = R.APGDAttack(clf, n_iter=args.iterations, norm="Linf" if args.norm == "linf" else "L2", n_restarts=1, eps=eps, seed=0,
-                           loss="ce", alpha=2.0, use_rs=True)
+        atk = R.APGDAttack(clf, n_iter=args.iterations, norm="Linf", n_restarts=1, eps=eps, seed=0, loss="ce", alpha=2.0, use_rs=True)
 
         def step():
             return atk.perturb(x, y)
+    if workload is None:
+        workload = (f"{'FARE' if args.attack == 'pgd' else 'TeCoA-CE'} {args.attack.upper()} {args.iterations}-step eps={eps_txt} on "
+                    f"{args.model} {args.precision}, batch={B} per GPU, 224x224x3 synthetic, seeded random-init weights "
+                    f"({_baseline_config_name(args.attack, world, B, args.model)})")
 
     def barrier():
         if dist is not None:
@@ -507,24 +340,31 @@ def main():
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
-    sampler = None
-    if rank == 0 and not args.no_roofline:
-        with ClockSampler(local_rank) as sampler:
+    # Every rank then looks at its OWN GPU (untimed extra calls, all ranks at once so that the node is loaded as in the timed
+    # region): rocm-smi clock / socket power of its device and the shader clock its GEMM launches actually got.  The boxes of this
+    # pool hold 1.74-1.92 GHz under the power cap; a 1 -> 8 curve has to show whether a slow rank is a slow GPU.
+    sampler, my_clock = None, None
+    if not args.no_roofline:
+        with ClockSampler(dev_index) as sampler:
             for _ in range(min(args.steps, 3)):
                 step()
             torch.cuda.synchronize()
-    per_rank_s = [el]
+        my_clock = in_kernel_clock(step, dev)
+    smi = sampler.summary() if sampler is not None else None
+    mine = {"rank": rank, "device": dev_index, "seconds": el, "images_per_sec": B * args.steps / el,
+            "sclk_in_kernel_mhz": (my_clock or {}).get("sclk_mhz_effective"),
+            "sclk_smi_mhz_mean": (smi or {}).get("sclk_mhz_mean"), "socket_power_w_mean": (smi or {}).get("socket_power_w_mean"),
+            "cpu_affinity": affinity}
+    per_rank = [mine]
     if dist is not None:
-        t = torch.tensor([el], device=coll_dev, dtype=torch.float64)
-        allt = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(allt, t)
-        per_rank_s = [float(v.item()) for v in allt]
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+        per_rank_s = [r["seconds"] for r in per_rank]
         el = max(per_rank_s)                                 # the job is as slow as its slowest rank
-    barrier()
-    if args.norm == "linf":
-        assert float((out - x).abs().max()) <= 4 / 255 + 1e-6, "perturbation left the eps ball"
     else:
-        assert float((out - x).flatten(1).norm(dim=1).max()) <= eps * (1 + 1e-5), "perturbation left the L2 eps ball"
+        per_rank_s = [el]
+    barrier()
+    assert in_ball(out), "perturbation left the eps ball"
 
     res = None
     if rank == 0:
@@ -541,23 +381,11 @@ def main():
             "ms_per_step_median": 0.5 * (step_ms[(len(step_ms) - 1) // 2] + step_ms[len(step_ms) // 2]),
             "ms_per_step_min": step_ms[0], "ms_per_step_max": step_ms[-1],
             "value_median_call": B * 1e3 / (0.5 * (step_ms[(len(step_ms) - 1) // 2] + step_ms[len(step_ms) // 2])) * world,
-            "config": {"workload": (f"{'FARE' if args.attack == 'pgd' else 'TeCoA-CE'} {args.attack.upper()} {args.iterations}-step eps={eps_txt} on {args.model} "
-                                    f"{args.precision}, batch={B} per GPU, 224x224x3 synthetic, seeded random-init weights "
-                                    f"({_baseline_config_name(args.attack, world, B) if args.norm == 'linf' else 'the L2 threat model of the same entry points; no BASELINE config'})")
-                                   if args.attack != "square" else
-                                   (f"black-box SquareAttack, {args.iterations} queries, eps=4/255 on {args.model} {args.precision} + "
-                                    f"1000-class zero-shot head, batch={B} per GPU (clip_robustbench.py --blackbox_only route; "
-                                    f"forward passes only, samples leave the batch once fooled)"),
+            "config": {"workload": workload,
                        "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world} (no data-path collective)",
-                       "loss": "l2/mean" if args.attack == "pgd" else "margin" if args.attack == "square" else "ce/none",
-                       "norm": args.norm,
+                       "loss": loss_name, "norm": args.norm,
                        "input_seeds": {**seeds, "generator": "torch device generator, rank 0 (rank r: + 1000 r)"}},
-            # pgd: I x (fwd+bwd); apgd_train: (I+1) fwd + I bwd; APGDAttack: (I+2) fwd + (I+1) bwd  ~ I+1 pairs;
-            # square: at most I + 3 forwards (0.49 of a pair each; fewer once samples are fooled)
-            "whole_loop_tflops_per_gpu": value / world * FLOP_PER_IMG_ITER.get(args.model, 0) *
-                                         (args.iterations if args.attack == "pgd" else args.iterations + 0.5 if
-                                          args.attack == "apgd" else 0.49 * (args.iterations + 3) if
-                                          args.attack == "square" else args.iterations + 1.5) / 1e12,
+            "whole_loop_tflops_per_gpu": value / world * FLOP_PER_IMG_ITER.get(args.model, 0) * pairs / 1e12,
         }
         if rehearsal:
             res["rehearsal"] = REHEARSAL_NOTE
@@ -569,7 +397,12 @@ def main():
                                     else "external torch.distributed.run",
                         "per_rank_images_per_sec_min": min(B * args.steps / t for t in per_rank_s),
                         "per_rank_images_per_sec_max": max(B * args.steps / t for t in per_rank_s),
-                        "cpu_affinity_rank0": affinity}
+                        # `value` is the contract's number: all images / the SLOWEST rank's time.  The sum of the ranks' own rates
+                        # is what the GPUs delivered; the gap between the two is rank imbalance (clock / power per rank below),
+                        # not communication - the attack has no data-path collective
+                        "images_per_sec_sum_of_rank_rates": sum(B * args.steps / t for t in per_rank_s),
+                        "cpu_affinity_rank0": affinity,
+                        "per_rank": per_rank}
         res["whole_loop_frac_of_peak"] = res["whole_loop_tflops_per_gpu"] / (PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_TFLOPS)
         res["whole_loop_flop_basis"] = ("reference model FLOPs per image (SURVEY.md Appendix C); the engine's class-token "
                                         "tail skips the dead rows of the last block (~3 % of them) - roofline.achieved "
@@ -582,25 +415,7 @@ def main():
         step()
         prof = eng.get_profile()
         eng.set_profiling(False)
-        # effective shader clock INSIDE the GEMM launches of one more step: the persistent kernel's trace hook makes wave 0
-        # of every workgroup stamp s_memtime (shader clock) and s_memrealtime (constant 100 MHz) at its start and end
-        eff_clock = None
-        try:
-            from robustvlm_amd import _lib as L
-            tr = torch.zeros(256 * 8 * 4, dtype=torch.int64, device=dev)
-            L.load().rvlm_k_gemm_set_trace(tr.data_ptr())
-            step()
-            torch.cuda.synchronize()
-            L.load().rvlm_k_gemm_set_trace(None)
-            t = tr.view(256, 8, 4)[:, 7, :].double()          # [wg][memtime0, realtime0, memtime1, realtime1] of the LAST launch
-            ok = (t[:, 3] > t[:, 1]) & (t[:, 2] > t[:, 0])
-            if bool(ok.any()):
-                mhz = ((t[ok, 2] - t[ok, 0]) / (t[ok, 3] - t[ok, 1]) * 100.0)
-                eff_clock = {"sclk_mhz_effective": float(mhz.mean()), "workgroups": int(ok.sum()),
-                             "source": "s_memtime / s_memrealtime stamps of the last persistent-GEMM launch of a pgd() call "
-                                       "(rvlm_k_gemm_set_trace)"}
-        except Exception as e:                     # measurement aid only
-            eff_clock = {"error": f"{type(e).__name__}: {e}"}
+        eff_clock = my_clock
         gemm = {k: v for k, v in prof.items() if k.startswith("gemm_") and "patch" not in k}
         gflops = sum(v["flops"] for v in gemm.values())
         gms = sum(v["ms"] for v in gemm.values())
@@ -672,15 +487,16 @@ def main():
             # (attention: q, k, v in + o out forward; q, k, v, o, dO in + dq, dk, dv out backward, bf16; LayerNorm: the
             # byte counts the engine's profile scopes carry - 6 B per element forward, 16 B backward)
             "hbm_classes": hbm_classes(prof, cfg, B, (pmc or {}).get("hbm_class_traffic")),
-            "per_class_source": "ONE separate profiled pgd() call after the timed region (HIP events between the kernels: the "
-                                "call runs ~1 % longer than a timed one, so the class sum exceeds ms_per_step)",
+            "per_class_source": "ONE separate profiled pgd() call after the timed region, HIP events around every scope of the "
+                                "engine: the attack-update kernels and the host-side gaps between scopes are in no class, the events "
+                                "themselves cost the call ~1 %, so the class sum lands within ~1 % of ms_per_step on either side",
             "per_class": {k: {"ms": round(v["ms"], 3), "launches": v["launches"],
                               "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 and v["flops"] > 0 else None,
                               "gbps": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 and v["bytes"] > 0 else None}
                           for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
         }
     if rank == 0 and sampler is not None and "roofline" in res:
-        clk = sampler.summary()
+        clk = smi
         res["roofline"]["clock"] = clk
         eff = (res["roofline"].get("clock_in_kernel") or {}).get("sclk_mhz_effective")
         if clk or eff:

@@ -931,7 +931,10 @@ extern "C" int rvlm_vit_create(const rvlm_vit_config* cfg, const rvlm_vit_weight
         // split-K slabs: 8 x <=256 rows x 4W columns for the few-row GEMMs; trainable handles also run
         // the weight-gradient GEMMs split-K (few output tiles, K = all tokens): up to 3 x [3W, W] slabs
         size_t sk = (size_t)8 * 256 * 4 * W * sizeof(float);
-        if (cfg->trainable > 0) sk = std::max(sk, (size_t)16 * W * W * sizeof(float));
+        // (sized from the plan itself - ADVICE r5: 16 W^2 floats cover W = 1024 exactly but not W = 768, whose QKV plan wants 9
+        // slabs of [3W, W]; those shapes then fell to the transposing path, whose scratch the copy-free sizing no longer covers)
+        if (cfg->trainable > 0)
+            sk = std::max({sk, wgrad_slab_bytes(3 * W, W), wgrad_slab_bytes(W, W), wgrad_slab_bytes(4 * W, W), wgrad_slab_bytes(W, 4 * W)});
         ALLOC_OR_DIE(h->splitk_scratch, sk);
         h->splitk_bytes = sk;
         if (cfg->trainable > 0) {

@@ -283,6 +283,13 @@ static int gemm_bf16_nt_128(const GemmBf16& p, hipStream_t s) {
 // tB = [splits][K][Kc] (token chunks of the transposed operands, written by transpose_split): one batched launch of
 // splits * (N/256) * (K/256) work items, fp32 slabs [splits][N][K], then the deterministic slab reduce.
 // Plan: enough splits to give every CU one work item (the W x W out-projection gradient has 16 output tiles).
+// fp32 slab bytes the plan below asks for at its largest split count (M >= 128 * 16 tokens): what a trainable handle must own
+// for the copy-free weight gradient of an [N, K] linear (0: the shape never takes that path)
+size_t wgrad_slab_bytes(int N, int K) {
+    if (N % 256 != 0 || K % 256 != 0) return 0;
+    const int tiles = (N / 256) * (K / 256);
+    return (size_t)std::max(1, std::min(16, 256 / tiles)) * N * K * sizeof(float);
+}
 int wgrad_split_plan(int M, int N, int K, size_t slab_bytes, int* splits, int* Kc) {
     if (N % 256 != 0 || K % 256 != 0 || M < 256) return 0;
     const int tiles = (N / 256) * (K / 256), nk128 = cdiv(M, 128);

@@ -163,6 +163,7 @@ int transpose_pad(const T* in, long ldi, int R, int C, T* out, long ldo, int Rp,
 // split-K weight gradient (bf16): plan -> (splits, Kc), 0 when the shape is not covered; operands transposed into
 // [splits][C][Kc] token chunks (optionally emitting the bias gradient = column sums); batched persistent GEMM + reduce
 int wgrad_split_plan(int M, int N, int K, size_t slab_bytes, int* splits, int* Kc);
+size_t wgrad_slab_bytes(int N, int K);
 int transpose_split(const bf16_t* in, long ldi, int R, int C, bf16_t* out, int Kc, int splits, float* dbias,
                     int accumulate, float* red, size_t red_floats, hipStream_t s);
 // the same from the operands AS THEY LIE (dY [M, N] ld lddy, X [M, K] ld ldx, token-major): no transposed copies

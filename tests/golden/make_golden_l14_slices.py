@@ -14,6 +14,7 @@ What is executed from the reference (nothing is copied into this repo):
   * ``train.apgd_train.apgd_train`` (train/apgd_train.py:125-373) - config 3: TeCoA (CE on ``emb @ (100 T)``), 10 iterations, on
     the first NP images with the labels of the test batch (randint seed 2); written to l14_slices_c3.npz
     (``python tests/golden/make_golden_l14_slices.py c3`` makes that file alone);
+  * both again on the SAME images of the tower with CLIP-like weight statistics (``... clip`` -> l14_slices_clip.npz; round 6);
   * ``autoattack.autopgd_base.APGDAttack.attack_single_run`` (autoattack/autopgd_base.py:205-451) - config 5: CE loss,
     ALL 100 iterations, on the first NA images, from a recorded start point (seed 9), labels = the model's own clean
     predictions.
@@ -67,8 +68,84 @@ def config3(ref, cfg, x):
     print("wrote", path, os.path.getsize(path) >> 10, "KiB")
 
 
+def weights_sha(w):
+    import hashlib
+    h = hashlib.sha256()
+    for k in sorted(w):
+        h.update(w[k].numpy().tobytes())
+    return h.hexdigest()
+
+
+def clip_like():
+    """the reference's own pgd() (config 2) and apgd_train() (config 3) on 8 images of the ViT-L/14 with
+    CLIP-LIKE weight statistics (oracle/vit_ref.py::make_clip_like: outlier residual channels, LayerNorm gains over 2.5
+    decades, heavy-tailed projections, peaked attention), plus - for the per-iteration bf16 gate - the gradient signs and
+    per-sample losses along the trajectory of the first NS images (oracle pgd_ref with its trace, asserted bit-equal to the
+    reference's result here)."""
+    from oracle import attacks_ref as A
+    NS = 4
+    cfg = V.VIT_L_14
+    t0 = time.time()
+    w = V.init_weights(cfg, seed=3, clip_like=True)
+    ref = V.ClipVisionModelRef(cfg, w).eval()
+    print(f"clip-like weights: {time.time() - t0:.0f} s, sha256 {weights_sha(w)[:16]}", flush=True)
+    x = torch.rand(256, 3, 224, 224, generator=torch.Generator().manual_seed(0))
+    d0 = (torch.rand(256, 3, 224, 224, generator=torch.Generator().manual_seed(1)) * 2 - 1) * EPS
+    y = torch.randint(0, 1000, (256,), generator=torch.Generator().manual_seed(2))
+    T = torch.nn.functional.normalize(torch.randn(cfg.out_dim, 1000, generator=torch.Generator().manual_seed(3)), dim=0)
+    out = dict(threads=np.int64(THREADS), torch_version=np.array(torch.__version__), weights_seed=np.int64(3),
+               weights_sha256=np.array(weights_sha(w)), eps=np.float64(EPS), stepsize=np.float64(STEP))
+    t0 = time.time()
+    xc, dc = x[:NP].clone(), d0[:NP].clone()
+    with torch.no_grad():
+        e0 = ref(xc, False)
+    wrap = Lr.ComputeLossWrapperRef(e0, None, "mean", "l2", 100.)
+    x_adv = ref_pgd(ref, wrap, xc, None, "linf", EPS, 10, STEP, False, perturbation=dc.clone().requires_grad_(True),
+                    mode="max").detach()
+    with torch.no_grad():
+        loss_end = ((ref(x_adv, False) - e0) ** 2).sum(1)
+        loss_start = ((ref(xc + dc, False) - e0) ** 2).sum(1)
+    print(f"pgd: {time.time() - t0:.0f} s, loss {loss_start.mean():.4g} -> {loss_end.mean():.4g}", flush=True)
+    out.update(pgd_n=np.int64(NP), pgd_x_adv=x_adv.numpy(), pgd_e0=e0.numpy(), pgd_loss_end=loss_end.numpy(),
+               pgd_loss_start=loss_start.numpy())
+    # trajectory of the first NS images: gradient signs at every iterate (int8) and the per-sample loss there
+    t0 = time.time()
+    trace = []
+    x_or = A.pgd_ref(ref, Lr.ComputeLossWrapperRef(e0[:NS], None, "mean", "l2", 100.), xc[:NS], None, "linf", EPS, 10, STEP,
+                     False, perturbation=dc[:NS].clone(), mode="max", trace=trace)
+    assert torch.equal(x_or, x_adv[:NS]), "oracle pgd_ref and the reference's pgd() must agree bit for bit on the slice"
+    signs = np.stack([np.sign(t["grad"]).astype(np.int8) for t in trace])
+    xn = xc[:NS].numpy().astype(np.float32)
+    delta, vel = dc[:NS].numpy().astype(np.float32).copy(), np.zeros_like(xn)
+    losses, gnorm = [], []
+    for t in trace:
+        with torch.no_grad():
+            losses.append(((ref(torch.from_numpy(xn + delta), False) - e0[:NS]) ** 2).sum(1).numpy())
+        gnorm.append(np.sqrt((t["grad"].astype(np.float64) ** 2).reshape(NS, -1).sum(1)))
+        delta, vel = A.pgd_linf_update_ref(xn, t["grad"], delta, vel, EPS, STEP, 0.9, "max")
+    assert np.array_equal(xn + delta, x_or.numpy())
+    print(f"trajectory: {time.time() - t0:.0f} s, per-iteration loss {[float(l.mean()) for l in losses]}", flush=True)
+    out.update(traj_n=np.int64(NS), traj_grad_sign=signs, traj_loss=np.stack(losses), traj_grad_norm=np.stack(gnorm))
+    # config 3: the reference's apgd_train with the TeCoA wrapper
+    t0 = time.time()
+    yc = y[:NP].clone()
+    wrap3 = Lr.ComputeLossWrapperRef(None, T, "none", "ce", 100.)
+    x3 = ref_apgd_train(ref, xc, yc, "linf", EPS, n_iter=10, loss_fn=wrap3).detach()
+    with torch.no_grad():
+        ce = lambda xx: Lr.compute_loss_ref("ce", ref(xx, True), yc, None, 100., T, "none")     # noqa: E731
+        l_clean, l_adv = ce(xc), ce(x3)
+    print(f"apgd_train: {time.time() - t0:.0f} s, ce {l_clean.mean():.4g} -> {l_adv.mean():.4g}", flush=True)
+    out.update(c3_x_adv=x3.numpy(), c3_y=yc.numpy(), c3_loss_clean=l_clean.numpy(), c3_loss_adv=l_adv.numpy())
+    path = os.path.join(ROOT, "tests", "golden", "l14_slices_clip.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) >> 10, "KiB")
+
+
 def main():
     torch.set_num_threads(THREADS)
+    if len(sys.argv) > 1 and sys.argv[1] == "clip":
+        clip_like()
+        return
     cfg = V.VIT_L_14
     w = V.init_weights(cfg, seed=3)
     ref = V.ClipVisionModelRef(cfg, w).eval()

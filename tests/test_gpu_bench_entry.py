@@ -12,12 +12,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, "bench.py")
 
 
-def run(*a, env=None, timeout=600):
+BENCH_EXTRA = os.path.join(ROOT, "scripts", "bench_extra.py")     # the workloads no BASELINE config names (L2, Square, other models)
+
+
+def run(*a, env=None, timeout=600, script=BENCH):
     e = dict(os.environ)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         e.pop(k, None)
     e.update(env or {})
-    return subprocess.run([sys.executable, BENCH, *a], capture_output=True, text=True, env=e, timeout=timeout, cwd=ROOT)
+    return subprocess.run([sys.executable, script, *a], capture_output=True, text=True, env=e, timeout=timeout, cwd=ROOT)
 
 
 def test_more_gpus_than_devices_exits_nonzero():
@@ -77,6 +80,15 @@ def test_two_rank_rehearsal_attack_line():
     rk = d["ranks"]
     assert rk["gloo_ranks"] == 2 and rk["rccl_ranks"] == 0 and "self-launch" in rk["launcher"]
     assert 0 < rk["per_rank_images_per_sec_min"] <= rk["per_rank_images_per_sec_max"]
+    # the line explains itself: every rank reports its own rate, the clock its GEMM launches got, its
+    # device's socket power and its CPU binding; value = slowest-rank rate x ranks, next to the sum of the ranks' own rates
+    assert [r["rank"] for r in rk["per_rank"]] == [0, 1]
+    for r in rk["per_rank"]:
+        for k in ("device", "images_per_sec", "sclk_in_kernel_mhz", "sclk_smi_mhz_mean", "socket_power_w_mean", "cpu_affinity"):
+            assert k in r, k
+        assert r["images_per_sec"] > 0 and (r["sclk_in_kernel_mhz"] is None or 500 < r["sclk_in_kernel_mhz"] < 2600)
+    assert rk["images_per_sec_sum_of_rank_rates"] >= d["value"] * (1 - 1e-9)
+    assert abs(rk["images_per_sec_sum_of_rank_rates"] - sum(r["images_per_sec"] for r in rk["per_rank"])) < 1e-6 * d["value"]
     assert d["config"]["global_batch"] == 16 and d["config"]["parallelism"].startswith("dp2")
     # value = all ranks' images / the slowest rank's time
     assert abs(d["value"] - 2 * rk["per_rank_images_per_sec_min"]) / d["value"] < 1e-6
@@ -127,8 +139,16 @@ def test_mixed_precision_line():
 
 @pytest.mark.parametrize("attack", ["pgd", "apgd", "autopgd"])
 def test_l2_norm_lines(attack):
-    """--norm l2: the three entry points under the L2 threat model; the line names it and is not labelled as a BASELINE config."""
+    """scripts/bench_extra.py --norm l2: the three entry points under the L2 threat model through bench.py's harness; the line names
+    it and is not labelled as a BASELINE config.  bench.py itself does not know the option (it only holds BASELINE's workloads)."""
     d = _one_line(run("--gpus", "1", "--steps", "1", "--warmup", "1", "--model", "ViT-B-32", "--batch", "8", "--attack", attack,
-                      "--norm", "l2", "--no-cpu-baseline"))
+                      "--norm", "l2", "--no-cpu-baseline", script=BENCH_EXTRA))
     assert d["config"]["norm"] == "l2" and "L2" in d["metric"] and "BASELINE configs" not in d["config"]["workload"]
     assert d["value"] > 0
+
+
+def test_headline_harness_refuses_the_extras():
+    """bench.py only parses what BASELINE.json's configs need: --norm / --attack square / other models live in scripts/bench_extra.py."""
+    for extra in (("--norm", "l2"), ("--attack", "square"), ("--model", "ViT-L-14-336")):
+        r = run("--steps", "1", "--warmup", "0", *extra)
+        assert r.returncode == 2 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")], (extra, r.stderr[-300:])

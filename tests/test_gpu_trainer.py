@@ -21,12 +21,16 @@ def to_cfg(c):
 
 # width 1024 / 65 tokens / B=8: the encoder-shaped case - weight gradients take the split-K persistent-GEMM path
 VIT_WIDE = V.VitConfig(64, 8, 1024, 2, 16, 64)
+VIT_B16_SHALLOW = V.VitConfig(64, 16, 768, 2, 12, 512)
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 # (VIT_WIDE, 3): 195 tokens - fewer than the copy-free weight gradient takes: every linear goes through the transposing fallback
 # with the short leading dimension (the scratch of a W % 256 == 0 handle is sized for conv1 and this case only since round 5)
-@pytest.mark.parametrize("cfg,B,norm", [(V.VIT_TINY, 4, False), (V.VIT_TINY2, 3, True), (VIT_WIDE, 8, True), (VIT_WIDE, 3, True)])
+# (VIT_B16_SHALLOW, 16 / 3): the widths of ViT-B/16 (W = 768, P = 16), 272 / 51 tokens - ADVICE r5: at W = 768 the QKV plan wants 9
+# slabs of [3W, W], more than the 16 W^2 floats a trainable handle used to own, so every B/16 training step failed in the fallback
+@pytest.mark.parametrize("cfg,B,norm", [(V.VIT_TINY, 4, False), (V.VIT_TINY2, 3, True), (VIT_WIDE, 8, True), (VIT_WIDE, 3, True),
+                                        (VIT_B16_SHALLOW, 16, True), (VIT_B16_SHALLOW, 3, False)])
 def test_weight_gradients_vs_autograd(cfg, B, norm, precision):
     w = V.init_weights(cfg, seed=11)
     g = torch.Generator().manual_seed(2)

@@ -432,3 +432,42 @@ def test_eval_oracle_vs_reference_train_one_epoch(name):
     assert np.array_equal(adv.numpy(), z[f"{name}::x_adv_eval"])
     want = z[f"{name}::eval"]
     assert acc == want[0] and racc == want[1] and cs == want[2], (acc, racc, cs, want)
+
+
+def test_clip_like_tower_is_the_fixtures_and_is_clip_like():
+    """oracle/vit_ref.py::make_clip_like (round 6): deterministic across hosts (the sha256 the reference-run fixture
+    tests/golden/l14_slices_clip.npz recorded), the oracle reproduces the reference's clean embeddings of that fixture, and the
+    tower has the statistics it is named after - outlier residual channels 30-100x the ordinary RMS at the input of the first
+    block, LayerNorm gains over more than two decades, peaked attention."""
+    import hashlib
+    import os
+    import torch.nn.functional as F
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "l14_slices_clip.npz"))
+    cfg = V.VIT_L_14
+    torch.set_num_threads(8)
+    w = V.init_weights(cfg, seed=3, clip_like=True)
+    sha = hashlib.sha256()
+    for k in sorted(w):
+        sha.update(w[k].numpy().tobytes())
+    assert sha.hexdigest() == str(g["weights_sha256"])
+    x = torch.rand(256, 3, 224, 224, generator=torch.Generator().manual_seed(0))[:2]
+    with torch.no_grad():
+        e, tok = V.vit_forward(cfg, w, V.normalize_pixels(x), return_tokens=True)
+        # (thread count / blocking may differ from the generating host: fp32 summation order, not bits)
+        assert float((e - torch.from_numpy(g["pgd_e0"][:2])).abs().max() / e.abs().max()) < 2e-5
+        W = cfg.width
+        t = F.conv2d(V.normalize_pixels(x), w["conv1.weight"], stride=cfg.patch).reshape(2, W, -1).permute(0, 2, 1)
+        t = torch.cat([w["class_embedding"].expand(2, 1, W), t], 1) + w["positional_embedding"]
+        t = F.layer_norm(t, (W,), w["ln_pre.weight"], w["ln_pre.bias"], 1e-5)
+        mag = t.abs().mean(dim=(0, 1))
+        top = mag.topk(V.CLIP_LIKE_OUTLIERS).values
+        rms = float(t[..., mag < top.min()].pow(2).mean().sqrt())
+        assert 25 < float(top.min()) / rms and float(top.max()) / rms < 120, (top, rms)
+        gains = torch.cat([w[k] for k in w if "ln_" in k and k.endswith(".weight")])
+        assert float(gains.max() / gains.min()) > 150
+        p = "transformer.resblocks.0."
+        h = F.layer_norm(t, (W,), w[p + "ln_1.weight"], w[p + "ln_1.bias"], 1e-5)
+        q, k, _ = F.linear(h, w[p + "attn.in_proj_weight"], w[p + "attn.in_proj_bias"]).split(W, -1)
+        q, k = (z.reshape(2, -1, cfg.heads, 64).transpose(1, 2) for z in (q, k))
+        pmax = torch.softmax(q @ k.transpose(-1, -2) / 8.0, -1).amax(-1).mean()
+        assert float(pmax) > 10.0 / cfg.tokens          # far from uniform attention (1 / 257)
