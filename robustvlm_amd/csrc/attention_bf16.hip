@@ -736,7 +736,41 @@ attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __res
 // =============================================================================================
 constexpr int FB2_TILE = 2048;   // one wave's dS tile [32 keys][32 q] bf16
 
-template <int NK>
+// Cross-lane sums WITHOUT address registers (ds_swizzle bit mode for lane ^ 1 .. 16, v_permlane32_swap for lane ^ 32).  __shfl_xor
+// is ds_bpermute: one per-lane address VGPR per distance, derived from the lane id - loop-invariant values that hipcc hoists out of
+// the persistent head loop, where the fused backward has no register left for them (they were parked in scratch).
+__device__ __forceinline__ float xor32_sum(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);     // r[0] = the lower half's value everywhere, r[1] the upper's
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+__device__ __forceinline__ float wave_sum_swz(float v) {
+#define RVLM_SWZ_ADD(K) v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), ((K) << 10) | 0x1f))
+    RVLM_SWZ_ADD(1); RVLM_SWZ_ADD(2); RVLM_SWZ_ADD(4); RVLM_SWZ_ADD(8); RVLM_SWZ_ADD(16);
+#undef RVLM_SWZ_ADD
+    return xor32_sum(v);
+}
+
+// PF (round 6, "everything of the next head arrives under this one"): the persistent form above still staged K and V of every
+// head in its phase 0 - 72 KB of HBM misses per workgroup at the ~12 B per clock a CU pulls them, 28 % of the kernel, exposed
+// (profiles/r05_attn_ab_bwd_variants_fwd_persistent.log).  K and V are only read in phase 1 (fragments to registers), and V only
+// row-major by the wave that owns the key tile.  So with PF:
+//   * V never touches LDS: a wave's V fragments (32 keys x 64 d = the 4 KiB it owns) are plain global loads to registers, like
+//     the O rows; the odd key's V row sits in a 128-B LDS array (Ve) next to its K row;
+//   * the K tile keeps its own 36 KiB, dead after phase 1: the NEXT head's K lands there during the query-tile loop (4 more
+//     1-KiB DMAs per step next to the 8 of Q / dO);
+//   * the dK / dV store staging (8 x 4 KiB) aliases the dS tiles (dead after the loop; one barrier in front of phase 3, which
+//     replaces the end-of-head barrier: the count per head stays 12);
+//   * the next head's V / O fragments, lse, odd rows are requested into registers at the top of phase 3 and land under the stores.
+// LDS: Q 36 | dO 36 | K 36 | dS / staging 32 | small arrays 9.6 KiB = 149.6 KiB.  Phase 0 of every head but a workgroup's first
+// is then: commit the small arrays from registers, s_waitcnt vmcnt(0), barrier.
+// MEASURED (profiles/r06_attn_bwd_prefetch_ab.log, same box, three alternations): phase 0 12.9 k -> 4.2 k cycles per head as
+// designed, but the tile loop 25.6 k -> 30.9 k (12 instead of 8 DMA requests per step through the CU's one texture queue, in front
+// of the step's barrier: ~150 cycles of critical path each) and the store phase 1.9 k -> 4.7 k (the register prefetches queue in
+// front of the stores): 190.5-192 -> 198-203 us per launch, 44.5 -> 46.9 ms per step in the pipeline.  NOT the shipped form: PF =
+// true is only instantiated by make EXPERIMENTAL=1 (RVLM_ATTN_BWD_PF=1).  The bytes of a head have to come through that queue
+// somewhere; exposed in phase 0 they at least cost no barrier-synchronised step time.
+template <int NK, bool PF>
 __global__ void __launch_bounds__(NK * 64)
 attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __restrict__ o, long ldo,
                       const bf16_t* __restrict__ d_o, long lddo, const float* __restrict__ lse2,
@@ -758,31 +792,74 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Qt = smem;
     char* Dt = smem + Sp * 128;
-    char* area = smem + Sp * 256;                              // K | V tiles, later NK partial slots
+    char* area = smem + Sp * 256;                              // K | V tiles, later NK partial slots (PF: K tile | dS tiles)
     char* Kt = area;
-    char* Vt = area + Sp * 128;
-    float* Ls = (float*)(area + Sp * 256);
+    char* Vt = area + Sp * 128;                                // (not PF)
+    char* dsarea = PF ? area + Sp * 128 : area;                // dS tiles (+ store staging behind them; PF: aliased onto them)
+    float* Ls = (float*)(PF ? dsarea + 2 * NK * FB2_TILE : area + Sp * 256);
     float* Ds = Ls + Sp;
     float* Pe = Ds + Sp;                                       // p[q][odd key]
     float* De = Pe + Sp;                                       // dS[q][odd key]
     float* Ke = De + Sp;                                       // k[odd key][0..63] as fp32
     float* KVe = Ke + 64;                                      // [NK + 1][2][64] per-wave (+ odd query) dK / dV of the odd key
+    // PF: the odd token's rows, raw bf16 [4][64]: dO, O, Q, V.  V's is also the odd KEY's row as an MFMA operand (Ve).  They
+    // arrive by LDS-DMA (two 4-byte-per-lane requests of wave 0: lanes 0-31 one row, 32-63 the next), not through registers
+    bf16_t* Orow = (bf16_t*)(KVe + (NK + 1) * 128);
+    bf16_t* Ve = Orow + 3 * 64;
+    // PF: what the next head needs in REGISTERS, requested at the top of phase 3 (a workgroup's first head: in its phase 0)
+    bf16x8 vf_n[4], ofr_n[4];
+    // (the 16-bit ones stay RAW until they are used: converted where they are loaded, every load got its own s_waitcnt vmcnt(0) -
+    // four serial HBM round trips at the top of phase 3)
+    float ls_n = INFINITY;
+    unsigned short kv_n = 0;
+    auto raw16 = [](const bf16_t* q) { return *(const unsigned short*)q; };
+    auto cvt16 = [](unsigned short u) { return __uint_as_float((unsigned)u << 16); };
+    auto fetch_regs = [&](int bh2, int tid2) __attribute__((always_inline)) {
+        const int b2 = bh2 / H, h2 = bh2 % H, w2 = tid2 >> 6, lane2 = tid2 & 63;
+        const bf16_t* base2 = qkv + (long)b2 * lay.qkv_b + (long)h2 * lay.qkv_h;
+        const bf16_t* dob2 = d_o + (long)b2 * lay.o_b + (long)h2 * lay.o_h;
+        const bf16_t* ob2 = o + (long)b2 * lay.o_b + (long)h2 * lay.o_h;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            vf_n[kk] = frag_global(base2 + 2 * W, ld, w2 * 32 + (lane2 & 31), kk, lane2);
+            ofr_n[kk] = frag_global(ob2, ldo, w2 * 32 + (lane2 & 31), kk, lane2);
+        }
+        ls_n = (tid2 < S) ? lse2[((long)b2 * H + h2) * Sp + tid2] : INFINITY;
+        if (tid2 < 64) kv_n = raw16(base2 + (long)SE * ld + W + tid2);
+        if (w2 == 0) {
+            // rows dO | O, then Q | V of token SE -> Orow[0..1], Orow[2..3] (readers: wave 0 at the end of phase 1 and the odd-key
+            // operand of every wave in phase 1 - all in front of the barrier that precedes this call)
+            const int half = lane2 >> 5, c = (lane2 & 31) * 2;
+            const bf16_t* g0 = (half ? ob2 + (long)SE * ldo : dob2 + (long)SE * lddo) + c;
+            const bf16_t* g1 = base2 + (long)SE * ld + (half ? 2 * W : 0) + c;
+            const unsigned d0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_char*)Orow);
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" :: "v"(g0), "s"(d0) : "memory", "m0");
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" :: "v"(g1), "s"(d0 + 256u) : "memory", "m0");
+        }
+    };
     // PERSISTENT over the (image, head) pairs bh = blockIdx.x, + gridDim.x, ... (the launcher gives <= 256 workgroups when
     // RVLM_ATTN_PERSIST is on): while a head's query-tile loop runs, the NEXT head's Q and dO tiles are requested into the
     // LDS tile slots the loop has finished with (one 1-KiB DMA per wave and step, through inline asm: a compiler-visible
     // LDS-DMA would make hipcc drain vmcnt in front of every LDS read that might alias it).  A CU pulls HBM misses at only
     // ~12 B per clock, so the 144 KB staging of a head cost 27 % of the kernel; half of it now arrives under the loop.
     bool have_qd = false;       // Q / dO of the head about to start are already in LDS
+    const int wave_u = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     for (int bh = blockIdx.x; bh < nbh; bh += gridDim.x) {
     // (opaque per iteration: otherwise every lane-derived offset of the phases below is hoisted out of this loop, lives
     // across the whole head - 256 VGPRs, 52 spilled dwords - and the kernel ran 40 % slower than its one-head form)
+    // (PF: rebuilt from the wave index (an SGPR) and mbcnt instead of from threadIdx.x, whose register would have to survive the
+    // whole head next to 256 live ones - it was the one value hipcc parked in scratch and reloaded at the top of every head)
     int tid = threadIdx.x;
+    if (PF) {    // (inside a volatile asm: as builtins the two mbcnt are loop-invariant and get hoisted - and spilled - again)
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=&v"(tid));
+        tid += wave_u * 64;
+    }
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63, w = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     // optional phase timeline (RVLM_ATTN_TRACE=1: 5 s_memtime stamps per head into the dsum scratch buffer)
     auto stamp = [&](int k) {
-        if (trace && trace_mode < 2 && threadIdx.x == 0) trace[(long)bh * 8 + k] = __builtin_amdgcn_s_memtime();
+        if (trace && trace_mode < 2 && tid == 0) trace[(long)bh * 8 + k] = __builtin_amdgcn_s_memtime();
     };
     stamp(0);
     const int b = bh / H, h = bh % H;
@@ -802,21 +879,30 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
     if (!have_qd) {
         stage_tile(Qt, base, ld, S, Sp, w, NK, lane);
         stage_tile(Dt, dob, lddo, S, Sp, w, NK, lane);
+        if (PF) { stage_tile(Kt, base + W, ld, S, Sp, w, NK, lane); fetch_regs(bh, tid); }
     }
-    stage_tile(Kt, base + W, ld, S, Sp, w, NK, lane);
-    stage_tile(Vt, base + 2 * W, ld, S, Sp, w, NK, lane);
-    for (int i = tid; i < Sp; i += NK * 64) Ls[i] = (i < S) ? lse2[((long)b * H + h) * Sp + i] : INFINITY;
-    if (tid < 64) Ke[tid] = (float)base[(long)SE * ld + W + tid];
     bf16x8 ofr[4];   // O rows of this wave's query tile (for D = rowsum(dO * O)): requested under the staging
+    if (!PF) {
+        stage_tile(Kt, base + W, ld, S, Sp, w, NK, lane);
+        stage_tile(Vt, base + 2 * W, ld, S, Sp, w, NK, lane);
+        for (int i = tid; i < Sp; i += NK * 64) Ls[i] = (i < S) ? lse2[((long)b * H + h) * Sp + i] : INFINITY;
+        if (tid < 64) Ke[tid] = (float)base[(long)SE * ld + W + tid];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) ofr[kk] = frag_global(ob, ldo, w * 32 + (lane & 31), kk, lane);
+        for (int kk = 0; kk < 4; ++kk) ofr[kk] = frag_global(ob, ldo, w * 32 + (lane & 31), kk, lane);
+    } else {
+        // commit what came in registers (every wave is past the previous head's loop: the barrier in front of its phase 3)
+        if (tid < Sp) Ls[tid] = ls_n;
+        if (tid < 64) Ke[tid] = cvt16(kv_n);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) ofr[kk] = ofr_n[kk];
+    }
     // the odd query's rows as 64-wide vectors (ONE wave), requested under the staging as well: fetched in phase 1 they put
     // an HBM round trip on the path to the phase's barrier.  That wave is wave 0: per-wave stamps (RVLM_ATTN_TRACE=2) put
     // the first-dispatched waves 0-3 at the phase's barrier after 4.3 k cycles, waves 4-6 after 5.6 k, and the wave that
     // carries these 1.7 k cycles of serial shuffles on top - it used to be the last one - after 7.3 k
     constexpr int ODD_Q_WAVE = 0;
     float odd_do = 0.0f, odd_o = 0.0f, odd_q = 0.0f, odd_v = 0.0f;
-    if (w == ODD_Q_WAVE) {
+    if (!PF && w == ODD_Q_WAVE) {
         odd_do = (float)dob[(long)SE * lddo + lane]; odd_o = (float)ob[(long)SE * ldo + lane];
         odd_q = (float)base[(long)SE * ld + lane]; odd_v = (float)base[(long)SE * ld + 2 * W + lane];
     }
@@ -827,9 +913,23 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
 
     const FragOffs fo = make_offs(lane);
     // ---- phase 1: this wave's key tile in registers; D for its query tile(s); the odd key -------------------
+    // (PF: D = rowsum(dO * O) of this wave's query tile FIRST - the prefetched O fragments are the 16 registers this phase has
+    // no room for next to the K^T fragments; with the sum placed where it stood, behind them, hipcc parked 12 of the
+    // prefetched dwords in scratch right behind their loads, i.e. waited for them in phase 3)
+    float dsum_pf = 0.0f;
+    if (PF) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const bf16x8 dof0 = frag_rm(Dt, w * 32, fo.rm[kk]), of = ofr[kk];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dsum_pf = fmaf((float)dof0[e], (float)of[e], dsum_pf);
+        }
+        dsum_pf = xor32_sum(dsum_pf);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     bf16x8 kf[4], vf[4];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) { kf[kk] = frag_rm(Kt, w * 32, fo.rm[kk]); vf[kk] = frag_rm(Vt, w * 32, fo.rm[kk]); }
+    for (int kk = 0; kk < 4; ++kk) { kf[kk] = frag_rm(Kt, w * 32, fo.rm[kk]); vf[kk] = PF ? vf_n[kk] : frag_rm(Vt, w * 32, fo.rm[kk]); }
     // dQ ownership: wave w computes the 16 (d) x 16 (q) block (db, qb) of every query tile's dQ^T over ALL keys, so no
     // partial sums cross waves.  Its A operands K^T[16 d][32 keys] of the NK key tiles stay in registers
     // (v_mfma_f32_16x16x32_bf16: lane <-> d = 16 db + (lane & 15), k = 8 (lane >> 4) + 0..7 <-> key).
@@ -856,16 +956,24 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
             for (int kk = 0; kk < 4; ++kk) {
                 qf[kk] = frag_rm(Qt, qe * 32, fo.rm[kk]);
                 dof[kk] = frag_rm(Dt, qe * 32, fo.rm[kk]);
-                const bf16x8 of = ofr[kk];
+                if (!PF) {
+                    const bf16x8 of = ofr[kk];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) dsum = fmaf((float)dof[kk][e], (float)of[e], dsum);
+                    for (int e = 0; e < 8; ++e) dsum = fmaf((float)dof[kk][e], (float)of[e], dsum);
+                }
             }
+            if (PF) dsum = dsum_pf; else
             dsum += __shfl_xor(dsum, 32, 64);
             // S^T / dP^T against the last (padded) key tile: lane <-> query, register 0 of the hi = 0 lanes <-> odd key
             f32x16 sT = zero16(), dpT = zero16();
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 sT = MFMA(frag_rm(Kt, SE, fo.rm[kk]), qf[kk], sT);
+                if (PF) {     // the padded last key tile of V: row 0 (lanes 0 and 32) = the odd key's row, the others zero
+                    bf16x8 ve = *(const bf16x8*)(Ve + (kk * 2 + hi) * 8);
+                    if (l31 != 0) ve = bf16x8{};
+                    dpT = MFMA(ve, dof[kk], dpT);
+                } else
                 dpT = MFMA(frag_rm(Vt, SE, fo.rm[kk]), dof[kk], dpT);
             }
             const float pe = EXP2(fmaf(sT[0], scale_log2, -Ls[q]));
@@ -906,8 +1014,10 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
     }
     if (w == ODD_Q_WAVE) {
         // the odd QUERY (row SE) against the odd key, as 64-wide vectors (lane <-> d): D, p, dS, and its dK / dV terms
+        if (PF) { odd_do = (float)Orow[lane]; odd_o = (float)Orow[64 + lane]; odd_q = (float)Orow[128 + lane]; odd_v = (float)Orow[192 + lane]; }
         const float dov = odd_do, ov = odd_o, qv = odd_q, kv = Ke[lane], vv = odd_v;
-        const float dsum = wave_sum(dov * ov), sc = wave_sum(qv * kv), dpe = wave_sum(dov * vv);
+        const float dsum = PF ? wave_sum_swz(dov * ov) : wave_sum(dov * ov), sc = PF ? wave_sum_swz(qv * kv) : wave_sum(qv * kv),
+                    dpe = PF ? wave_sum_swz(dov * vv) : wave_sum(dov * vv);
         const float pe = EXP2(fmaf(sc, scale_log2, -Ls[SE]));
         const float de = pe * (dpe - dsum);
         if (lane < 32) { Ds[SE + lane] = (lane == 0) ? dsum : 0.0f; Pe[SE + lane] = (lane == 0) ? pe : 0.0f; De[SE + lane] = (lane == 0) ? de : 0.0f; }
@@ -915,9 +1025,9 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
         KVe[(NK * 2 + 1) * 64 + lane] = pe * dov;
     }
     if (trace) stamp(7);                                                               // this wave's part of phase 1 done
-    if (trace && trace_mode == 2 && (threadIdx.x & 63) == 0) {
+    if (trace && trace_mode == 2 && lane == 0) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        trace[(long)bh * 8 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memtime() - t_p1;
+        trace[(long)bh * 8 + w] = __builtin_amdgcn_s_memtime() - t_p1;
     }
     __syncthreads();   // K / V tiles are dead: the area becomes the partial slots; Ds / Pe / De are complete
     stamp(2);
@@ -926,7 +1036,7 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
     // (8 MFMA) and this wave's dQ^T block from the NK waves' dS tiles (NK v_mfma_f32_16x16x32_bf16) -> dQ stored.
     // The dS tiles are double-buffered by tile parity: a wave that writes tile qt + 1 has passed barrier qt, which
     // every wave reaches only after its reads of tile qt - 1 - one barrier per tile is enough.
-    lds_char* dsb = (lds_char*)area;                          // [2][NK] tiles of FB2_TILE bytes: [32 keys][32 q] bf16
+    lds_char* dsb = (lds_char*)dsarea;                        // [2][NK] tiles of FB2_TILE bytes: [32 keys][32 q] bf16
     // write: this lane's key row (64-B rows), 8-B chunk (4 consecutive q) index XOR ((key >> 1) & 7): the 8 same-parity
     // rows of a 16-lane ds_write_b64 group get 8 different keys, and the two rows r, r + 8 that share a bank phase in
     // the transposing read below differ in key bit 2 = the other 32-B half of the row (round 2 XORed (key >> 2) & 7: 2-way
@@ -954,6 +1064,39 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
         const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_char*)((w < 4 ? Qt : Dt) + blk * 1024));
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gp), "s"(dst) : "memory", "m0");
     };
+    // PF: the next head's K into the K tile, dead since phase 1: blocks 4 t .. 4 t + 3 (8 rows each) at step t, by the waves of
+    // parity t (one DMA each, so that a step adds one request to half of the waves only)
+    const bf16_t* nk_src = nullptr;
+    if (PF && prefetch_next) nk_src = qkv + (long)(nxt / H) * lay.qkv_b + (long)(nxt % H) * lay.qkv_h + W;
+    auto prefetch_k = [&](int t) {
+        if ((w & 1) != (t & 1)) return;
+        const int blk = 4 * t + (w >> 1), row = blk * 8 + (lane >> 3);
+        const bf16_t* gp = nk_src + (long)min(row, S - 1) * ld + ((lane & 7) ^ swz_key(row)) * 8;
+        const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_char*)(Kt + blk * 1024));
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gp), "s"(dst) : "memory", "m0");
+    };
+    // PF: RUNNING request pointers for steps t < NT - 1.  The row a lane requests at step t is 32 t + 8 (block of its wave) +
+    // (lane >> 3) - never clamped below the last tile - and the swizzle key only sees row bits 1-3, so pointer(t) = pointer(0) +
+    // 32 t rows: one 64-bit add and one SALU add per request instead of the ~20 VALU (64-bit multiply, min, swizzle) hipcc emitted
+    // for each call of the two lambdas above, in a loop that is bound by instruction issue.  The last tile (clamped rows) keeps
+    // the generic form, outside the loop.
+    const bf16_t* pq = nullptr;
+    const bf16_t* pk = nullptr;
+    unsigned dq_dst = 0, dk_dst = 0;
+    if (PF && prefetch_next) {
+        const int rq = (w & 3) * 8 + (lane >> 3), rk = (w & 1) * 32 + (w >> 1) * 8 + (lane >> 3);
+        pq = nsrc + (long)rq * nld + ((lane & 7) ^ swz_key(rq)) * 8;
+        pk = nk_src + (long)rk * ld + ((lane & 7) ^ swz_key(rk)) * 8;
+        dq_dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_char*)((w < 4 ? Qt : Dt) + (w & 3) * 1024));
+        dk_dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_char*)(Kt + ((w & 1) * 4 + (w >> 1)) * 1024));
+    }
+    const long pq_step = 32 * nld, pk_step = 64 * ld;
+    // which steps request: bit t of a mask that is shifted along (a loop-CARRIED condition: written as tests of qt and of the wave's
+    // parity hipcc unswitched / peeled the tile loop into three copies and spilled 31 registers).  Q / dO tile qt - 1 at steps 1 ..
+    // NT - 1; K blocks 4 qt .. 4 qt + 3 at steps qt < NT - 1 of the wave's parity
+    unsigned qmask = (PF && prefetch_next) ? ((1u << NT) - 2u) : 0u;
+    unsigned kmask = (PF && prefetch_next) ? (((wave_u & 1) ? 0xAAAAAAAAu : 0x55555555u) & ((1u << (NT - 1)) - 1u)) : 0u;
+    asm volatile("" : "+s"(qmask), "+s"(kmask));
     for (int qt = 0; qt < NT; ++qt) {
         f32x16 s = zero16(), dp = zero16();
         // Round 5: the tile's 32 lse / D values (8 x 16 B per lane, two distinct addresses per instruction: broadcasts) are
@@ -1007,6 +1150,17 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
                 dot[ks][dt] = frag_tr(Dt, qt * 32 + ks * 16, fo, dt);
                 qtr[ks][dt] = frag_tr(Qt, qt * 32 + ks * 16, fo, dt);
             }
+        if (PF) {
+            if (qmask & 1u) {                                       // Q / dO tile qt - 1 (< NT - 1)
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(pq), "s"(dq_dst) : "memory", "m0");
+                pq += pq_step; dq_dst += 4096;
+            }
+            if (kmask & 1u) {                                       // K blocks 4 qt .. 4 qt + 3: the waves of parity qt
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(pk), "s"(dk_dst) : "memory", "m0");
+                pk += pk_step; dk_dst += 8192;
+            }
+            qmask >>= 1; kmask >>= 1;
+        } else
         if (prefetch_next && qt > 0) prefetch_tile(qt - 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the dS tile is in LDS
         __builtin_amdgcn_s_barrier();
@@ -1048,6 +1202,17 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
     }
 
     if (prefetch_next) prefetch_tile(NT - 1);
+    if (PF && prefetch_next) prefetch_k(NT - 1);                    // (Sp / 8 = 4 NT blocks: steps 0 .. NT - 1 cover the K tile)
+    if (PF) {
+        // every wave is done with the dS tiles (the store staging below aliases them) and with Ls / Ds / De (the next head's
+        // phase 0 rewrites them); then the next head's register operands go out, to land under the stores
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // (unconditional: a conditional definition would keep the PREVIOUS values live through the whole head, tile loop included;
+        // a workgroup's last head re-reads its own operands and drops them)
+        fetch_regs(prefetch_next ? nxt : bh, tid);
+    }
     stamp(3);
     // ---- phase 3: dK, dV of this wave's keys; the odd key ------------------------------------------------------
     // Through a wave-private 4 KiB LDS tile ([32 keys][64 d] bf16, 16-B chunk index XOR (key & 7)), so that the global
@@ -1055,7 +1220,7 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
     // dwordx4 stores instead of 16 + 16 dwordx2; the store tail was 10 % of the kernel, issue-bound).  The tile lives
     // behind the dS buffers, which slower waves may still be reading.
     {
-        lds_char* tile = (lds_char*)area + 2 * NK * FB2_TILE + w * 4096;
+        lds_char* tile = (lds_char*)dsarea + (PF ? 0 : 2 * NK * FB2_TILE) + w * 4096;
         const int r8 = lane >> 3, c8 = lane & 7;
         bf16_t* kbase = dqkv + (long)b * lay.qkv_b + (long)h * lay.qkv_h + (long)(w * 32) * lddq + W + c8 * 8;
 #pragma unroll
@@ -1091,7 +1256,10 @@ attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, long ld, const bf16_t* __r
     }
     stamp(4);
     have_qd = prefetch_next;
-    __syncthreads();      // the next head's staging overwrites the K / V area (dS tiles, store transposes) and the small arrays
+    // the next head's staging overwrites the K / V area (dS tiles, store transposes) and the small arrays.  (PF: nothing is staged
+    // there any more - the small arrays are rewritten behind the barrier in front of phase 3, KVe behind the next phase-0 barrier,
+    // which wave 0 reaches after its reads below... above: the odd key's row is summed by wave 0 before it leaves this phase.)
+    if (!PF) __syncthreads();
     }
 }
 
@@ -1187,8 +1355,21 @@ int attn_bwd_bf16(const bf16_t* qkv, long ldqkv, const bf16_t* o, long ldo, cons
     if (fused < 0) { const char* e = getenv("RVLM_ATTN_FUSED"); fused = e ? atoi(e) : 1; }
     if (fused && g_use_tr && S == 257) {   // one kernel: dQ, dK, dV (see attn_bwd_fused_kernel)
         constexpr int NK = 8, SpF = (NK + 1) * 32;
-        const size_t lds_f = (size_t)SpF * 256 + (size_t)SpF * 256 + (4 * SpF + 64 + (NK + 1) * 128) * sizeof(float);
-        if ((rc = set_lds(attn_bwd_fused_kernel<NK>, lds_f))) return rc;
+        // RVLM_ATTN_BWD_PF=1 (make EXPERIMENTAL=1 builds only; measured SLOWER, profiles/r06_attn_bwd_prefetch_ab.log): K / V / O /
+        // lse of the next head arrive under the current one (template parameter PF above)
+#ifdef RVLM_EXPERIMENTAL_GEMM
+        static int pf = -1;
+        if (pf < 0) { const char* e = getenv("RVLM_ATTN_BWD_PF"); pf = e ? atoi(e) : 0; }
+#else
+        constexpr int pf = 0;
+#endif
+        const size_t smalls = (4 * SpF + 64 + (NK + 1) * 128) * sizeof(float) + 4 * 128;
+        const size_t lds_f = pf ? (size_t)SpF * 384 + 2 * NK * FB2_TILE + smalls : (size_t)SpF * 512 + smalls;
+#ifdef RVLM_EXPERIMENTAL_GEMM
+        if ((rc = pf ? set_lds(attn_bwd_fused_kernel<NK, true>, lds_f) : set_lds(attn_bwd_fused_kernel<NK, false>, lds_f))) return rc;
+#else
+        if ((rc = set_lds(attn_bwd_fused_kernel<NK, false>, lds_f))) return rc;
+#endif
         static int trace = -1, desync = -1;
         if (trace < 0) { const char* e = getenv("RVLM_ATTN_TRACE"); trace = e ? atoi(e) : 0; }
         if (desync < 0) { const char* e = getenv("RVLM_ATTN_DESYNC"); desync = e ? atoi(e) : 0; }
@@ -1196,17 +1377,22 @@ int attn_bwd_bf16(const bf16_t* qkv, long ldqkv, const bf16_t* o, long ldo, cons
         if (hm < 0) { const char* e = getenv("RVLM_ATTN_HM"); hm = e ? atoi(e) : 0; }
         if (persist < 0) { const char* e = getenv("RVLM_ATTN_PERSIST"); persist = e ? atoi(e) : 1; }
         const int nbh = B * H, grid = persist ? std::min(nbh, 256) : nbh;
+#ifdef RVLM_EXPERIMENTAL_GEMM
+#define LAUNCH_FUSED(PFV, ...) hipLaunchKernelGGL((attn_bwd_fused_kernel<NK, PFV>), dim3(grid), dim3(NK * 64), lds_f, s, __VA_ARGS__)
+#else       // (the shipped library instantiates the measured form only)
+#define LAUNCH_FUSED(PFV, ...) hipLaunchKernelGGL((attn_bwd_fused_kernel<NK, false>), dim3(grid), dim3(NK * 64), lds_f, s, __VA_ARGS__)
+#endif
+        unsigned long long* tr = trace ? (unsigned long long*)dsum_scratch : nullptr;
         if (hm) {
             const AttnLayout lay = {(long)H * S * 64, (long)S * 64, (long)H * S * 64, (long)S * 64};
-            hipLaunchKernelGGL((attn_bwd_fused_kernel<NK>), dim3(grid), dim3(NK * 64), lds_f, s, qkv, 64L, o, 64L, d_o, 64L,
-                               lse, dqkv, 64L, H, S, (long)B * H * S * 64, scale, sl2,
-                               trace ? (unsigned long long*)dsum_scratch : nullptr, desync | (trace << 8), lay, nbh);
+            if (pf) LAUNCH_FUSED(true, qkv, 64L, o, 64L, d_o, 64L, lse, dqkv, 64L, H, S, (long)B * H * S * 64, scale, sl2, tr, desync | (trace << 8), lay, nbh);
+            else LAUNCH_FUSED(false, qkv, 64L, o, 64L, d_o, 64L, lse, dqkv, 64L, H, S, (long)B * H * S * 64, scale, sl2, tr, desync | (trace << 8), lay, nbh);
         } else {
             const AttnLayout lay = {(long)S * ldqkv, 64L, (long)S * ldo, 64L};
-            hipLaunchKernelGGL((attn_bwd_fused_kernel<NK>), dim3(grid), dim3(NK * 64), lds_f, s, qkv, ldqkv, o, ldo, d_o, lddo,
-                               lse, dqkv, lddqkv, H, S, (long)W, scale, sl2,
-                               trace ? (unsigned long long*)dsum_scratch : nullptr, desync | (trace << 8), lay, nbh);
+            if (pf) LAUNCH_FUSED(true, qkv, ldqkv, o, ldo, d_o, lddo, lse, dqkv, lddqkv, H, S, (long)W, scale, sl2, tr, desync | (trace << 8), lay, nbh);
+            else LAUNCH_FUSED(false, qkv, ldqkv, o, ldo, d_o, lddo, lse, dqkv, lddqkv, H, S, (long)W, scale, sl2, tr, desync | (trace << 8), lay, nbh);
         }
+#undef LAUNCH_FUSED
         RVLM_CHECK_LAUNCH();
         return RVLM_OK;
     }

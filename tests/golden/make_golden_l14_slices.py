@@ -86,7 +86,8 @@ def clip_like():
     NS = 4
     cfg = V.VIT_L_14
     t0 = time.time()
-    w = V.init_weights(cfg, seed=3, clip_like=True)
+    rec = {}
+    w = V.init_weights(cfg, seed=3, clip_like=True, record=rec)
     ref = V.ClipVisionModelRef(cfg, w).eval()
     print(f"clip-like weights: {time.time() - t0:.0f} s, sha256 {weights_sha(w)[:16]}", flush=True)
     x = torch.rand(256, 3, 224, 224, generator=torch.Generator().manual_seed(0))
@@ -94,7 +95,8 @@ def clip_like():
     y = torch.randint(0, 1000, (256,), generator=torch.Generator().manual_seed(2))
     T = torch.nn.functional.normalize(torch.randn(cfg.out_dim, 1000, generator=torch.Generator().manual_seed(3)), dim=0)
     out = dict(threads=np.int64(THREADS), torch_version=np.array(torch.__version__), weights_seed=np.int64(3),
-               weights_sha256=np.array(weights_sha(w)), eps=np.float64(EPS), stepsize=np.float64(STEP))
+               weights_sha256=np.array(weights_sha(w)), weights_calib=np.array(rec["calib"], dtype=np.int64),
+               weights_fingerprint=V.weights_fingerprint(w), eps=np.float64(EPS), stepsize=np.float64(STEP))
     t0 = time.time()
     xc, dc = x[:NP].clone(), d0[:NP].clone()
     with torch.no_grad():
