@@ -51,9 +51,10 @@ def parse(extra=None):
     ap.add_argument("--model", default="ViT-L-14", choices=list(HEADLINE_MODELS) + list(getattr(extra, "MODELS", ())))
     ap.add_argument("--batch", type=int, default=128, help="images per GPU per step")
     ap.add_argument("--iterations", type=int, default=10)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16+fp32-first"],
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "x3", "bf16+fp32-first", "bf16+x3-first"],
                     help="bf16: the throughput path (headline); fp32: the reference's own precision on the fp32 matrix-pipe tiles; "
-                         "bf16+fp32-first: pgd with its first iteration (and the clean embedding) in fp32")
+                         "x3: fp32 storage, the linears as split-bf16 products (3 bf16 MFMAs per product, ~16 mantissa bits); "
+                         "bf16+fp32-first / bf16+x3-first: pgd with its first iteration (and the clean embedding) on that handle")
     ap.add_argument("--attack", default="pgd", choices=["pgd", "apgd", "autopgd"] + list(getattr(extra, "ATTACKS", ())),
                     help="pgd: BASELINE configs 2/4 (FARE); apgd: config 3 (TeCoA apgd_train); autopgd: config 5 "
                          "(APGDAttack CE on the zero-shot head, use --iterations 100 --batch 256)")
@@ -471,8 +472,10 @@ def main(extra=None):
             "bound": "mfma",
             "kernel": "gemm_f32_mfma_kernel (v_mfma_f32_32x32x2_f32 tiles: QKV/out-proj/fc1/fc2, fwd + dgrad)" if fp32_run else
                       "gemm_bf16_nt_256p_kernel (QKV/out-proj/fc1/fc2, fwd + dgrad; the 128 remainder rows ride in the same launch)"
-                      + (" - the bf16 handle's launches only (iterations 2..I); the fp32 first iteration is not in this object"
-                         if args.precision == "bf16+fp32-first" else ""),
+                      + (" - the bf16 handle's launches only (iterations 2..I); the first iteration's handle is not in this object"
+                         if "+" in args.precision else "")
+                      + (" - split-bf16 linears: `achieved` counts MODEL FLOPs (2 M N K per linear, split + activation passes in its "
+                         "time); the kernel executes 3x that in bf16 MFMAs" if args.precision == "x3" else ""),
             "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
             "traffic": traffic, "traffic_unit": "bytes per GEMM launch (fabric side: 2*FETCH_SIZE + WRITE_SIZE)",
             "traffic_source": traffic_src, "pmc_in_run_error": pmc_error,

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RVLM_VERSION 107
+#define RVLM_VERSION 108
 
 typedef void* rvlm_stream_t; /* hipStream_t */
 typedef struct rvlm_vit rvlm_vit;
@@ -38,7 +38,10 @@ typedef enum {
     RVLM_ERR_UNSUPPORTED = 4  /* configuration the kernels do not cover */
 } rvlm_status;
 
-enum { RVLM_PREC_F32 = 0, RVLM_PREC_BF16 = 1 };       /* GEMM/attention operand precision */
+/* GEMM / attention operand precision.  RVLM_PREC_F32X3 (ABI 108): fp32 storage and fp32 LayerNorm / softmax / attention products
+ * like RVLM_PREC_F32, the encoder's linears as split-bf16 products (a_hi w_hi + a_hi w_lo + a_lo w_hi, fp32 accumulate) on the
+ * bf16 matrix pipe: ~16 mantissa bits at 3 bf16 MFMAs per product (robustvlm_amd/csrc/x3_kernels.hip); attack / inference only */
+enum { RVLM_PREC_F32 = 0, RVLM_PREC_BF16 = 1, RVLM_PREC_F32X3 = 2 };
 enum { RVLM_ACT_QUICK_GELU = 0, RVLM_ACT_GELU = 1 };  /* open_clip QuickGELU / exact erf GELU */
 enum { RVLM_LOSS_L2 = 0, RVLM_LOSS_CE = 1,             /* FARE l2 / TeCoA ce (…clip.py:495-528) */
        RVLM_LOSS_DLR = 2, RVLM_LOSS_DLR_TARGETED = 3 }; /* AutoAttack DLR losses (autopgd_base.py:195-201, 613-618) */

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.abspath(os.environ["RVLM_LIB_PATH"]) if os.environ.get("RVLM_LIB_PATH") else os.path.join(_HERE, "librvlm.so")
 
 RVLM_OK, RVLM_ERR_ARG, RVLM_ERR_HIP, RVLM_ERR_STATE, RVLM_ERR_UNSUPPORTED = 0, 1, 2, 3, 4
-PREC_F32, PREC_BF16 = 0, 1
+PREC_F32, PREC_BF16, PREC_F32X3 = 0, 1, 2
 ACT_QUICK_GELU, ACT_GELU = 0, 1
 LOSS_L2, LOSS_CE, LOSS_DLR, LOSS_DLR_TARGETED = 0, 1, 2, 3
 RED_MEAN, RED_NONE = 0, 1

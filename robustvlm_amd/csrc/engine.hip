@@ -32,6 +32,9 @@ struct rvlm_vit {
     rvlm_vit_config cfg;
     int S, G, W, L, H, D, P, img, Kp, Kpad, maxB, Mp, Mp0;
     bool bf16;
+    bool x3 = false;     // fp32 storage, split-bf16 linears (RVLM_PREC_F32X3, csrc/x3_kernels.hip): w_*_nk / w_*_t hold [N, 3K] / [K, 3N]
+    bf16_t* a3 = nullptr;        // x3: [Mp, 3 * 4W] bf16, the split copy [hi | hi | lo] of the linear in front of the GEMM
+    const void* a3_of = nullptr; // x3: the fp32 buffer whose split a3 ALREADY holds (written by the fused activation + split pass)
     size_t esz;  // activation element size
     std::vector<Layer> layers;
     float *cls, *pos, *proj, *lnpre_w, *lnpre_b, *lnpost_w, *lnpost_b, *conv_f32;
@@ -189,6 +192,18 @@ static int load_weights(rvlm_vit* h, const rvlm_vit_weights* w, hipStream_t s, b
             CP(y.w_out, b.attn_out_proj_weight, (size_t)W * W);
             CP(y.w_fc, b.mlp_c_fc_weight, (size_t)4 * W * W);
             CP(y.w_proj, b.mlp_c_proj_weight, (size_t)4 * W * W);
+            if (h->x3) {      // [W_hi | W_lo | W_hi] and the same of W^T, from the device copies just made
+                struct { bf16_t **nk, **t; const float* src; int rows, cols; } ws[4] = {
+                    {&y.w_in_nk, &y.w_in_t, b.attn_in_proj_weight, 3 * W, W}, {&y.w_out_nk, &y.w_out_t, b.attn_out_proj_weight, W, W},
+                    {&y.w_fc_nk, &y.w_fc_t, b.mlp_c_fc_weight, 4 * W, W}, {&y.w_proj_nk, &y.w_proj_t, b.mlp_c_proj_weight, W, 4 * W}};
+                for (auto& q : ws) {
+                    if (alloc) {
+                        if ((rc = dev_alloc(h, (void**)q.nk, (size_t)q.rows * q.cols * 6, false))) return rc;
+                        if ((rc = dev_alloc(h, (void**)q.t, (size_t)q.rows * q.cols * 6, false))) return rc;
+                    }
+                    if ((rc = x3_prepare_weight(q.src, q.rows, q.cols, *q.nk, *q.t, s))) return rc;
+                }
+            }
         }
     }
 #undef CP
@@ -204,6 +219,11 @@ template <typename T>
 static int linear_fwd(rvlm_vit* h, hipStream_t s, const void* A, long lda, int M, int N, int K,
                       const float* w_f32, const bf16_t* w_nk, const float* bias, int epi, void* out, long ldo,
                       void* out_pre, const float* residual, int a_rows = 0);
+// x3 mode: the encoder linears whose shapes the persistent bf16 GEMM takes (everything else - the patch embedding with its
+// K = 3 P^2, tiny test models - stays on the fp32 tiles)
+static inline bool x3_takes(const rvlm_vit* h, int M, int N, int K) {
+    return h->x3 && h->a3 && M >= 256 && N % 256 == 0 && K % 128 == 0 && (long)round_up(M, 256) * 3 * K * 2 < (1L << 31);
+}
 template <>
 int linear_fwd<bf16_t>(rvlm_vit* h, hipStream_t s, const void* A, long lda, int M, int N, int K,
                        const float*, const bf16_t* w_nk, const float* bias, int epi, void* out, long ldo,
@@ -217,8 +237,32 @@ int linear_fwd<bf16_t>(rvlm_vit* h, hipStream_t s, const void* A, long lda, int 
 }
 template <>
 int linear_fwd<float>(rvlm_vit* h, hipStream_t s, const void* A, long lda, int M, int N, int K,
-                      const float* w_f32, const bf16_t*, const float* bias, int epi, void* out, long ldo,
+                      const float* w_f32, const bf16_t* w_nk, const float* bias, int epi, void* out, long ldo,
                       void* out_pre, const float* residual, int) {
+    if (x3_takes(h, M, N, K) && w_nk) {
+        // split-bf16: A3 = [A_hi | A_hi | A_lo] against W3 = [W_hi | W_lo | W_hi] - one bf16 GEMM of contraction length 3 K with an
+        // fp32 epilogue; the activation (fc1) runs as its own pass over the fp32 pre-activation
+        int rc = RVLM_OK;
+        if (h->a3_of != A && (rc = x3_split_rows((const float*)A, lda, h->a3, M, (int)round_up(M, 256), K, s))) return rc;
+        h->a3_of = nullptr;
+        const bool act = epi == EPI_BF16_ACT;
+        GemmBf16 g;
+        g.A = h->a3; g.lda = 3L * K; g.Bw = w_nk; g.ldb = 3L * K; g.M = M; g.N = N; g.K = 3 * K;
+        g.a_rows = (int)round_up(M, 256); g.bias = bias; g.residual = residual;
+        g.epi = residual ? EPI_F32_RESID : EPI_F32;
+        g.out = (act && out_pre) ? out_pre : out; g.ldo = ldo; g.act = h->cfg.act;
+        with_scratch(h, g);
+        if ((rc = gemm_bf16_nt(g, s))) return rc;
+        if (act) {
+            // act(h) goes straight into the split copy the next linear (fc2: A = `out`, K = N) reads; `out` itself is not written
+            // (its only other reader is the weight gradient, which this precision does not have)
+            const bool fuse = x3_takes(h, M, 256, N);
+            if ((rc = x3_act((const float*)g.out, ldo, (float*)out, ldo, fuse ? h->a3 : nullptr, M, (int)round_up(M, 256), N, h->cfg.act, 0, s)))
+                return rc;
+            if (fuse) h->a3_of = out;
+        }
+        return RVLM_OK;
+    }
     GemmF32 g;
     g.A = (const float*)A; g.sam = lda; g.sak = 1;
     g.B = w_f32; g.sbn = K; g.sbk = 1;
@@ -245,8 +289,25 @@ int linear_dgrad<bf16_t>(rvlm_vit* h, hipStream_t s, const void* dY, long lddy, 
 }
 template <>
 int linear_dgrad<float>(rvlm_vit* h, hipStream_t s, const void* dY, long lddy, int M, int N, int K,
-                        const float* w_f32, long ldw, const bf16_t*, int epi, void* out, long ldo,
+                        const float* w_f32, long ldw, const bf16_t* w_t, int epi, void* out, long ldo,
                         const void* h_pre, int) {
+    if (x3_takes(h, M, K, N) && w_t) {      // out[M, K] = dY[M, N] W[N, K]: contraction over N, B operand = [W^T_hi | W^T_lo | W^T_hi]
+        int rc = RVLM_OK;
+        if (h->a3_of != dY && (rc = x3_split_rows((const float*)dY, lddy, h->a3, M, (int)round_up(M, 256), N, s))) return rc;
+        h->a3_of = nullptr;
+        GemmBf16 g;
+        g.A = h->a3; g.lda = 3L * N; g.Bw = w_t; g.ldb = 3L * N; g.M = M; g.N = K; g.K = 3 * N;
+        g.a_rows = (int)round_up(M, 256); g.epi = EPI_F32; g.out = out; g.ldo = ldo; g.act = h->cfg.act;
+        with_scratch(h, g);
+        if ((rc = gemm_bf16_nt(g, s))) return rc;
+        if (epi == EPI_BF16_DACT) {      // out * act'(h): straight into the split copy the next dgrad (fc1: dY = `out`) reads
+            const bool fuse = x3_takes(h, M, 256, K);
+            if ((rc = x3_act((const float*)h_pre, ldo, (float*)out, ldo, fuse ? h->a3 : nullptr, M, (int)round_up(M, 256), K, h->cfg.act, 1, s)))
+                return rc;
+            if (fuse) h->a3_of = out;
+        }
+        return RVLM_OK;
+    }
     GemmF32 g;
     g.A = (const float*)dY; g.sam = lddy; g.sak = 1;
     g.B = w_f32; g.sbn = 1; g.sbk = ldw;          // (n = k_out, k = n_in) at n_in*ldw + k_out
@@ -254,6 +315,16 @@ int linear_dgrad<float>(rvlm_vit* h, hipStream_t s, const void* dY, long lddy, i
     g.M = M; g.N = K; g.K = N;
     if (epi == EPI_BF16_DACT) { g.dact_h = (const float*)h_pre; g.dact_kind = h->cfg.act; }
     return gemm_f32(g, s);
+}
+
+// x3 mode: the LayerNorm in front of a linear writes that linear's split operand itself (a3_of = the fp32 buffer the linear will be
+// handed, which is then never written: its only other reader is the weight gradient, which this precision does not have)
+static bool ln_into_split(rvlm_vit* h, hipStream_t s, const float* x, const float* gamma, const float* beta, const void* ln_out,
+                          float* mean, float* rstd, int M, int N_next) {
+    if (!x3_takes(h, M, N_next, h->W)) return false;
+    if (!x3_layernorm_fwd(x, h->W, gamma, beta, h->a3, mean, rstd, M, (int)round_up(M, 256), h->W, s)) return false;
+    h->a3_of = ln_out;
+    return true;
 }
 
 // ---- attention (dispatch on precision) -------------------------------------------------------
@@ -418,6 +489,8 @@ static int forward_impl(rvlm_vit* h, const float* x, const float* delta, int B, 
         void* gact = save == 2 ? h->g_act_l[l] : h->g_act;
         {
             PROF("layernorm_fwd", 0, (double)M * W * (4 + sizeof(T)));
+            if (ln_into_split(h, s, x_in, y.ln1_w, y.ln1_b, ln1o, h->mean_at(1 + 2 * l), h->rstd_at(1 + 2 * l), M, 3 * W)) {}
+            else
             if ((rc = layernorm_fwd<T>(x_in, W, y.ln1_w, y.ln1_b, (T*)ln1o, W, h->mean_at(1 + 2 * l),
                                        h->rstd_at(1 + 2 * l), M, W, s))) return rc;
         }
@@ -460,6 +533,8 @@ static int forward_impl(rvlm_vit* h, const float* x, const float* delta, int B, 
         }
         {
             PROF("layernorm_fwd", 0, (double)M * W * (4 + sizeof(T)));
+            if (ln_into_split(h, s, x_mid, y.ln2_w, y.ln2_b, ln2o, h->mean_at(2 + 2 * l), h->rstd_at(2 + 2 * l), M, 4 * W)) {}
+            else
             if ((rc = layernorm_fwd<T>(x_mid, W, y.ln2_w, y.ln2_b, (T*)ln2o, W, h->mean_at(2 + 2 * l),
                                        h->rstd_at(2 + 2 * l), M, W, s))) return rc;
         }
@@ -831,13 +906,17 @@ extern "C" int rvlm_vit_create(const rvlm_vit_config* cfg, const rvlm_vit_weight
     RVLM_REQUIRE(cfg->patch > 0 && cfg->image_size % cfg->patch == 0, "rvlm_vit_create: image_size % patch");
     RVLM_REQUIRE(cfg->heads > 0 && cfg->width == cfg->heads * 64, "rvlm_vit_create: head_dim must be 64");
     RVLM_REQUIRE(cfg->layers > 0 && cfg->out_dim > 0 && cfg->max_batch > 0, "rvlm_vit_create: sizes");
-    RVLM_REQUIRE(cfg->precision == RVLM_PREC_F32 || cfg->precision == RVLM_PREC_BF16, "rvlm_vit_create: precision");
+    RVLM_REQUIRE(cfg->precision == RVLM_PREC_F32 || cfg->precision == RVLM_PREC_BF16 || cfg->precision == RVLM_PREC_F32X3,
+                 "rvlm_vit_create: precision");
+    RVLM_REQUIRE(cfg->precision != RVLM_PREC_F32X3 || cfg->trainable <= 0, "rvlm_vit_create: the split-bf16 mode is an attack / inference "
+                 "precision (no weight gradients)");
     RVLM_REQUIRE(cfg->act == RVLM_ACT_QUICK_GELU || cfg->act == RVLM_ACT_GELU, "rvlm_vit_create: act");
     RVLM_REQUIRE(cfg->width <= 2048, "rvlm_vit_create: width > 2048 unsupported");
     hipStream_t s = (hipStream_t)stream;
     rvlm_vit* h = new rvlm_vit();
     h->cfg = *cfg;
     h->bf16 = cfg->precision == RVLM_PREC_BF16;
+    h->x3 = cfg->precision == RVLM_PREC_F32X3;
     h->esz = h->bf16 ? 2 : 4;
     h->img = cfg->image_size; h->P = cfg->patch; h->G = h->img / h->P; h->S = h->G * h->G + 1;
     h->W = cfg->width; h->L = cfg->layers; h->H = cfg->heads; h->D = cfg->out_dim;
@@ -853,6 +932,10 @@ extern "C" int rvlm_vit_create(const rvlm_vit_config* cfg, const rvlm_vit_weight
 #define ALLOC_OR_DIE(ptr, bytes) do { rc = dev_alloc(h, (void**)&(ptr), (bytes)); if (rc) { rvlm_vit_destroy(h); return rc; } } while (0)
     ALLOC_OR_DIE(h->A0, Mp0 * h->Kpad * e);
     ALLOC_OR_DIE(h->patch_out, Mp0 * W * 4);
+    if (h->x3 && W % 256 == 0) {      // split copy of a linear's input: up to [Mp, 3 * 4W] bf16 (0.8 GB for ViT-L/14 at B = 128)
+        rc = dev_alloc(h, (void**)&h->a3, Mp * 12 * W * 2, false);
+        if (rc) { rvlm_vit_destroy(h); return rc; }
+    }
     const bool inference_only = cfg->trainable < 0;   // no backward of any kind: one slot per buffer kind
     h->inference_only = inference_only;
     h->xs.resize(2 * L + 1);

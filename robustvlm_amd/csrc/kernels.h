@@ -164,6 +164,12 @@ int transpose_pad(const T* in, long ldi, int R, int C, T* out, long ldo, int Rp,
 // [splits][C][Kc] token chunks (optionally emitting the bias gradient = column sums); batched persistent GEMM + reduce
 int wgrad_split_plan(int M, int N, int K, size_t slab_bytes, int* splits, int* Kc);
 size_t wgrad_slab_bytes(int N, int K);
+// split-bf16 ("x3") linears of the fp32-storage engine (x3_kernels.hip)
+int x3_split_rows(const float* A, long lda, bf16_t* A3, int M, int rows_out, int K, hipStream_t s);
+int x3_prepare_weight(const float* src, int rows, int cols, bf16_t* nk3, bf16_t* t3, hipStream_t s);
+bool x3_layernorm_fwd(const float* x, long ldx, const float* gamma, const float* beta, bf16_t* A3, float* mean, float* rstd, int M,
+                      int rows_out, int W, hipStream_t s);
+int x3_act(const float* hbuf, long ldh, float* out, long ldo, bf16_t* A3, int M, int rows_out, int N, int act, int mode, hipStream_t s);
 int transpose_split(const bf16_t* in, long ldi, int R, int C, bf16_t* out, int Kc, int splits, float* dbias,
                     int accumulate, float* red, size_t red_floats, hipStream_t s);
 // the same from the operands AS THEY LIE (dY [M, N] ld lddy, X [M, K] ld ldx, token-major): no transposed copies

@@ -28,7 +28,11 @@ class VitEngine:
     gradient-free forwards (``save=False``: the clean embedding FARE's loss is measured against) run there too, everything
     else in bf16.  Why: FARE's first cotangent 2 (phi(x + d0) - phi(x)) is a difference of nearly equal embeddings and
     one part bf16 rounding noise in three; with one fp32 iteration the attack takes the
-    reference's first step (gradient-sign agreement 0.82 -> 0.9999) at the price of one fp32 iteration per call."""
+    reference's first step (gradient-sign agreement 0.82 -> 0.9999) at the price of one fp32 iteration per call.
+    'x3' (round 6): fp32 storage, LayerNorm, softmax and attention products like 'fp32', the encoder's LINEARS as split-bf16
+    products (a_hi w_hi + a_hi w_lo + a_lo w_hi, fp32 accumulate: ~16 mantissa bits) on the bf16 matrix pipe -
+    embeddings within ~1e-5 of the fp32 mode's at a third of its time; 'bf16+x3-first' = the mixed mode with that handle
+    for the first iteration and the clean embedding (oracle/split_bf16_emulation.py: first-step sign agreement 0.9996)."""
 
     def __init__(self, cfg, state_dict: dict, precision: str = "bf16", max_batch: int = 128,
                  mean=CLIP_MEAN, std=CLIP_STD, device=None, trainable: bool = False,
@@ -52,12 +56,14 @@ class VitEngine:
         c.image_size, c.patch, c.width, c.layers = cfg.image_size, cfg.patch, cfg.width, cfg.layers
         c.heads, c.out_dim = cfg.heads, cfg.out_dim
         c.act = L.ACT_QUICK_GELU if cfg.act == "quick_gelu" else L.ACT_GELU
-        if precision not in ("bf16", "fp32", "bf16+fp32-first"):
+        if precision not in ("bf16", "fp32", "x3", "bf16+fp32-first", "bf16+x3-first"):
             raise ValueError(f"precision {precision!r} not supported")
-        self.mixed = precision == "bf16+fp32-first"
+        self.mixed = precision in ("bf16+fp32-first", "bf16+x3-first")
         if self.mixed and (trainable or inference_only):
-            raise ValueError("precision 'bf16+fp32-first' is an attack-engine option (not trainable / inference_only)")
-        c.precision = L.PREC_F32 if precision == "fp32" else L.PREC_BF16
+            raise ValueError(f"precision {precision!r} is an attack-engine option (not trainable / inference_only)")
+        if precision == "x3" and trainable:
+            raise ValueError("precision 'x3' is an attack / inference precision (no weight gradients)")
+        c.precision = L.PREC_F32 if precision == "fp32" else L.PREC_F32X3 if precision == "x3" else L.PREC_BF16
         self._h32 = C.c_void_p()
         c.max_batch = self.max_batch
         c.trainable = 1 if trainable else (-1 if inference_only else 0)
@@ -69,7 +75,7 @@ class VitEngine:
             L.check(self.lib.rvlm_vit_create(C.byref(c), C.byref(w), L.stream_ptr(), C.byref(self._h)),
                     "rvlm_vit_create")
             if self.mixed:
-                c.precision = L.PREC_F32
+                c.precision = L.PREC_F32X3 if precision == "bf16+x3-first" else L.PREC_F32
                 L.check(self.lib.rvlm_vit_create(C.byref(c), C.byref(w), L.stream_ptr(), C.byref(self._h32)),
                         "rvlm_vit_create (fp32 handle)")
         del keep

@@ -721,3 +721,50 @@ def test_mixed_precision_engine_is_an_attack_option_only():
     assert mixed.workspace_bytes() == e32.workspace_bytes() + e16.workspace_bytes()
     for e in (mixed, e32, e16):
         e.close()
+
+
+# ---- split-bf16 ("x3") precision (round 6; csrc/x3_kernels.hip) -----------------------------------------------------------
+VIT_X3 = V.VitConfig(64, 8, 1024, 3, 16, 64)          # width 1024, 65 tokens: B = 8 -> 520 rows, every encoder linear takes the x3 GEMM
+
+
+@pytest.mark.parametrize("act", ["quick_gelu", "gelu"])
+def test_x3_engine_vs_oracle_and_fp32_engine(act):
+    """precision='x3': fp32 storage, the encoder's linears as a_hi w_hi + a_hi w_lo + a_lo w_hi on the bf16 matrix pipe (one
+    GEMM of contraction length 3K).  Against the fp32 oracle: embeddings and input gradients to ~1e-5 (the fp32 engine: 1e-6,
+    the bf16 engine: 2e-3) - the bar oracle/split_bf16_emulation.py predicts for 16 mantissa bits."""
+    cfg = V.VitConfig(VIT_X3.image_size, VIT_X3.patch, VIT_X3.width, VIT_X3.layers, VIT_X3.heads, VIT_X3.out_dim, act)
+    w = V.init_weights(cfg, seed=4)
+    ref = V.ClipVisionModelRef(cfg, w).eval()
+    B = 8
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(B, 3, cfg.image_size, cfg.image_size, generator=g)
+    cot = torch.randn(B, cfg.out_dim, generator=g)
+    xr = x.clone().requires_grad_(True)
+    e_ref = ref(xr, False)
+    (g_ref,) = torch.autograd.grad((e_ref * cot).sum(), xr)
+    out = {}
+    for prec in ("x3", "fp32", "bf16"):
+        eng = make_engine(cfg, w, prec, max_batch=B)
+        emb = eng.forward(x.to(dev()), None, False, save=True)
+        gx = eng.backward_input(cot.to(dev()))
+        torch.cuda.synchronize()
+        out[prec] = (rel_max(emb.cpu(), e_ref.detach()), rel_max(gx.cpu(), g_ref))
+        if prec == "x3":     # the linears really ran on the bf16 GEMM families (this small M: split-K slabs / 128-row tiles too)
+            assert L.load().rvlm_k_gemm_last_kernels() & (1 | 4 | 16), "x3 linears must run on the bf16 matrix pipe"
+        eng.close()
+    assert out["x3"][0] < 5e-5 and out["x3"][1] < 2e-4, out
+    assert out["x3"][0] < 0.05 * out["bf16"][0] and out["x3"][1] < 0.05 * out["bf16"][1], out
+    assert out["fp32"][0] < 1e-5, out
+
+
+def test_x3_falls_back_to_the_fp32_tiles_on_small_shapes():
+    """Shapes the persistent GEMM does not take (tiny test models, < 256 rows) stay on the fp32 matrix-pipe tiles: bit-identical
+    with the fp32 engine; x3 refuses to be trainable."""
+    cfg = V.VIT_TINY2
+    w = V.init_weights(cfg, seed=1)
+    x = torch.rand(3, 3, cfg.image_size, cfg.image_size, generator=torch.Generator().manual_seed(0)).to(dev())
+    e3, e32 = make_engine(cfg, w, "x3", 4), make_engine(cfg, w, "fp32", 4)
+    assert torch.equal(e3.forward(x, None, True), e32.forward(x, None, True))
+    e3.close(); e32.close()
+    with pytest.raises(ValueError, match="no weight gradients"):
+        R.VitEngine(to_cfg(cfg), {k: v.to(dev()) for k, v in w.items()}, precision="x3", max_batch=4, trainable=True)
