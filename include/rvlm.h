@@ -380,7 +380,7 @@ int rvlm_version(void);   /* = RVLM_VERSION.  101: rvlm_loss_spec.y_target, rvlm
                            * rvlm_project_perturbation, rvlm_normalize_grad; 104: rvlm_preproc_run_batch, rvlm_ce_logits takes B = 1,
                            * rvlm_vit_backward_params_stages refuses out-of-order stages; 105: rvlm_apgd_controller_rho,
                            * rvlm_vit_set_apgd_rho, rvlm_comm_* / rvlm_allreduce_grads; 106: rvlm_pgd_run_mixed, fp32 mode on v_mfma_f32_32x32x2_f32;
-                           * 107: rvlm_l2_random_start */
+                           * 107: rvlm_l2_random_start; 108: RVLM_PREC_F32X3 (split-bf16 linears over fp32 storage) */
 
 #ifdef __cplusplus
 }

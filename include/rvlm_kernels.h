@@ -31,6 +31,9 @@ int rvlm_k_gemm_f32_ex(const float* A, long sam, long sak, long sab, const float
 /* 1: the VALU fmaf-chain tiles for every later fp32 GEMM instead of the v_mfma_f32_32x32x2_f32 tiles (the two are
  * bit-identical: both evaluate every output element as the k-ordered fp32 fma chain); 0: default */
 int rvlm_k_gemm_f32_set_valu(int on);
+/* fp32 attention path: in-place row softmax of s (backward = 0), or ds = p * (ds - sum(p * ds)) * scale in place (backward = 1);
+ * rows of `cols` values, `ld` floats apart */
+int rvlm_k_softmax_rows(const float* p, float* s, long rows, int cols, int ld, float scale, int backward, rvlm_stream_t stream);
 /* bf16 flash attention on packed qkv [B*S, 3W] (head_dim 64); lse2 [B*H*round_up(S,32)] */
 int rvlm_k_attn_fwd_bf16(const uint16_t* qkv, uint16_t* o, float* lse2, int B, int H, int S,
                          rvlm_stream_t stream);

@@ -274,6 +274,10 @@ extern "C" int rvlm_k_gemm_f32_ex(const float* A, long sam, long sak, long sab, 
     g.bias = bias; g.act = act; g.C_pre = C_pre; g.dact_h = dact_h; g.residual = residual;
     return gemm_f32(g, (hipStream_t)stream);
 }
+extern "C" int rvlm_k_softmax_rows(const float* p, float* s, long rows, int cols, int ld, float scale, int backward,
+                                   rvlm_stream_t stream) {
+    return backward ? softmax_rows_bwd(p, s, rows, cols, ld, scale, (hipStream_t)stream) : softmax_rows_fwd(s, rows, cols, ld, (hipStream_t)stream);
+}
 extern "C" int rvlm_k_gemm_f32_set_valu(int on) { gemm_f32_set_valu(on); return RVLM_OK; }
 extern "C" int rvlm_k_attn_fwd_bf16(const uint16_t* qkv, uint16_t* o, float* lse2, int B, int H, int S,
                                     rvlm_stream_t stream) {

@@ -600,12 +600,86 @@ softmax_bwd_kernel(const float* __restrict__ p, float* __restrict__ dp, long row
     dot = wave_sum(dot);
     for (int c = lane; c < cols; c += 64) dr[c] = pr[c] * (dr[c] - dot) * scale;
 }
+// Rows of 257 .. 260 columns (S = 257: the ViT-L/14 and ViT-B/16 score matrices, ld = 260), round 6: every element is read ONCE
+// (16 bytes per lane: lane l holds columns 4 l .. 4 l + 3, lane 0 also the tail 256 .. 259) and written once, four rows per wave with
+// their loads in flight together.  The kernels above walk a row three times through memory with 4-byte accesses: 470 / 405 us per
+// launch on the [526 336, 260] matrices of ViT-L/14 at B = 128, 11 % of the fp32 / split-bf16 engines' step (profiles/
+// r06_x3_kernel_stats.csv).  Same arithmetic per element; the row sums associate differently from the generic kernels' (a lane
+// holds 4 consecutive columns instead of columns l, l + 64, ..: fp32, ~1 ulp of the row sum - like layernorm_fwd8 above).
+template <bool BWD>
+__global__ void __launch_bounds__(256)
+softmax257_kernel(const float* __restrict__ p, float* __restrict__ s, long rows, int cols, int ld, float scale) {
+    constexpr int R = 4;
+    const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+    const int lane = threadIdx.x & 63;
+    if (row0 >= rows) return;
+    float4 v[R], t[R], q[R], u[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const long row = min(row0 + r, rows - 1);
+        float* sr = s + row * ld;
+        v[r] = *(const float4*)(sr + 4 * lane);
+        t[r] = lane == 0 ? *(const float4*)(sr + 256) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (BWD) {
+            const float* pr = p + row * ld;
+            q[r] = *(const float4*)(pr + 4 * lane);
+            u[r] = lane == 0 ? *(const float4*)(pr + 256) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    const int ntail = cols - 256;      // 1 .. 4 valid tail columns (lane 0)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (row0 + r >= rows) break;
+        float* sr = s + (row0 + r) * ld;
+        float a[4] = {v[r].x, v[r].y, v[r].z, v[r].w}, b[4] = {t[r].x, t[r].y, t[r].z, t[r].w};
+        if (!BWD) {
+            float m = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
+            if (lane == 0)
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) if (e < ntail) m = fmaxf(m, b[e]);
+            m = wave_max(m);
+            float sum = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a[e] = expf(a[e] - m); sum += a[e]; }
+            if (lane == 0)
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) if (e < ntail) { b[e] = expf(b[e] - m); sum += b[e]; }
+            sum = wave_sum(sum);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] = a[e] / sum;
+            if (lane == 0)
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) if (e < ntail) b[e] = b[e] / sum;
+        } else {
+            const float pa[4] = {q[r].x, q[r].y, q[r].z, q[r].w}, pb[4] = {u[r].x, u[r].y, u[r].z, u[r].w};
+            float dot = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dot = fmaf(pa[e], a[e], dot);
+            if (lane == 0)
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) if (e < ntail) dot = fmaf(pb[e], b[e], dot);
+            dot = wave_sum(dot);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] = pa[e] * (a[e] - dot) * scale;
+            if (lane == 0)
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) if (e < ntail) b[e] = pb[e] * (b[e] - dot) * scale;
+        }
+        *(float4*)(sr + 4 * lane) = make_float4(a[0], a[1], a[2], a[3]);
+        if (lane == 0)
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) if (e < ntail) sr[256 + e] = b[e];
+    }
+}
+static bool softmax257_ok(const void* a, const void* b, int cols, int ld) {
+    return cols > 256 && cols <= 260 && ld >= 260 && ld % 4 == 0 && (((size_t)a | (size_t)b) & 15) == 0;
+}
 int softmax_rows_fwd(float* s, long rows, int cols, int ld, hipStream_t st) {
+    if (softmax257_ok(s, s, cols, ld))
+        hipLaunchKernelGGL((softmax257_kernel<false>), dim3(cdiv(rows, 16)), dim3(256), 0, st, nullptr, s, rows, cols, ld, 1.0f);
+    else
     hipLaunchKernelGGL(softmax_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, s, rows, cols, ld);
     RVLM_CHECK_LAUNCH();
     return RVLM_OK;
 }
 int softmax_rows_bwd(const float* p, float* dp, long rows, int cols, int ld, float scale, hipStream_t st) {
+    if (softmax257_ok(p, dp, cols, ld))
+        hipLaunchKernelGGL((softmax257_kernel<true>), dim3(cdiv(rows, 16)), dim3(256), 0, st, p, dp, rows, cols, ld, scale);
+    else
     hipLaunchKernelGGL(softmax_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, p, dp, rows, cols, ld,
                        scale);
     RVLM_CHECK_LAUNCH();

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     for sym in declared:
         assert hasattr(lib, sym), f"{sym} declared in include/ but not exported by librvlm.so"
     assert declared == set(L.EXPORTED_SYMBOLS), declared ^ set(L.EXPORTED_SYMBOLS)
-    assert lib.rvlm_version() == 107
+    assert lib.rvlm_version() == 108
 
 
 def test_product_path_fails_loudly_without_gpu():

@@ -593,3 +593,31 @@ def test_config2_x3_first_iteration(setup):
         assert same_mixed > 0.90, same_mixed
     finally:
         eng.close(); eng3.close()
+
+
+def test_clip_like_x3_vs_reference(setup_clip):
+    """The split-bf16 precision on the CLIP-like tower (outlier channels 30-100x, LayerNorm gains over 2.5 decades): the x3 engine
+    alone against the reference's pgd() on the 8-image slice, and its first-iteration gradient signs against the reference's."""
+    s = setup_clip
+    n = s["n"]
+    w = V.init_weights(s["cfg"], seed=3, clip_like=True)
+    eng3 = R.VitEngine(to_cfg(s["cfg"]), {k: v.to(dev()) for k, v in w.items()}, precision="x3", max_batch=n)
+    try:
+        x, d0 = s["x"][:n].to(dev()), s["d0"][:n].to(dev())
+        m3 = R.ClipVisionModel(eng3).eval()
+        e0 = m3(x, False)
+        emb_rel = rel(e0.cpu(), torch.from_numpy(GOLDC["pgd_e0"]))
+        xa = R.pgd(m3, R.ComputeLossWrapper(e0, None, "mean", "l2", 100.), x, None, "linf", EPS, 10, STEP, False,
+                   perturbation=d0.clone(), mode="max")
+        same = float((xa.cpu() == torch.from_numpy(GOLDC["pgd_x_adv"])).float().mean())
+        ns = int(GOLDC["traj_n"])
+        _, per, _, g = eng3.fwd_inputgrad(x, d0, "l2", "mean", e0, None, False)
+        sg = GOLDC["traj_grad_sign"][0]
+        sign0 = float(np.mean((np.sign(g[:ns].cpu().numpy()) == sg)[sg != 0]))
+        record("clip_like_x3", same_pixels_x3_vs_reference=same, sign_agree_it0_x3_vs_reference=sign0, emb_rel_x3_vs_reference=emb_rel,
+               loss_ratio_it0=float((per[:ns].cpu().numpy() / GOLDC["traj_loss"][0]).mean()))
+        assert emb_rel < 1e-4, emb_rel
+        assert sign0 > 0.995, sign0
+        assert same > 0.97, same
+    finally:
+        eng3.close()

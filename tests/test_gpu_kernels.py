@@ -518,3 +518,28 @@ def test_gemm_bf16_headline_shapes_production_dispatch(name, N, K, epi):
     if epi in (0, 2, 3):
         ref_t = acc[tail] if epi == 0 else (act_ref(acc[tail], 0) if epi == 2 else acc[tail] * hp[tail].double())
         assert rel_max(out[tail].float(), ref_t) < 1.5e-2
+
+
+@pytest.mark.parametrize("cols,ld", [(257, 260), (258, 260), (260, 264), (50, 52), (577, 580)])
+def test_softmax_rows_fp32(cols, ld):
+    """Row softmax of the fp32 attention path and its backward (round 6: S = 257 rows take a single-pass kernel with 16-byte
+    accesses, lane 0 carrying the 1-4 tail columns; other widths the generic three-pass kernel) against torch fp64; pad
+    columns cols .. ld - 1 must stay untouched."""
+    l = lib()
+    rows = 4 * 16 * 3 + 5            # not a multiple of the 16 rows a workgroup takes
+    g = torch.Generator(device=dev()).manual_seed(cols)
+    s = torch.randn(rows, ld, generator=g, device=dev()) * 3
+    s[:, cols:] = 777.0
+    ref = torch.softmax(s[:, :cols].double(), dim=-1)
+    p = s.clone()
+    L.check(l.rvlm_k_softmax_rows(None, p.data_ptr(), rows, cols, ld, 1.0, 0, st()))
+    torch.cuda.synchronize()
+    assert float((p[:, :cols].double() - ref).abs().max()) < 5e-7, float((p[:, :cols].double() - ref).abs().max())
+    assert bool((p[:, cols:] == 777.0).all())
+    dp = torch.randn(rows, ld, generator=g, device=dev())
+    dp[:, cols:] = 555.0
+    want = ref * (dp[:, :cols].double() - (ref * dp[:, :cols].double()).sum(-1, keepdim=True)) * 0.125
+    L.check(l.rvlm_k_softmax_rows(p.data_ptr(), dp.data_ptr(), rows, cols, ld, 0.125, 1, st()))
+    torch.cuda.synchronize()
+    assert float((dp[:, :cols].double() - want).abs().max()) < 5e-7, float((dp[:, :cols].double() - want).abs().max())
+    assert bool((dp[:, cols:] == 555.0).all())
