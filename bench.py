@@ -438,7 +438,7 @@ def main(extra=None):
             except Exception as e:                    # measurement aid: fall back to the committed passes, flagged as such
                 pmc_error = f"{type(e).__name__}: {e}"[:400]
                 traffic, traffic_src, pmc = None, None, None
-        for tag in ("r05", "r04", "r03", "r02"):
+        for tag in ("r06", "r05", "r04", "r03", "r02"):
             tj = os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_traffic.json")
             if traffic is None and os.path.exists(tj) and headline:
                 try:
@@ -454,7 +454,7 @@ def main(extra=None):
                     traffic = None
         # matrix-pipe utilisation INSIDE this pipeline (not of a cube): rocprofv3 --pmc passes over this same command,
         # summarised per kernel by scripts/pmc_pipeline.sh (counters cannot be read from inside this process either)
-        pj = next((q for q in (os.path.join(ROOT, "profiles", f"{t}_pmc_pipeline.json") for t in ("r05", "r04", "r03")) if os.path.exists(q)), "")
+        pj = next((q for q in (os.path.join(ROOT, "profiles", f"{t}_pmc_pipeline.json") for t in ("r06", "r05", "r04", "r03")) if os.path.exists(q)), "")
         if pj and headline and pmc is None:
             try:
                 kd = json.load(open(pj))["kernels"]

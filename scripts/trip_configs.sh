@@ -10,3 +10,5 @@ run b32 --model ViT-B-32 --steps 5 --warmup 2
 BENCH_SCRIPT=scripts/bench_extra.py run l14_336 --model ViT-L-14-336 --batch 64 --steps 2 --warmup 1 --no-roofline
 run fp32 --precision fp32 --steps 2 --warmup 1 --no-pmc
 run mixed --precision bf16+fp32-first --steps 3 --warmup 1 --no-pmc
+run x3 --precision x3 --steps 2 --warmup 1 --no-pmc
+run mixed_x3 --precision bf16+x3-first --steps 3 --warmup 1 --no-pmc

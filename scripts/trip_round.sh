@@ -21,4 +21,4 @@ find gpurun_out/prof -name "*kernel_trace.csv" -delete 2>/dev/null
 bash scripts/pmc_pipeline.sh > gpurun_out/pmc_pipeline.log 2>&1; tail -2 gpurun_out/pmc_pipeline.log | cut -c1-200
 bash scripts/pmc_traffic.sh > gpurun_out/pmc_traffic.log 2>&1; tail -2 gpurun_out/pmc_traffic.log | cut -c1-200
 bash scripts/trip_configs.sh 2>&1 | cut -c1-250
-( timeout 300 scripts/probes/ln_bwd_bytes_probe.bin 20 ) > gpurun_out/ln_bwd_bytes_probe.log 2>&1; cat gpurun_out/ln_bwd_bytes_probe.log
+
