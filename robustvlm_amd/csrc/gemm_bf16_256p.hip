@@ -33,9 +33,10 @@
 // THIS FILE HOLDS THE MEASURED FORM ONLY (round 5): split roles, fragment reads between the MFMAs, the v_mfma_f32_16x16x32_bf16
 // tile phase, two side-input slots, in-place last phase.  Every A/B arm it was measured against - the 32x32x16 shape, the
 // lockstep and grouped-read schedules, the ablation / wait-sum / timeline instantiations, start stagger, K rotation, static
-// priority, the register-path operand stream - lives in experimental/gemm_bf16_256p_abl.hip, which `make EXPERIMENTAL=1` builds
-// INSTEAD of this file (librvlm_exp.so).  The production kernels of the two files are the same instruction streams (the
-// assembly of the nine instantiations was diffed when this file was cut).
+// priority, the register-path operand stream - lives in experimental/gemm_bf16_256p_abl.patch, a patch over THIS file that
+// `make EXPERIMENTAL=1` applies (-> build_exp/gen/gemm_bf16_256p_abl.hip) and builds INSTEAD of this file (librvlm_exp.so): one
+// source, so a change here reaches the A/B library too or fails its build where an arm no longer fits.  The production kernels
+// of the two are the same instruction streams (the assembly of the nine instantiations was diffed when this file was cut).
 namespace rvlm {
 
 // Contraction-major form: both transposing reads of one fragment - tile t (its pair index XORed into the per-lane base + slot

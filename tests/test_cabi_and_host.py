@@ -35,6 +35,22 @@ def test_library_exports_every_declared_symbol():
     assert lib.rvlm_version() == 108
 
 
+def test_ab_gemm_file_is_generated_from_the_production_file(tmp_path):
+    """The A/B library's persistent GEMM is gemm_bf16_256p.hip + a patch (one source): the patch must apply cleanly."""
+    import shutil
+    import subprocess
+    csrc = os.path.join(ROOT, "robustvlm_amd", "csrc")
+    if not shutil.which("patch"):
+        pytest.skip("no patch(1) here")
+    out = tmp_path / "abl.hip"
+    r = subprocess.run(["patch", "-s", "-o", str(out), os.path.join(csrc, "gemm_bf16_256p.hip"),
+                        os.path.join(csrc, "experimental", "gemm_bf16_256p_abl.patch")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    text = out.read_text()
+    assert "launch_256p_abl" in text and "P_KNOBS" in text
+    assert not os.path.exists(os.path.join(csrc, "experimental", "gemm_bf16_256p_abl.hip")), "a second copy of the kernel source"
+
+
 def test_product_path_fails_loudly_without_gpu():
     if torch.cuda.is_available():
         pytest.skip("GPU present")
