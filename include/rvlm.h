@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RVLM_VERSION 108
+#define RVLM_VERSION 109
 
 typedef void* rvlm_stream_t; /* hipStream_t */
 typedef struct rvlm_vit rvlm_vit;
@@ -122,6 +122,13 @@ int rvlm_vit_forward(rvlm_vit* h, const float* x, const float* delta, int B, int
 /* grad_x[B,3,H,W] = d<d_emb, emb>/d(x+delta) for the last saved forward (dgrad only, no wgrad). */
 int rvlm_vit_backward_input(rvlm_vit* h, const float* d_emb, int B, float* grad_x,
                             rvlm_stream_t stream);
+/* The same for the forward saved on ANOTHER handle of the same model and max_batch (ABI 109): h_saved holds fp32 storage
+ * (RVLM_PREC_F32 / RVLM_PREC_F32X3), h is a bf16 handle whose backward kernels evaluate the gradient - qkv, attention output and
+ * act'(fc1) are exported to bf16, the fp32 residual stream / LayerNorm statistics are read in place.  For the first FARE iteration
+ * (torch.autograd.grad(loss, perturbation), train/pgd_train.py:38): the forward difference needs the precision, the backward does
+ * not.  Invalidates h's own saved forward. */
+int rvlm_vit_backward_input_from(rvlm_vit* h, rvlm_vit* h_saved, const float* d_emb, int B, float* grad_x,
+                                 rvlm_stream_t stream);
 
 /* Weight gradients of the outer training step (loss_total.backward(), …clip.py:361): for the last
  * forward run with save_for_backward == 2 on a `trainable` handle, writes (accumulate == 0) or adds
@@ -290,6 +297,12 @@ int rvlm_pgd_run_mixed(rvlm_vit* h, rvlm_vit* h_first, int n_first, const float*
                        const rvlm_loss_spec* loss, int norm_kind, float eps, int iterations, float stepsize, float momentum,
                        int mode_max, float* x_adv_out, float* loss_trace, int32_t* flags, rvlm_stream_t stream);
 
+/* rvlm_pgd_run_mixed with the handoff (ABI 109): iterations [0, n_first) evaluate forward + loss on h_first (fp32 storage) and the
+ * input gradient on h's bf16 kernels from h_first's saved forward (rvlm_vit_backward_input_from).  Same max_batch on both. */
+int rvlm_pgd_run_mixed_fwd(rvlm_vit* h, rvlm_vit* h_first, int n_first, const float* x, const float* delta0, int B,
+                           const rvlm_loss_spec* loss, int norm_kind, float eps, int iterations, float stepsize, float momentum,
+                           int mode_max, float* x_adv_out, float* loss_trace, int32_t* flags, rvlm_stream_t stream);
+
 /* APGD L-inf.  x_init: NULL -> start from clamp(x,0,1) (apgd_train) or the caller-provided random
  * start (APGDAttack).  logits_from_head: 0 -> the `argmax(model output)==y` test runs on the
  * embedding (apgd_train quirk); 1 -> on emb @ (logit_scale*T) logits
@@ -380,7 +393,8 @@ int rvlm_version(void);   /* = RVLM_VERSION.  101: rvlm_loss_spec.y_target, rvlm
                            * rvlm_project_perturbation, rvlm_normalize_grad; 104: rvlm_preproc_run_batch, rvlm_ce_logits takes B = 1,
                            * rvlm_vit_backward_params_stages refuses out-of-order stages; 105: rvlm_apgd_controller_rho,
                            * rvlm_vit_set_apgd_rho, rvlm_comm_* / rvlm_allreduce_grads; 106: rvlm_pgd_run_mixed, fp32 mode on v_mfma_f32_32x32x2_f32;
-                           * 107: rvlm_l2_random_start; 108: RVLM_PREC_F32X3 (split-bf16 linears over fp32 storage) */
+                           * 107: rvlm_l2_random_start; 108: RVLM_PREC_F32X3 (split-bf16 linears over fp32 storage);
+                           * 109: rvlm_vit_backward_input_from, rvlm_pgd_run_mixed_fwd (fp32-storage forward, bf16 backward) */
 
 #ifdef __cplusplus
 }

@@ -107,6 +107,32 @@ class StoreGrad(torch.autograd.Function):
         return bf(g)
 
 
+class AttnHandoff(torch.autograd.Function):
+    """Attention core of the handoff: forward = the precise path's (products in `att`, fp32 softmax), backward = the bf16 flash
+    kernel's arithmetic on bf16-ROUNDED q, k, v, O, dO with the probabilities recomputed from the rounded q, k against the
+    PRECISE forward's log-sum-exp (so its rows do not sum to one exactly), D = rowsum(dO * O)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, att, scale):
+        s = prod(q, k.transpose(-1, -2), att) * scale
+        lse = torch.logsumexp(s, dim=-1, keepdim=True)
+        o = prod(torch.exp(s - lse), v, att)
+        ctx.save_for_backward(q, k, v, o, lse)
+        ctx.scale = scale
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse = ctx.saved_tensors
+        qb, kb, vb, ob, dob = bf(q), bf(k), bf(v), bf(o), bf(do)
+        p = torch.exp((qb @ kb.transpose(-1, -2)) * ctx.scale - lse)
+        dv = bf(p).transpose(-1, -2) @ dob
+        dp = dob @ vb.transpose(-1, -2)
+        d = (dob * ob).sum(-1, keepdim=True)
+        ds = bf(p * (dp - d) * ctx.scale)
+        return bf(ds @ kb), bf(ds.transpose(-1, -2) @ qb), bf(dv), None, None
+
+
 def forward(cfg, w, x, lin, att, store_bf16):
     """oracle/vit_ref.py::vit_forward with every GEMM routed through Mat (linears: `lin`, attention products: `att`)."""
     W, H = cfg.width, cfg.heads
@@ -125,9 +151,12 @@ def forward(cfg, w, x, lin, att, store_bf16):
         h = st(F.layer_norm(t, (W,), w[p + "ln_1.weight"], w[p + "ln_1.bias"], 1e-5))
         qkv = st(Mat.apply(h, w[p + "attn.in_proj_weight"].t(), lin) + w[p + "attn.in_proj_bias"])
         q, k, v = (z.reshape(B, N, H, dh).transpose(1, 2) for z in qkv.split(W, dim=-1))
-        s = Mat.apply(q, k.transpose(-1, -2), att) * (1.0 / math.sqrt(dh))
-        pr = torch.softmax(s, dim=-1)
-        a = st(Mat.apply(st(pr) if att == "bf16" or store_bf16 == "grad" else pr, v, att).transpose(1, 2).reshape(B, N, W))
+        if att.endswith("/flash"):
+            a = st(AttnHandoff.apply(q, k, v, att.partition("/")[0], 1.0 / math.sqrt(dh)).transpose(1, 2).reshape(B, N, W))
+        else:
+            s = Mat.apply(q, k.transpose(-1, -2), att) * (1.0 / math.sqrt(dh))
+            pr = torch.softmax(s, dim=-1)
+            a = st(Mat.apply(st(pr) if att == "bf16" or store_bf16 == "grad" else pr, v, att).transpose(1, 2).reshape(B, N, W))
         t = t + Mat.apply(a, w[p + "attn.out_proj.weight"].t(), lin) + w[p + "attn.out_proj.bias"]
         h = st(F.layer_norm(t, (W,), w[p + "ln_2.weight"], w[p + "ln_2.bias"], 1e-5))
         h = st(act(Mat.apply(h, w[p + "mlp.c_fc.weight"].t(), lin) + w[p + "mlp.c_fc.bias"]))
@@ -148,6 +177,7 @@ MODES = {
     # engine's backward: bf16 operands (saved activations rounded), gradients stored in bf16
     "x3fwd-bf16bwd": ("x3/bf16", "f32/bf16", "grad"),
     "f32fwd-bf16bwd": ("f32/bf16", "f32/bf16", "grad"),
+    "x3fwd-bf16bwd-flash": ("x3/bf16", "f32/flash", "grad"),   # ... with the backward's attention core as the flash kernel runs it
     "x3lin-bf16att-bf16bwd": ("x3/bf16", "bf16", "grad"),      # ... and the forward's attention products on bf16 operands too
     "x3lin-x2att-bf16bwd": ("x3/bf16", "x2/bf16", "grad"),
 }

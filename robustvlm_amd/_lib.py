@@ -138,6 +138,10 @@ _SIGS = {
     "rvlm_pgd_run_mixed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_f32p, c_f32p, C.c_int, C.POINTER(LossSpecC), C.c_int,
                                      C.c_float, C.c_int, C.c_float, C.c_float, C.c_int, c_f32p, c_f32p, C.c_void_p,
                                      c_stream]),
+    "rvlm_pgd_run_mixed_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_f32p, c_f32p, C.c_int, C.POINTER(LossSpecC), C.c_int,
+                                         C.c_float, C.c_int, C.c_float, C.c_float, C.c_int, c_f32p, c_f32p, C.c_void_p,
+                                         c_stream]),
+    "rvlm_vit_backward_input_from": (C.c_int, [C.c_void_p, C.c_void_p, c_f32p, C.c_int, c_f32p, c_stream]),
     "rvlm_apgd_run": (C.c_int, [C.c_void_p, c_f32p, c_f32p, C.c_int, C.POINTER(LossSpecC), C.c_float,
                                 C.c_int, C.c_float, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p,
                                 C.c_void_p, c_stream]),

@@ -48,6 +48,9 @@ struct rvlm_vit {
     std::vector<void*> qkv;      // L x [Mp, 3W] T
     std::vector<void*> attn_o;   // L x [Mp, W] T
     std::vector<float*> lse;     // L x [B*H*Sp]
+    std::vector<float*> lse2;    // fp32 storage: L x [B*H*Sp], the flash kernels' log-sum-exp rows, written by the softmax pass of a
+                                 // saving forward for the handoff to a bf16 handle's backward (vit_backward_from)
+    float* cur_lse2 = nullptr;   // ... of the block the forward is in
     std::vector<void*> h_pre;    // L x [Mp, 4W] T
     void* g_act;         // [Mp, 4W] T
     float *pooled, *emb_raw, *inv_norm;   // [maxB, W], [maxB, D], [maxB]
@@ -348,7 +351,7 @@ static int attn_scores_f32(rvlm_vit* h, hipStream_t s, const float* qkv, float* 
     g.C = P; g.scm = Sld; g.scn = 1; g.scb1 = (long)H * S * Sld; g.scb2 = (long)S * Sld;
     g.M = S; g.N = S; g.K = 64; g.nb1 = B; g.nb2 = H; g.alpha = 0.125f;
     int rc = gemm_f32(g, s); if (rc) return rc;
-    return softmax_rows_fwd(P, (long)B * H * S, S, Sld, s);
+    return softmax_rows_fwd(P, (long)B * H * S, S, Sld, s, h->cur_lse2, (int)round_up(S, 32));
 }
 template <>
 int attention_fwd<float>(rvlm_vit* h, hipStream_t s, const void* qkv_, void* o, float* P, int B) {
@@ -524,6 +527,7 @@ static int forward_impl(rvlm_vit* h, const float* x, const float* delta, int B, 
         }
         {
             PROF("attn_fwd", attn_flops, 0);
+            h->cur_lse2 = (save && !h->lse2.empty()) ? h->lse2[sl] : nullptr;
             if ((rc = attention_fwd<T>(h, s, h->qkv[sl], h->attn_o[sl], h->lse[sl], B))) return rc;
         }
         {
@@ -875,6 +879,52 @@ static int vit_backward(rvlm_vit* h, const float* d_emb, int B, float* grad_x, h
     return h->bf16 ? backward_impl<bf16_t>(h, d_emb, B, grad_x, s) : backward_impl<float>(h, d_emb, B, grad_x, s);
 }
 
+// HANDOFF (round 6): the input gradient of the forward SAVED ON `hx` (an fp32-storage handle: x3 or fp32 precision) evaluated by the
+// bf16 handle `hb`'s backward kernels.  FARE's first cotangent 2 (phi(x + d0) - phi(x)) needs a faithful FORWARD - the difference of two
+// nearly equal embeddings is where bf16 rounding noise decides a fifth of the first step's signs - but not a faithful backward: the
+// cotangent's way back through the network only meets relative rounding errors (oracle/split_bf16_emulation.py: split-bf16 forward +
+// bf16 backward 0.998 first-step sign agreement with the fp32 oracle; split-bf16 both ways 0.9996; bf16 both ways 0.82).  What the
+// bf16 backward reads as fp32 (residual stream, LayerNorm statistics, patch embeddings, the unnormalised output) it reads from hx's
+// buffers in place (pointers swapped for the duration of the enqueue); what it reads in bf16 (qkv, attention output, act'(fc1)) is
+// exported here from the fp32 tensors hx kept; the log-sum-exp rows were written by hx's softmax pass in the flash kernels' convention.
+// The class-token tail is switched off for this pass (hx ran the last block on every row).
+static int vit_backward_from(rvlm_vit* hb, rvlm_vit* hx, const float* d_emb, int B, float* grad_x, hipStream_t s) {
+    if (!hb->bf16 || hx->bf16) return fail(RVLM_ERR_STATE, "handoff: needs a bf16 handle and an fp32-storage (fp32 / x3) handle");
+    if (hx->saved_B != B || B <= 0) return fail(RVLM_ERR_STATE, "handoff: no saved forward for this batch size on the fp32-storage handle");
+    if (hx->lse2.empty() || hb->inference_only) return fail(RVLM_ERR_STATE, "handoff: inference-only handle");
+    if (hb->Mp != hx->Mp || hb->Mp0 != hx->Mp0 || hb->W != hx->W || hb->L != hx->L || hb->S != hx->S || hb->H != hx->H ||
+        hb->D != hx->D || hb->P != hx->P || hb->cfg.act != hx->cfg.act)
+        return fail(RVLM_ERR_STATE, "handoff: the two handles must hold the same architecture and max_batch");
+    rvlm_vit* h = hb;                      // (PROF accounts on the bf16 handle)
+    const int W = hb->W, L = hb->L, M = B * hb->S;
+    int rc;
+    {
+        PROF("handoff_export", 0, (double)M * W * (3 * 6 + 6 + 4 * 6) * L);
+        for (int l = 0; l < L; ++l) {
+            if ((rc = x3_export_bf16((const float*)hx->qkv[l], 3 * W, (bf16_t*)hb->qkv[l], 3 * W, M, 3 * W, 0, 0, s))) return rc;
+            if ((rc = x3_export_bf16((const float*)hx->attn_o[l], W, (bf16_t*)hb->attn_o[l], W, M, W, 0, 0, s))) return rc;
+            if ((rc = x3_export_bf16((const float*)hx->h_pre[l], 4 * W, (bf16_t*)hb->h_pre[l], 4 * W, M, 4 * W, hb->cfg.act, 1, s))) return rc;
+        }
+    }
+    struct Swap {      // hb reads hx's fp32 state in place; restored on every exit path
+        rvlm_vit *a, *b;
+        Swap(rvlm_vit* a_, rvlm_vit* b_) : a(a_), b(b_) { swap(); }
+        ~Swap() { swap(); }
+        void swap() {
+            std::swap(a->xs, b->xs); std::swap(a->st_mean, b->st_mean); std::swap(a->st_rstd, b->st_rstd);
+            std::swap(a->patch_out, b->patch_out); std::swap(a->emb_raw, b->emb_raw); std::swap(a->inv_norm, b->inv_norm);
+            std::swap(a->lse, b->lse2);
+        }
+    } swapped(hb, hx);
+    const bool tail = hb->cls_tail;
+    const bool sn = hb->saved_norm;
+    hb->cls_tail = false; hb->saved_norm = hx->saved_norm;
+    rc = backward_impl<bf16_t>(hb, d_emb, B, grad_x, s);
+    hb->cls_tail = tail; hb->saved_norm = sn;
+    hb->saved_B = 0;        // (hb's own saved forward, if any, lost its bf16 tensors to the exports)
+    return rc;
+}
+
 __global__ void __launch_bounds__(256)
 add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -958,6 +1008,10 @@ extern "C" int rvlm_vit_create(const rvlm_vit_config* cfg, const rvlm_vit_weight
         // bf16: log-sum-exp rows of the flash kernels; fp32: the block's probabilities [B, H, S, round_up(S, 4)], zero pad columns
         ALLOC_OR_DIE(h->lse[l], h->bf16 ? (size_t)B * h->H * Sp * 4 : (size_t)B * h->H * S * round_up(S, 4) * 4);
         ALLOC_OR_DIE(h->h_pre[l], Mp * 4 * W * e);
+        if (!h->bf16 && !inference_only) {      // (2.4 MB per block at ViT-L/14, B = 128)
+            h->lse2.resize(L);
+            ALLOC_OR_DIE(h->lse2[l], (size_t)B * h->H * Sp * 4);
+        }
     }
     ALLOC_OR_DIE(h->g_act, Mp * 4 * W * e);
     ALLOC_OR_DIE(h->pooled, (size_t)B * W * 4);
@@ -1082,6 +1136,12 @@ extern "C" int rvlm_vit_backward_input(rvlm_vit* h, const float* d_emb, int B, f
     return vit_backward(h, d_emb, B, grad_x, (hipStream_t)stream);
 }
 
+extern "C" int rvlm_vit_backward_input_from(rvlm_vit* h, rvlm_vit* h_saved, const float* d_emb, int B, float* grad_x,
+                                            rvlm_stream_t stream) {
+    RVLM_REQUIRE(h && h_saved && d_emb && grad_x, "rvlm_vit_backward_input_from: null argument");
+    return vit_backward_from(h, h_saved, d_emb, B, grad_x, (hipStream_t)stream);
+}
+
 extern "C" int rvlm_vit_backward_params(rvlm_vit* h, const float* d_emb, int B, const rvlm_vit_weights* grads,
                                         int accumulate, rvlm_stream_t stream) {
     RVLM_REQUIRE(h && d_emb && grads && grads->blocks_host, "rvlm_vit_backward_params: null argument");
@@ -1150,9 +1210,12 @@ extern "C" int rvlm_vit_fwd_inputgrad(rvlm_vit* h, const float* x, const float* 
 // One perturbation loop; iterations [0, n_first) evaluate model and gradient on `hf` (a second handle of the same model, e.g.
 // its fp32 mode), the others on `h`.  The attack state (delta, velocity, gradient) lives in h's buffers throughout; a
 // handle only contributes forward + loss + input gradient (what pgd_train.py:33-38 asks of the model).
+// handoff: the first iterations run forward + loss on `hf` and the input gradient on h's (bf16) kernels from hf's saved forward
+// (vit_backward_from above).
 static int pgd_run_impl(rvlm_vit* h, rvlm_vit* hf, int n_first, const float* x, const float* delta0, int B,
                         const rvlm_loss_spec* loss, int norm_kind, float eps, int iterations, float stepsize,
-                        float momentum, int mode_max, float* x_adv_out, float* loss_trace, int32_t* flags, hipStream_t s) {
+                        float momentum, int mode_max, float* x_adv_out, float* loss_trace, int32_t* flags, hipStream_t s,
+                        bool handoff = false) {
     const size_t n = (size_t)B * 3 * h->img * h->img;
     float *delta = h->img_buf[0], *vel = h->img_buf[1], *grad = h->img_buf[2];
     int rc;
@@ -1169,7 +1232,7 @@ static int pgd_run_impl(rvlm_vit* h, rvlm_vit* hf, int n_first, const float* x, 
         if ((rc = vit_forward(m, x, delta, B, loss->output_normalize, 1, m->emb, s))) return rc;
         float* lsc = loss_trace ? loss_trace + it : (it < 4096 ? h->loss_scalar + it : nullptr);
         if ((rc = loss_step(m, loss, B, loss->reduction, lsc, nullptr, s))) return rc;
-        if ((rc = vit_backward(m, m->d_emb, B, grad, s))) return rc;
+        if ((rc = (handoff && m != h) ? vit_backward_from(h, m, m->d_emb, B, grad, s) : vit_backward(m, m->d_emb, B, grad, s))) return rc;
         {
             PROF("linf_update", 0, (double)n * 28);
             float* xo = it == iterations - 1 ? x_adv_out : nullptr;
@@ -1213,6 +1276,24 @@ extern "C" int rvlm_pgd_run_mixed(rvlm_vit* h, rvlm_vit* h_first, int n_first, c
     RVLM_REQUIRE(!h->inference_only && !h_first->inference_only, "rvlm_pgd_run_mixed: inference-only handle");
     return pgd_run_impl(h, h_first, n_first, x, delta0, B, loss, norm_kind, eps, iterations, stepsize, momentum, mode_max,
                         x_adv_out, loss_trace, flags, (hipStream_t)stream);
+}
+
+// ... with the handoff (round 6): the first n_first iterations' FORWARD + loss on h_first (fp32 storage: x3 or fp32 precision), their
+// input gradient on h's bf16 backward from h_first's saved forward - FARE's first step needs a faithful embedding difference, not a
+// faithful backward.  Both handles: same architecture AND the same max_batch.
+extern "C" int rvlm_pgd_run_mixed_fwd(rvlm_vit* h, rvlm_vit* h_first, int n_first, const float* x, const float* delta0, int B,
+                                      const rvlm_loss_spec* loss, int norm_kind, float eps, int iterations, float stepsize,
+                                      float momentum, int mode_max, float* x_adv_out, float* loss_trace,
+                                      int32_t* flags, rvlm_stream_t stream) {
+    RVLM_REQUIRE(h && h_first && x && loss && x_adv_out && loss->ref, "rvlm_pgd_run_mixed_fwd: null argument");
+    if (norm_kind != 0 && norm_kind != 2) return fail(RVLM_ERR_UNSUPPORTED, "rvlm_pgd_run_mixed_fwd: norm must be L-inf (0) or L2 (2)");
+    RVLM_REQUIRE(B > 1 && B <= h->maxB && B <= h_first->maxB, "rvlm_pgd_run_mixed_fwd: need 1 < B <= max_batch of both handles");
+    RVLM_REQUIRE(iterations >= 0 && iterations <= 4096 && n_first >= 0, "rvlm_pgd_run_mixed_fwd: iterations");
+    RVLM_REQUIRE(h->bf16 && !h_first->bf16, "rvlm_pgd_run_mixed_fwd: h must be a bf16 handle, h_first an fp32-storage (fp32 / x3) one");
+    RVLM_REQUIRE(h->Mp == h_first->Mp && h->Mp0 == h_first->Mp0, "rvlm_pgd_run_mixed_fwd: the two handles need the same max_batch");
+    RVLM_REQUIRE(!h->inference_only && !h_first->inference_only, "rvlm_pgd_run_mixed_fwd: inference-only handle");
+    return pgd_run_impl(h, h_first, n_first, x, delta0, B, loss, norm_kind, eps, iterations, stepsize, momentum, mode_max,
+                        x_adv_out, loss_trace, flags, (hipStream_t)stream, true);
 }
 
 extern "C" int rvlm_pgd_run(rvlm_vit* h, const float* x, const float* delta0, int B,

@@ -125,7 +125,10 @@ int l2_normalize_bwd(const float* d_out, const float* e_raw, const float* inv_no
 // ---------------------------------------------------------------------------------------------
 // Softmax rows for the fp32 attention path (scores materialised): in place
 // ---------------------------------------------------------------------------------------------
-int softmax_rows_fwd(float* s, long rows, int cols, int ld, hipStream_t st);   // rows of `cols` values, `ld` floats apart
+// rows of `cols` values, `ld` floats apart.  lse2 != null: the rows are the [cols x cols] score matrices of (image, head) pairs and
+// lse2[(row / cols) * lse_ld + row % cols] = log2(sum_j exp(s_j)) - the bf16 flash kernels' log-sum-exp convention (attention_bf16.hip),
+// so that their backward can run on a forward this path computed (the handoff of engine.hip)
+int softmax_rows_fwd(float* s, long rows, int cols, int ld, hipStream_t st, float* lse2 = nullptr, int lse_ld = 0);
 // ds = p * (dp - sum_j p_j dp_j) * scale, in place over dp
 int softmax_rows_bwd(const float* p, float* dp, long rows, int cols, int ld, float scale, hipStream_t st);
 
@@ -170,6 +173,8 @@ int x3_prepare_weight(const float* src, int rows, int cols, bf16_t* nk3, bf16_t*
 bool x3_layernorm_fwd(const float* x, long ldx, const float* gamma, const float* beta, bf16_t* A3, float* mean, float* rstd, int M,
                       int rows_out, int W, hipStream_t s);
 int x3_act(const float* hbuf, long ldh, float* out, long ldo, bf16_t* A3, int M, int rows_out, int N, int act, int mode, hipStream_t s);
+// handoff of a saved fp32-storage forward to the bf16 backward: out = bf16(A) (dact = 0) or bf16(act'(A)) (dact = 1)
+int x3_export_bf16(const float* A, long lda, bf16_t* out, long ldo, int M, int N, int act, int dact, hipStream_t s);
 int transpose_split(const bf16_t* in, long ldi, int R, int C, bf16_t* out, int Kc, int splits, float* dbias,
                     int accumulate, float* red, size_t red_floats, hipStream_t s);
 // the same from the operands AS THEY LIE (dY [M, N] ld lddy, X [M, K] ld ldx, token-major): no transposed copies

@@ -574,7 +574,8 @@ int l2_normalize_bwd(const float* d_out, const float* e_raw, const float* inv_no
 // =============================================================================================
 // Softmax over rows (fp32 attention path, scores materialised), one wave per row, in place
 // =============================================================================================
-__global__ void __launch_bounds__(256) softmax_fwd_kernel(float* __restrict__ s, long rows, int cols, int ld) {
+__global__ void __launch_bounds__(256) softmax_fwd_kernel(float* __restrict__ s, long rows, int cols, int ld, float* __restrict__ lse2,
+                                                          int lse_ld) {
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
@@ -586,6 +587,7 @@ __global__ void __launch_bounds__(256) softmax_fwd_kernel(float* __restrict__ s,
     for (int c = lane; c < cols; c += 64) { float e = expf(r[c] - m); r[c] = e; sum += e; }
     sum = wave_sum(sum);
     for (int c = lane; c < cols; c += 64) r[c] = r[c] / sum;
+    if (lse2 && lane == 0) lse2[(row / cols) * lse_ld + row % cols] = (m + logf(sum)) * 1.4426950408889634f;
 }
 __global__ void __launch_bounds__(256)
 softmax_bwd_kernel(const float* __restrict__ p, float* __restrict__ dp, long rows, int cols, int ld,
@@ -608,7 +610,8 @@ softmax_bwd_kernel(const float* __restrict__ p, float* __restrict__ dp, long row
 // holds 4 consecutive columns instead of columns l, l + 64, ..: fp32, ~1 ulp of the row sum - like layernorm_fwd8 above).
 template <bool BWD>
 __global__ void __launch_bounds__(256)
-softmax257_kernel(const float* __restrict__ p, float* __restrict__ s, long rows, int cols, int ld, float scale) {
+softmax257_kernel(const float* __restrict__ p, float* __restrict__ s, long rows, int cols, int ld, float scale,
+                  float* __restrict__ lse2 = nullptr, int lse_ld = 0) {
     constexpr int R = 4;
     const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
     const int lane = threadIdx.x & 63;
@@ -643,6 +646,7 @@ softmax257_kernel(const float* __restrict__ p, float* __restrict__ s, long rows,
             if (lane == 0)
                 _Pragma("unroll") for (int e = 0; e < 4; ++e) if (e < ntail) { b[e] = expf(b[e] - m); sum += b[e]; }
             sum = wave_sum(sum);
+            if (lse2 && lane == 0) lse2[((row0 + r) / cols) * lse_ld + (row0 + r) % cols] = (m + logf(sum)) * 1.4426950408889634f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) a[e] = a[e] / sum;
             if (lane == 0)
@@ -668,17 +672,17 @@ softmax257_kernel(const float* __restrict__ p, float* __restrict__ s, long rows,
 static bool softmax257_ok(const void* a, const void* b, int cols, int ld) {
     return cols > 256 && cols <= 260 && ld >= 260 && ld % 4 == 0 && (((size_t)a | (size_t)b) & 15) == 0;
 }
-int softmax_rows_fwd(float* s, long rows, int cols, int ld, hipStream_t st) {
+int softmax_rows_fwd(float* s, long rows, int cols, int ld, hipStream_t st, float* lse2, int lse_ld) {
     if (softmax257_ok(s, s, cols, ld))
-        hipLaunchKernelGGL((softmax257_kernel<false>), dim3(cdiv(rows, 16)), dim3(256), 0, st, nullptr, s, rows, cols, ld, 1.0f);
+        hipLaunchKernelGGL((softmax257_kernel<false>), dim3(cdiv(rows, 16)), dim3(256), 0, st, nullptr, s, rows, cols, ld, 1.0f, lse2, lse_ld);
     else
-    hipLaunchKernelGGL(softmax_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, s, rows, cols, ld);
+    hipLaunchKernelGGL(softmax_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, s, rows, cols, ld, lse2, lse_ld);
     RVLM_CHECK_LAUNCH();
     return RVLM_OK;
 }
 int softmax_rows_bwd(const float* p, float* dp, long rows, int cols, int ld, float scale, hipStream_t st) {
     if (softmax257_ok(p, dp, cols, ld))
-        hipLaunchKernelGGL((softmax257_kernel<true>), dim3(cdiv(rows, 16)), dim3(256), 0, st, p, dp, rows, cols, ld, scale);
+        hipLaunchKernelGGL((softmax257_kernel<true>), dim3(cdiv(rows, 16)), dim3(256), 0, st, p, dp, rows, cols, ld, scale, (float*)nullptr, 0);
     else
     hipLaunchKernelGGL(softmax_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, p, dp, rows, cols, ld,
                        scale);

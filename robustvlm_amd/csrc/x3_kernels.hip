@@ -134,6 +134,38 @@ int x3_act(const float* hbuf, long ldh, float* out, long ldo, bf16_t* A3, int M,
     return RVLM_OK;
 }
 
+// ---- handoff to the bf16 engine (round 6): the forward ran here (fp32 storage), the input gradient runs on the bf16 handle's
+// kernels (engine.hip, vit_backward_from) - FARE's first-iteration noise sits in the forward DIFFERENCE phi(x + d0) - phi(x), not in
+// the cotangent's way back (oracle/split_bf16_emulation.py, arm x3fwd-bf16bwd-flash: gradient-sign agreement with the fp32 oracle
+// 0.998 against 0.9996 for a split-bf16 backward and 0.82 for the bf16 forward).  What the bf16 backward reads in bf16 - qkv, the
+// attention output, act'(h) - is exported from the fp32 tensors the forward kept; 8 columns per lane, 16-byte stores.
+template <bool DACT>
+__global__ void __launch_bounds__(256)
+x3_export_bf16_kernel(const float* __restrict__ A, long lda, bf16_t* __restrict__ O, long ldo, int M, int N, int act) {
+    const int chunks = N >> 3;
+    const long total = (long)M * chunks;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int r = (int)(i / chunks), c = (int)(i - (long)r * chunks) * 8;
+        float v[8];
+        *(float4*)&v[0] = *(const float4*)(A + (long)r * lda + c);
+        *(float4*)&v[4] = *(const float4*)(A + (long)r * lda + c + 4);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(DACT ? act_bwd_precise(v[e], act) : v[e]);
+        *(bf16x8*)(O + (long)r * ldo + c) = o;
+    }
+}
+// dact = 0: out = bf16(A); 1: out = bf16(act'(A)) (A = the fp32 pre-activation fc1 left: what the bf16 forward's fc1 epilogue stores)
+int x3_export_bf16(const float* A, long lda, bf16_t* out, long ldo, int M, int N, int act, int dact, hipStream_t s) {
+    if (N % 8 != 0 || lda % 4 != 0 || ldo % 8 != 0 || (((size_t)A | (size_t)out) & 15)) return fail(RVLM_ERR_ARG, "x3_export_bf16: alignment");
+    const long total = (long)M * (N >> 3);
+    const int grid = (int)std::min<long>((total + 255) / 256, 256 * 32);
+    if (dact) hipLaunchKernelGGL((x3_export_bf16_kernel<true>), dim3(grid), dim3(256), 0, s, A, lda, out, ldo, M, N, act);
+    else hipLaunchKernelGGL((x3_export_bf16_kernel<false>), dim3(grid), dim3(256), 0, s, A, lda, out, ldo, M, N, act);
+    RVLM_CHECK_LAUNCH();
+    return RVLM_OK;
+}
+
 // LayerNorm forward whose output goes STRAIGHT into the split copy [hi | hi | lo] of the linear behind it (W = NV * 512; the same
 // row arithmetic as layernorm_fwd8_kernel in vit_kernels.hip, fp32 result split instead of stored): the fp32 LayerNorm output -
 // 4 B written + 4 B read back per element by x3_split_rows - never exists.  Rows M .. rows_out - 1 of A3 are zero-filled.

@@ -32,7 +32,12 @@ class VitEngine:
     'x3' (round 6): fp32 storage, LayerNorm, softmax and attention products like 'fp32', the encoder's LINEARS as split-bf16
     products (a_hi w_hi + a_hi w_lo + a_lo w_hi, fp32 accumulate: ~16 mantissa bits) on the bf16 matrix pipe -
     embeddings within ~1e-5 of the fp32 mode's at a third of its time; 'bf16+x3-first' = the mixed mode with that handle
-    for the first iteration and the clean embedding (oracle/split_bf16_emulation.py: first-step sign agreement 0.9996)."""
+    for the first iteration and the clean embedding (oracle/split_bf16_emulation.py: first-step sign agreement 0.9996).
+    'bf16+x3fwd-first' (round 6): the same, but only the FORWARDS of the first iteration (and the clean embedding) run on the x3
+    handle; the first input gradient is evaluated by the bf16 backward kernels from the x3 forward's saved tensors
+    (rvlm_pgd_run_mixed_fwd / rvlm_vit_backward_input_from) - the noise of FARE's first step sits in the forward difference
+    phi(x + d0) - phi(x), not in the cotangent's way back (emulation: 0.998 sign agreement), and the x3 backward was more than
+    half of the mixed mode's extra time."""
 
     def __init__(self, cfg, state_dict: dict, precision: str = "bf16", max_batch: int = 128,
                  mean=CLIP_MEAN, std=CLIP_STD, device=None, trainable: bool = False,
@@ -56,9 +61,10 @@ class VitEngine:
         c.image_size, c.patch, c.width, c.layers = cfg.image_size, cfg.patch, cfg.width, cfg.layers
         c.heads, c.out_dim = cfg.heads, cfg.out_dim
         c.act = L.ACT_QUICK_GELU if cfg.act == "quick_gelu" else L.ACT_GELU
-        if precision not in ("bf16", "fp32", "x3", "bf16+fp32-first", "bf16+x3-first"):
+        if precision not in ("bf16", "fp32", "x3", "bf16+fp32-first", "bf16+x3-first", "bf16+x3fwd-first"):
             raise ValueError(f"precision {precision!r} not supported")
-        self.mixed = precision in ("bf16+fp32-first", "bf16+x3-first")
+        self.mixed = precision in ("bf16+fp32-first", "bf16+x3-first", "bf16+x3fwd-first")
+        self.handoff = precision == "bf16+x3fwd-first"
         if self.mixed and (trainable or inference_only):
             raise ValueError(f"precision {precision!r} is an attack-engine option (not trainable / inference_only)")
         if precision == "x3" and trainable:
@@ -75,7 +81,7 @@ class VitEngine:
             L.check(self.lib.rvlm_vit_create(C.byref(c), C.byref(w), L.stream_ptr(), C.byref(self._h)),
                     "rvlm_vit_create")
             if self.mixed:
-                c.precision = L.PREC_F32X3 if precision == "bf16+x3-first" else L.PREC_F32
+                c.precision = L.PREC_F32 if precision == "bf16+fp32-first" else L.PREC_F32X3
                 L.check(self.lib.rvlm_vit_create(C.byref(c), C.byref(w), L.stream_ptr(), C.byref(self._h32)),
                         "rvlm_vit_create (fp32 handle)")
         del keep
@@ -181,6 +187,27 @@ class VitEngine:
                     "rvlm_vit_backward_input")
         return g
 
+    def handoff_inputgrad(self, x, delta, ref=None, output_normalize=False, cot=None):
+        """The first FARE iteration of the mixed modes' handoff, as two calls: forward(x + delta) on the fp32-storage handle
+        (activations kept), then d mean_b |emb - ref|^2 / d(x + delta) - or d <cot, emb> / d(x + delta) for a given cotangent -
+        on the bf16 handle's backward kernels (rvlm_vit_backward_input_from).  Returns (emb, grad_x)."""
+        if not self.mixed:
+            raise ValueError("handoff_inputgrad needs a mixed-precision engine (two handles)")
+        self._check_images(x)
+        x = _f32c(x)
+        d = _f32c(delta) if delta is not None else None
+        B = x.shape[0]
+        emb = torch.empty(B, self.cfg.out_dim, device=x.device, dtype=torch.float32)
+        g = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            L.check(self.lib.rvlm_vit_forward(self._h32, x.data_ptr(), L.ptr(d), B, int(bool(output_normalize)), 1,
+                                              emb.data_ptr(), L.stream_ptr()), "rvlm_vit_forward")
+            d_emb = _f32c(cot) if cot is not None else ((emb - _f32c(ref)) * (2.0 / B)).contiguous()
+            L.check(self.lib.rvlm_vit_backward_input_from(self._h, self._h32, d_emb.data_ptr(), B, g.data_ptr(), L.stream_ptr()),
+                    "rvlm_vit_backward_input_from")
+        self.generation += 1
+        return emb, g
+
     def fwd_inputgrad(self, x, delta, loss_kind, reduction, ref, targets, output_normalize, logit_scale=100.0):
         """One iteration's model work in one native call (rvlm_vit_fwd_inputgrad): returns
         (emb, loss_per_sample, loss_scalar, grad_x)."""
@@ -256,11 +283,12 @@ class VitEngine:
         trace = torch.zeros(max(iterations, 1), dtype=torch.float32, device=x.device) if want_trace else None
         with torch.cuda.device(x.device):
             if self.mixed:
-                L.check(self.lib.rvlm_pgd_run_mixed(self._h, self._h32, 1, x.data_ptr(), L.ptr(d0), x.shape[0],
-                                                    C.byref(ls), int(norm_kind), float(eps), int(iterations),
-                                                    float(stepsize), float(momentum), 1 if mode == "max" else 0,
-                                                    out.data_ptr(), L.ptr(trace), flags.data_ptr(), L.stream_ptr()),
-                        "rvlm_pgd_run_mixed")
+                fn = self.lib.rvlm_pgd_run_mixed_fwd if self.handoff else self.lib.rvlm_pgd_run_mixed
+                L.check(fn(self._h, self._h32, 1, x.data_ptr(), L.ptr(d0), x.shape[0],
+                           C.byref(ls), int(norm_kind), float(eps), int(iterations),
+                           float(stepsize), float(momentum), 1 if mode == "max" else 0,
+                           out.data_ptr(), L.ptr(trace), flags.data_ptr(), L.stream_ptr()),
+                        "rvlm_pgd_run_mixed_fwd" if self.handoff else "rvlm_pgd_run_mixed")
             else:
                 L.check(self.lib.rvlm_pgd_run_norm(self._h, x.data_ptr(), L.ptr(d0), x.shape[0], C.byref(ls),
                                                    int(norm_kind), float(eps), int(iterations), float(stepsize),

@@ -12,3 +12,4 @@ run fp32 --precision fp32 --steps 2 --warmup 1 --no-pmc
 run mixed --precision bf16+fp32-first --steps 3 --warmup 1 --no-pmc
 run x3 --precision x3 --steps 2 --warmup 1 --no-pmc
 run mixed_x3 --precision bf16+x3-first --steps 3 --warmup 1 --no-pmc
+run mixed_x3fwd --precision bf16+x3fwd-first --steps 3 --warmup 1 --no-pmc

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     for sym in declared:
         assert hasattr(lib, sym), f"{sym} declared in include/ but not exported by librvlm.so"
     assert declared == set(L.EXPORTED_SYMBOLS), declared ^ set(L.EXPORTED_SYMBOLS)
-    assert lib.rvlm_version() == 108
+    assert lib.rvlm_version() == 109
 
 
 def test_ab_gemm_file_is_generated_from_the_production_file(tmp_path):

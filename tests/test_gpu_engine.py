@@ -768,3 +768,63 @@ def test_x3_falls_back_to_the_fp32_tiles_on_small_shapes():
     e3.close(); e32.close()
     with pytest.raises(ValueError, match="no weight gradients"):
         R.VitEngine(to_cfg(cfg), {k: v.to(dev()) for k, v in w.items()}, precision="x3", max_batch=4, trainable=True)
+
+
+# ---- handoff: fp32-storage forward, bf16 backward (round 6; engine.hip::vit_backward_from) ---------------------------------
+@pytest.mark.parametrize("shape", ["s65", "s257"])
+@pytest.mark.parametrize("normalize", [False, True])
+def test_handoff_backward_from_x3_forward(shape, normalize):
+    """precision='bf16+x3fwd-first': the input gradient of a forward SAVED ON THE x3 HANDLE evaluated by the bf16 handle's backward
+    kernels (qkv / attention output / act'(fc1) exported to bf16, the log-sum-exp rows written by the fp32 softmax pass in the
+    flash kernels' convention, fp32 residual stream and LayerNorm statistics read in place).  (a) plumbing: for a random
+    cotangent it agrees with the fp32 oracle's gradient like the bf16 engine's own backward does; (b) the point of it: on the
+    FARE first-iteration gradient - a difference of nearly equal embeddings - it keeps the oracle's signs where the bf16
+    engine loses a fifth of them.  s257 runs the S = 257 flash backward (one kernel), s65 the generic pair."""
+    cfg = (V.VitConfig(64, 8, 1024, 3, 16, 64) if shape == "s65" else V.VitConfig(224, 14, 256, 2, 4, 64))
+    B = 8 if shape == "s65" else 2
+    w = V.init_weights(cfg, seed=4)
+    ref = V.ClipVisionModelRef(cfg, w).eval()
+    g = torch.Generator().manual_seed(7)
+    x = torch.rand(B, 3, cfg.image_size, cfg.image_size, generator=g)
+    d0 = (torch.rand(B, 3, cfg.image_size, cfg.image_size, generator=g) * 2 - 1) * (4 / 255)
+    cot = torch.randn(B, cfg.out_dim, generator=g)
+    # oracle: random cotangent, and the FARE first iteration
+    xr = (x + d0).clone().requires_grad_(True)
+    e_or = ref(xr, normalize)
+    (g_cot,) = torch.autograd.grad((e_or * cot).sum(), xr, retain_graph=True)
+    with torch.no_grad():
+        e0_or = ref(x, normalize)
+    (g_fare,) = torch.autograd.grad(((e_or - e0_or) ** 2).sum(1).mean(), xr)
+    wd = {k: v.to(dev()) for k, v in w.items()}
+    eng = R.VitEngine(to_cfg(cfg), wd, precision="bf16+x3fwd-first", max_batch=B)
+    e16 = make_engine(cfg, w, "bf16", max_batch=B)
+    try:
+        xd, dd = x.to(dev()), d0.to(dev())
+        emb, gh = eng.handoff_inputgrad(xd, dd, output_normalize=normalize, cot=cot.to(dev()))
+        assert rel_max(emb.cpu(), e_or.detach()) < 1e-4                          # the forward is the x3 handle's
+        e16.forward(xd, dd, normalize, save=True)
+        g16 = e16.backward_input(cot.to(dev()))
+        err_h, err_16 = rel_max(gh.cpu(), g_cot), rel_max(g16.cpu(), g_cot)
+        assert err_h < 3e-2 and err_h < 1.5 * err_16 + 1e-3, (err_h, err_16)
+        # FARE first iteration: clean embedding from the x3 handle (gradient-free forwards of a mixed engine run there)
+        e0 = eng.forward(xd, None, normalize, save=False)
+        _, gf = eng.handoff_inputgrad(xd, dd, ref=e0, output_normalize=normalize)
+        e0_16 = e16.forward(xd, None, normalize, save=False)
+        _, _, _, gf16 = e16.fwd_inputgrad(xd, dd, "l2", "mean", e0_16, None, normalize)
+        sign_h = float((torch.sign(gf.cpu()) == torch.sign(g_fare)).float().mean())
+        sign_16 = float((torch.sign(gf16.cpu()) == torch.sign(g_fare)).float().mean())
+        assert sign_h > 0.985, (sign_h, sign_16)
+        assert sign_h > sign_16, (sign_h, sign_16)
+        # the handoff invalidated the bf16 handle's own saved forward (its bf16 tensors were overwritten by the exports)
+        with pytest.raises(L.RvlmError):
+            eng.backward_input(cot.to(dev()))
+        # whole loop: deterministic, inside the ball
+        wrap = R.ComputeLossWrapper(e0, None, "mean", "l2", 100.)
+        model = R.ClipVisionModel(eng).eval()
+        if not normalize:
+            xa = R.pgd(model, wrap, xd, None, "linf", 4 / 255, 3, 1 / 255, False, perturbation=dd.clone(), mode="max")
+            xb = R.pgd(model, wrap, xd, None, "linf", 4 / 255, 3, 1 / 255, False, perturbation=dd.clone(), mode="max")
+            assert torch.equal(xa, xb)
+            assert float((xa - xd).abs().max()) <= 4 / 255 + 1e-6
+    finally:
+        eng.close(); e16.close()

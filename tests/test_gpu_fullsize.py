@@ -595,6 +595,40 @@ def test_config2_x3_first_iteration(setup):
         eng.close(); eng3.close()
 
 
+def test_config2_x3_forward_bf16_backward_first_iteration(setup):
+    """precision='bf16+x3fwd-first' (round 6): like 'bf16+x3-first', but the first iteration's input gradient runs on the bf16
+    backward kernels from the x3 forward's saved tensors (rvlm_pgd_run_mixed_fwd).  Emulation (oracle/split_bf16_emulation.py,
+    arm x3fwd-bf16bwd-flash): 0.998 first-step gradient signs.  Bars: first step >= 0.99 of the fp32 engine's pixels, the
+    ten-step result as close to the reference's own pgd() as the all-x3 first iteration gets (0.927) within 0.02."""
+    s = setup
+    wd = {k: v.to(dev()) for k, v in s["w"].items()}
+    eng = R.VitEngine(to_cfg(s["cfg"]), wd, precision="bf16+x3fwd-first", max_batch=NP)
+    try:
+        x, d0 = s["x"][:NP].to(dev()), s["d0"][:NP].to(dev())
+        model = R.ClipVisionModel(eng).eval()
+        e0 = model(x, False)
+        assert rel(e0.cpu(), torch.from_numpy(GOLD["pgd_e0"])) < 1e-4
+        run = lambda m, e, n: R.pgd(m, R.ComputeLossWrapper(e, None, "mean", "l2", 100.), x, None, "linf", EPS, n, STEP, False,   # noqa: E731
+                                    perturbation=d0.clone(), mode="max")
+        xa = run(model, e0, 10)
+        assert torch.equal(xa, run(model, e0, 10)), "not deterministic"
+        ball_and_range(xa, x)
+        same_mixed = float((xa.cpu() == torch.from_numpy(GOLD["pgd_x_adv"])).float().mean())
+        m32 = R.ClipVisionModel(s["eng32"]).eval()
+        e32 = s["eng32"].forward(x, None, False, save=False)
+        first = float((run(model, e0, 1) == run(m32, e32, 1)).float().mean())
+        _, gh = eng.handoff_inputgrad(x, d0, ref=e0)
+        _, _, _, g32 = s["eng32"].fwd_inputgrad(x, d0, "l2", "mean", e32, None, False)
+        sign0 = float((torch.sign(gh) == torch.sign(g32)).float().mean())
+        record("config2_x3fwd_first", same_pixels_mixed_x3fwd_vs_reference=same_mixed, first_step_same_pixels_x3fwd_vs_fp32=first,
+               sign_agree_it0_x3fwd_vs_fp32_engine=sign0)
+        assert sign0 > 0.99, sign0
+        assert first > 0.99, first
+        assert same_mixed > 0.90, same_mixed
+    finally:
+        eng.close()
+
+
 def test_clip_like_x3_vs_reference(setup_clip):
     """The split-bf16 precision on the CLIP-like tower (outlier channels 30-100x, LayerNorm gains over 2.5 decades): the x3 engine
     alone against the reference's pgd() on the 8-image slice, and its first-iteration gradient signs against the reference's."""
