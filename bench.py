@@ -51,7 +51,7 @@ def parse(extra=None):
     ap.add_argument("--model", default="ViT-L-14", choices=list(HEADLINE_MODELS) + list(getattr(extra, "MODELS", ())))
     ap.add_argument("--batch", type=int, default=128, help="images per GPU per step")
     ap.add_argument("--iterations", type=int, default=10)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "x3", "bf16+fp32-first", "bf16+x3-first", "bf16+x3fwd-first"],
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "x3", "bf16+fp32-first", "bf16+x3-first", "bf16+x3fwd-first", "bf16+x3fwd"],
                     help="bf16: the throughput path (headline); fp32: the reference's own precision on the fp32 matrix-pipe tiles; "
                          "x3: fp32 storage, the linears as split-bf16 products (3 bf16 MFMAs per product, ~16 mantissa bits); "
                          "bf16+fp32-first / bf16+x3-first: pgd with its first iteration (and the clean embedding) on that handle")

@@ -129,6 +129,11 @@ int rvlm_vit_backward_input(rvlm_vit* h, const float* d_emb, int B, float* grad_
  * not.  Invalidates h's own saved forward. */
 int rvlm_vit_backward_input_from(rvlm_vit* h, rvlm_vit* h_saved, const float* d_emb, int B, float* grad_x,
                                  rvlm_stream_t stream);
+/* A saving forward on the fp32-storage handle h FOR `consumer`'s backward (ABI 109): like rvlm_vit_forward(save_for_backward = 1), but
+ * the attention runs as the fp32 flash kernel (no probabilities kept - rvlm_vit_backward_input on h is refused for this pass) and the
+ * bf16 tensors rvlm_vit_backward_input_from(consumer, h, ...) reads are written by the forward itself instead of by export passes. */
+int rvlm_vit_forward_for(rvlm_vit* h, rvlm_vit* consumer, const float* x, const float* delta, int B, int output_normalize,
+                         float* out_emb, rvlm_stream_t stream);
 
 /* Weight gradients of the outer training step (loss_total.backward(), …clip.py:361): for the last
  * forward run with save_for_backward == 2 on a `trainable` handle, writes (accumulate == 0) or adds
@@ -394,7 +399,7 @@ int rvlm_version(void);   /* = RVLM_VERSION.  101: rvlm_loss_spec.y_target, rvlm
                            * rvlm_vit_backward_params_stages refuses out-of-order stages; 105: rvlm_apgd_controller_rho,
                            * rvlm_vit_set_apgd_rho, rvlm_comm_* / rvlm_allreduce_grads; 106: rvlm_pgd_run_mixed, fp32 mode on v_mfma_f32_32x32x2_f32;
                            * 107: rvlm_l2_random_start; 108: RVLM_PREC_F32X3 (split-bf16 linears over fp32 storage);
-                           * 109: rvlm_vit_backward_input_from, rvlm_pgd_run_mixed_fwd (fp32-storage forward, bf16 backward) */
+                           * 109: rvlm_vit_backward_input_from, rvlm_vit_forward_for, rvlm_pgd_run_mixed_fwd (fp32-storage forward, bf16 backward) */
 
 #ifdef __cplusplus
 }

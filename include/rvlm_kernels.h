@@ -35,6 +35,10 @@ int rvlm_k_gemm_f32_set_valu(int on);
  * rows of `cols` values, `ld` floats apart */
 int rvlm_k_softmax_rows(const float* p, float* s, long rows, int cols, int ld, float scale, int backward, rvlm_stream_t stream);
 /* bf16 flash attention on packed qkv [B*S, 3W] (head_dim 64); lse2 [B*H*round_up(S,32)] */
+/* fp32 flash forward (csrc/attention_f32.hip): qkv fp32 [B*S, 3*64*H], o fp32 [B*S, 64*H]; optional lse2 [B*H, round_up(S, 32)] (log2
+ * domain of 0.125 log2(e) q.k) and bf16 copies qkv_bf / o_bf in the same layouts; S <= 288 */
+int rvlm_k_attn_fwd_f32_flash(const float* qkv, float* o, float* lse2, uint16_t* qkv_bf, uint16_t* o_bf, int B, int H, int S,
+                              rvlm_stream_t stream);
 int rvlm_k_attn_fwd_bf16(const uint16_t* qkv, uint16_t* o, float* lse2, int B, int H, int S,
                          rvlm_stream_t stream);
 int rvlm_k_attn_bwd_bf16(const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o, const float* lse2,

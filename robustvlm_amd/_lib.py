@@ -142,6 +142,7 @@ _SIGS = {
                                          C.c_float, C.c_int, C.c_float, C.c_float, C.c_int, c_f32p, c_f32p, C.c_void_p,
                                          c_stream]),
     "rvlm_vit_backward_input_from": (C.c_int, [C.c_void_p, C.c_void_p, c_f32p, C.c_int, c_f32p, c_stream]),
+    "rvlm_vit_forward_for": (C.c_int, [C.c_void_p, C.c_void_p, c_f32p, c_f32p, C.c_int, C.c_int, c_f32p, c_stream]),
     "rvlm_apgd_run": (C.c_int, [C.c_void_p, c_f32p, c_f32p, C.c_int, C.POINTER(LossSpecC), C.c_float,
                                 C.c_int, C.c_float, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p,
                                 C.c_void_p, c_stream]),
@@ -168,6 +169,7 @@ _SIGS = {
                                      C.c_int, c_f32p, c_f32p, c_f32p, c_stream]),
     "rvlm_k_gemm_f32_set_valu": (C.c_int, [C.c_int]),
     "rvlm_k_softmax_rows": (C.c_int, [c_f32p, c_f32p, C.c_long, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
+    "rvlm_k_attn_fwd_f32_flash": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "rvlm_k_attn_fwd_bf16": (C.c_int, [C.c_void_p, C.c_void_p, c_f32p, C.c_int, C.c_int, C.c_int,
                                        c_stream]),
     "rvlm_k_attn_bwd_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_f32p, c_f32p,

@@ -51,6 +51,16 @@ struct rvlm_vit {
     std::vector<float*> lse2;    // fp32 storage: L x [B*H*Sp], the flash kernels' log-sum-exp rows, written by the softmax pass of a
                                  // saving forward for the handoff to a bf16 handle's backward (vit_backward_from)
     float* cur_lse2 = nullptr;   // ... of the block the forward is in
+    // Forward FOR a bf16 handle (the handoff, vit_backward_from): `peer` is set for the duration of a saving forward whose input
+    // gradient that handle will evaluate.  The attention then runs as the fp32 flash kernel (no probabilities kept: this handle's
+    // own backward is refused for that pass, saved_mode 3), which writes the peer's bf16 qkv / attention output / log-sum-exp rows as
+    // it goes; the split-bf16 activation pass writes the peer's act'(fc1).  What was exported is remembered per saved forward.
+    rvlm_vit* peer = nullptr;
+    rvlm_vit* exported_to = nullptr;     // the saved forward's bf16 qkv / attention output / lse rows already sit in this handle
+    bool exported_dact = false;          // ... and its act'(fc1)
+    bf16_t* cur_dact_out = nullptr;      // the peer's act'(fc1) buffer of the block the forward is in
+    bf16_t *cur_qkv_bf = nullptr, *cur_o_bf = nullptr;
+    bool cur_flash = false;              // this forward's attention runs as the flash kernel (save == 0, or a forward for a peer)
     std::vector<void*> h_pre;    // L x [Mp, 4W] T
     void* g_act;         // [Mp, 4W] T
     float *pooled, *emb_raw, *inv_norm;   // [maxB, W], [maxB, D], [maxB]
@@ -260,8 +270,10 @@ int linear_fwd<float>(rvlm_vit* h, hipStream_t s, const void* A, long lda, int M
             // act(h) goes straight into the split copy the next linear (fc2: A = `out`, K = N) reads; `out` itself is not written
             // (its only other reader is the weight gradient, which this precision does not have)
             const bool fuse = x3_takes(h, M, 256, N);
-            if ((rc = x3_act((const float*)g.out, ldo, (float*)out, ldo, fuse ? h->a3 : nullptr, M, (int)round_up(M, 256), N, h->cfg.act, 0, s)))
+            if ((rc = x3_act((const float*)g.out, ldo, (float*)out, ldo, fuse ? h->a3 : nullptr, M, (int)round_up(M, 256), N, h->cfg.act, 0, s,
+                             h->cur_dact_out, ldo)))
                 return rc;
+            if (h->cur_dact_out) h->exported_dact = true;
             if (fuse) h->a3_of = out;
         }
         return RVLM_OK;
@@ -357,7 +369,12 @@ template <>
 int attention_fwd<float>(rvlm_vit* h, hipStream_t s, const void* qkv_, void* o, float* P, int B) {
     const int S = h->S, W = h->W, H = h->H, Sld = (int)round_up(S, 4);
     const float* qkv = (const float*)qkv_;
-    int rc = attn_scores_f32(h, s, qkv, P, B); if (rc) return rc;
+    int rc = RVLM_OK;
+    if (h->cur_flash) {      // no backward of this handle's own will read P: one fused kernel, no score matrices
+        if (attn_fwd_f32_flash(qkv, (float*)o, h->cur_lse2, (int)round_up(S, 32), h->cur_qkv_bf, h->cur_o_bf, B, H, S, s, &rc)) return rc;
+        if (h->peer) return fail(RVLM_ERR_UNSUPPORTED, "forward for a peer handle: sequence length not covered by the fp32 flash kernel");
+    }
+    rc = attn_scores_f32(h, s, qkv, P, B); if (rc) return rc;
     GemmF32 g;  // O = P V
     g.A = P; g.sam = Sld; g.sak = 1; g.sab1 = (long)H * S * Sld; g.sab2 = (long)S * Sld; g.pad4 = 1;
     g.B = qkv + 2 * W; g.sbn = 1; g.sbk = 3 * W; g.sbb1 = (long)S * 3 * W; g.sbb2 = 64;
@@ -458,6 +475,12 @@ static int forward_impl(rvlm_vit* h, const float* x, const float* delta, int B, 
     // xs / qkv / attn_o / lse, pooled, emb_raw, inv_norm): a non-saving pass therefore invalidates the saved forward
     // instead of letting a later backward run on a mixture of two passes.
     h->saved_B = 0;
+    // a forward FOR a peer (handoff) is a saving forward of an fp32-storage handle; non-saving forwards of such handles use the flash
+    // attention too (nothing reads their probabilities)
+    rvlm_vit* const peer = (!h->bf16 && save == 1) ? h->peer : nullptr;
+    h->cur_flash = !h->bf16 && (save == 0 || peer != nullptr);
+    h->exported_to = nullptr; h->exported_dact = false;
+    h->cur_qkv_bf = h->cur_o_bf = nullptr; h->cur_dact_out = nullptr;
     {
         PROF("patch_im2col", 0, (double)B * 3 * h->img * h->img * (delta ? 8 : 4) + (double)M0 * h->Kpad * sizeof(T));
         if ((rc = im2col_normalize<T>(x, delta, B, h->img, h->P, h->cfg.mean, h->cfg.std, (T*)h->A0, h->Kpad, h->Kpad, s))) return rc;
@@ -528,6 +551,7 @@ static int forward_impl(rvlm_vit* h, const float* x, const float* delta, int B, 
         {
             PROF("attn_fwd", attn_flops, 0);
             h->cur_lse2 = (save && !h->lse2.empty()) ? h->lse2[sl] : nullptr;
+            if (peer) { h->cur_lse2 = peer->lse[l]; h->cur_qkv_bf = (bf16_t*)peer->qkv[l]; h->cur_o_bf = (bf16_t*)peer->attn_o[l]; }
             if ((rc = attention_fwd<T>(h, s, h->qkv[sl], h->attn_o[sl], h->lse[sl], B))) return rc;
         }
         {
@@ -544,8 +568,11 @@ static int forward_impl(rvlm_vit* h, const float* x, const float* delta, int B, 
         }
         {
             PROF("gemm_fc1_fwd", 2.0 * M * W * 4 * W, 0);
-            if ((rc = linear_fwd<T>(h, s, ln2o, W, M, 4 * W, W, y.w_fc, y.w_fc_nk, y.b_fc, EPI_BF16_ACT,
-                                    gact, 4 * W, save ? h->h_pre[sl] : nullptr, nullptr))) return rc;
+            h->cur_dact_out = peer ? (bf16_t*)peer->h_pre[l] : nullptr;
+            rc = linear_fwd<T>(h, s, ln2o, W, M, 4 * W, W, y.w_fc, y.w_fc_nk, y.b_fc, EPI_BF16_ACT,
+                               gact, 4 * W, save ? h->h_pre[sl] : nullptr, nullptr);
+            h->cur_dact_out = nullptr;
+            if (rc) return rc;
         }
         {
             PROF("gemm_fc2_fwd", 2.0 * M * W * 4 * W, 0);
@@ -569,6 +596,8 @@ static int forward_impl(rvlm_vit* h, const float* x, const float* delta, int B, 
         }
     }
     if (save) { h->saved_B = B; h->saved_norm = normalize != 0; h->saved_mode = save; h->next_param_stage = 0; }
+    if (peer) { h->saved_mode = 3; h->exported_to = peer; }      // (3: for the peer's backward only - no probabilities were kept)
+    h->cur_flash = false; h->cur_qkv_bf = h->cur_o_bf = nullptr; h->cur_lse2 = nullptr;
     return RVLM_OK;
 }
 
@@ -876,6 +905,7 @@ static int vit_forward(rvlm_vit* h, const float* x, const float* delta, int B, i
                    : forward_impl<float>(h, x, delta, B, normalize, save, out_emb, s);
 }
 static int vit_backward(rvlm_vit* h, const float* d_emb, int B, float* grad_x, hipStream_t s) {
+    if (h->saved_mode == 3) return fail(RVLM_ERR_STATE, "backward: the saved forward was run for another handle's backward (no probabilities kept)");
     return h->bf16 ? backward_impl<bf16_t>(h, d_emb, B, grad_x, s) : backward_impl<float>(h, d_emb, B, grad_x, s);
 }
 
@@ -900,22 +930,24 @@ static int vit_backward_from(rvlm_vit* hb, rvlm_vit* hx, const float* d_emb, int
     int rc;
     {
         PROF("handoff_export", 0, (double)M * W * (3 * 6 + 6 + 4 * 6) * L);
+        const bool have_qo = hx->exported_to == hb, have_dact = have_qo && hx->exported_dact;     // written by the forward itself
         for (int l = 0; l < L; ++l) {
-            if ((rc = x3_export_bf16((const float*)hx->qkv[l], 3 * W, (bf16_t*)hb->qkv[l], 3 * W, M, 3 * W, 0, 0, s))) return rc;
-            if ((rc = x3_export_bf16((const float*)hx->attn_o[l], W, (bf16_t*)hb->attn_o[l], W, M, W, 0, 0, s))) return rc;
-            if ((rc = x3_export_bf16((const float*)hx->h_pre[l], 4 * W, (bf16_t*)hb->h_pre[l], 4 * W, M, 4 * W, hb->cfg.act, 1, s))) return rc;
+            if (!have_qo && (rc = x3_export_bf16((const float*)hx->qkv[l], 3 * W, (bf16_t*)hb->qkv[l], 3 * W, M, 3 * W, 0, 0, s))) return rc;
+            if (!have_qo && (rc = x3_export_bf16((const float*)hx->attn_o[l], W, (bf16_t*)hb->attn_o[l], W, M, W, 0, 0, s))) return rc;
+            if (!have_dact && (rc = x3_export_bf16((const float*)hx->h_pre[l], 4 * W, (bf16_t*)hb->h_pre[l], 4 * W, M, 4 * W, hb->cfg.act, 1, s))) return rc;
         }
     }
+    const bool swap_lse = hx->exported_to != hb;      // (a forward run for hb wrote hb's log-sum-exp rows itself)
     struct Swap {      // hb reads hx's fp32 state in place; restored on every exit path
-        rvlm_vit *a, *b;
-        Swap(rvlm_vit* a_, rvlm_vit* b_) : a(a_), b(b_) { swap(); }
+        rvlm_vit *a, *b; bool lse;
+        Swap(rvlm_vit* a_, rvlm_vit* b_, bool lse_) : a(a_), b(b_), lse(lse_) { swap(); }
         ~Swap() { swap(); }
         void swap() {
             std::swap(a->xs, b->xs); std::swap(a->st_mean, b->st_mean); std::swap(a->st_rstd, b->st_rstd);
             std::swap(a->patch_out, b->patch_out); std::swap(a->emb_raw, b->emb_raw); std::swap(a->inv_norm, b->inv_norm);
-            std::swap(a->lse, b->lse2);
+            if (lse) std::swap(a->lse, b->lse2);
         }
-    } swapped(hb, hx);
+    } swapped(hb, hx, swap_lse);
     const bool tail = hb->cls_tail;
     const bool sn = hb->saved_norm;
     hb->cls_tail = false; hb->saved_norm = hx->saved_norm;
@@ -1136,6 +1168,19 @@ extern "C" int rvlm_vit_backward_input(rvlm_vit* h, const float* d_emb, int B, f
     return vit_backward(h, d_emb, B, grad_x, (hipStream_t)stream);
 }
 
+extern "C" int rvlm_vit_forward_for(rvlm_vit* h, rvlm_vit* consumer, const float* x, const float* delta, int B, int output_normalize,
+                                    float* out_emb, rvlm_stream_t stream) {
+    RVLM_REQUIRE(h && consumer && x && out_emb, "rvlm_vit_forward_for: null argument");
+    RVLM_REQUIRE(B > 0 && B <= h->maxB, "rvlm_vit_forward_for: batch exceeds max_batch");
+    RVLM_REQUIRE(!h->bf16 && consumer->bf16 && !h->inference_only && !consumer->inference_only && h->Mp == consumer->Mp &&
+                 h->W == consumer->W && h->L == consumer->L && h->S == consumer->S && h->H == consumer->H,
+                 "rvlm_vit_forward_for: needs an fp32-storage handle and a bf16 handle of the same architecture and max_batch");
+    h->peer = consumer;
+    const int rc = vit_forward(h, x, delta, B, output_normalize, 1, out_emb, (hipStream_t)stream);
+    h->peer = nullptr;
+    return rc;
+}
+
 extern "C" int rvlm_vit_backward_input_from(rvlm_vit* h, rvlm_vit* h_saved, const float* d_emb, int B, float* grad_x,
                                             rvlm_stream_t stream) {
     RVLM_REQUIRE(h && h_saved && d_emb && grad_x, "rvlm_vit_backward_input_from: null argument");
@@ -1229,7 +1274,10 @@ static int pgd_run_impl(rvlm_vit* h, rvlm_vit* hf, int n_first, const float* x, 
     }
     for (int it = 0; it < iterations; ++it) {
         rvlm_vit* m = (hf && it < n_first) ? hf : h;
-        if ((rc = vit_forward(m, x, delta, B, loss->output_normalize, 1, m->emb, s))) return rc;
+        if (handoff && m != h) m->peer = h;      // (the forward then writes h's bf16 tensors itself and keeps no probabilities)
+        rc = vit_forward(m, x, delta, B, loss->output_normalize, 1, m->emb, s);
+        m->peer = nullptr;
+        if (rc) return rc;
         float* lsc = loss_trace ? loss_trace + it : (it < 4096 ? h->loss_scalar + it : nullptr);
         if ((rc = loss_step(m, loss, B, loss->reduction, lsc, nullptr, s))) return rc;
         if ((rc = (handoff && m != h) ? vit_backward_from(h, m, m->d_emb, B, grad, s) : vit_backward(m, m->d_emb, B, grad, s))) return rc;

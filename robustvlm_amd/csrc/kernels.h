@@ -141,6 +141,10 @@ int attn_fwd_bf16(const bf16_t* qkv, long ldqkv, bf16_t* o, long ldo, float* lse
 int attn_bwd_bf16(const bf16_t* qkv, long ldqkv, const bf16_t* o, long ldo, const bf16_t* d_o,
                   long lddo, const float* lse, float* dsum_scratch, bf16_t* dqkv, long lddqkv,
                   int B, int H, int S, hipStream_t s);
+// fp32 flash forward (attention_f32.hip): O = softmax(0.125 Q K^T) V without materialised scores, on v_mfma_f32_32x32x2_f32; optional
+// lse2 rows (the bf16 flash kernels' convention) and bf16 copies of q | k | v and o.  false: shape not covered.
+bool attn_fwd_f32_flash(const float* qkv, float* o, float* lse2, int lse_ld, bf16_t* qkv_bf, bf16_t* o_bf, int B, int H, int S, hipStream_t s,
+                        int* rc_out);
 // class-token attention of the last block (only the class token's query row is live there): o [B, W] (row b = image b),
 // lse [B*H] natural log; bwd writes dqkv [B*S, 3W] in full (dQ rows of the other tokens are zero)
 int attn_cls_fwd_bf16(const bf16_t* qkv, long ldqkv, bf16_t* o, long ldo, float* lse, int B, int H, int S,
@@ -172,7 +176,9 @@ int x3_split_rows(const float* A, long lda, bf16_t* A3, int M, int rows_out, int
 int x3_prepare_weight(const float* src, int rows, int cols, bf16_t* nk3, bf16_t* t3, hipStream_t s);
 bool x3_layernorm_fwd(const float* x, long ldx, const float* gamma, const float* beta, bf16_t* A3, float* mean, float* rstd, int M,
                       int rows_out, int W, hipStream_t s);
-int x3_act(const float* hbuf, long ldh, float* out, long ldo, bf16_t* A3, int M, int rows_out, int N, int act, int mode, hipStream_t s);
+// dact_bf != null (mode 0 only): also writes bf16(act'(h)) there (row stride ld_dact) - the bf16 backward's stored derivative (handoff)
+int x3_act(const float* hbuf, long ldh, float* out, long ldo, bf16_t* A3, int M, int rows_out, int N, int act, int mode, hipStream_t s,
+           bf16_t* dact_bf = nullptr, long ld_dact = 0);
 // handoff of a saved fp32-storage forward to the bf16 backward: out = bf16(A) (dact = 0) or bf16(act'(A)) (dact = 1)
 int x3_export_bf16(const float* A, long lda, bf16_t* out, long ldo, int M, int N, int act, int dact, hipStream_t s);
 int transpose_split(const bf16_t* in, long ldi, int R, int C, bf16_t* out, int Kc, int splits, float* dbias,

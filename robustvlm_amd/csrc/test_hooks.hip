@@ -279,6 +279,13 @@ extern "C" int rvlm_k_softmax_rows(const float* p, float* s, long rows, int cols
     return backward ? softmax_rows_bwd(p, s, rows, cols, ld, scale, (hipStream_t)stream) : softmax_rows_fwd(s, rows, cols, ld, (hipStream_t)stream);
 }
 extern "C" int rvlm_k_gemm_f32_set_valu(int on) { gemm_f32_set_valu(on); return RVLM_OK; }
+extern "C" int rvlm_k_attn_fwd_f32_flash(const float* qkv, float* o, float* lse2, uint16_t* qkv_bf, uint16_t* o_bf, int B, int H, int S,
+                                         rvlm_stream_t stream) {
+    int rc = RVLM_OK;
+    if (!attn_fwd_f32_flash(qkv, o, lse2, (int)round_up(S, 32), (bf16_t*)qkv_bf, (bf16_t*)o_bf, B, H, S, (hipStream_t)stream, &rc))
+        return fail(RVLM_ERR_UNSUPPORTED, "rvlm_k_attn_fwd_f32_flash: sequence length not covered");
+    return rc;
+}
 extern "C" int rvlm_k_attn_fwd_bf16(const uint16_t* qkv, uint16_t* o, float* lse2, int B, int H, int S,
                                     rvlm_stream_t stream) {
     return attn_fwd_bf16((const bf16_t*)qkv, 3L * H * 64, (bf16_t*)o, H * 64L, lse2, B, H, S, (hipStream_t)stream);

@@ -91,10 +91,10 @@ int x3_prepare_weight(const float* src, int rows, int cols, bf16_t* nk3, bf16_t*
 // through the activation).  The same precise functions as gemm_f32's epilogue (common.h).  The result goes to `out` (fp32) or, with
 // A3 != null, STRAIGHT into the split copy [hi | hi | lo] the next linear reads ([rows_out, 3N], rows >= M zero) - the fp32
 // round trip of the [M, 4W] activation (4 B written + 4 B read back by x3_split_rows) is skipped: ~0.2 ms per block and pass.
-template <int MODE, bool SPLIT>
+template <int MODE, bool SPLIT, bool DACT = false>
 __global__ void __launch_bounds__(256)
 x3_act_kernel(const float* __restrict__ hbuf, long ldh, float* __restrict__ out, long ldo, bf16_t* __restrict__ A3, int M, int rows_out,
-              int N, int act) {
+              int N, int act, bf16_t* __restrict__ dact_bf = nullptr, long ld_dact = 0) {
     const int chunks = N >> 3;
     const long total = (long)(SPLIT ? rows_out : M) * chunks;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -110,6 +110,12 @@ x3_act_kernel(const float* __restrict__ hbuf, long ldh, float* __restrict__ out,
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = MODE == 0 ? act_fwd_precise(hv[e], act) : v[e] * act_bwd_precise(hv[e], act);
+            if (DACT) {      // the handoff: act'(h) in bf16 for the bf16 handle's fc2 dgrad epilogue
+                bf16x8 d;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d[e] = (bf16_t)act_bwd_precise(hv[e], act);
+                *(bf16x8*)(dact_bf + (long)r * ld_dact + c) = d;
+            }
         }
         if (SPLIT) {
             bf16x8 hi, lo;
@@ -122,11 +128,16 @@ x3_act_kernel(const float* __restrict__ hbuf, long ldh, float* __restrict__ out,
         }
     }
 }
-int x3_act(const float* hbuf, long ldh, float* out, long ldo, bf16_t* A3, int M, int rows_out, int N, int act, int mode, hipStream_t s) {
-    if (N % 8 != 0 || ldh % 4 != 0 || ldo % 4 != 0) return fail(RVLM_ERR_ARG, "x3_act: alignment");
+int x3_act(const float* hbuf, long ldh, float* out, long ldo, bf16_t* A3, int M, int rows_out, int N, int act, int mode, hipStream_t s,
+           bf16_t* dact_bf, long ld_dact) {
+    if (N % 8 != 0 || ldh % 4 != 0 || ldo % 4 != 0 || (dact_bf && (mode != 0 || ld_dact % 8 != 0))) return fail(RVLM_ERR_ARG, "x3_act: alignment");
     const long total = (long)(A3 ? rows_out : M) * (N >> 3);
     const int grid = (int)std::min<long>((total + 255) / 256, 256 * 32);
 #define RVLM_X3_ACT(MODE, SPLIT) hipLaunchKernelGGL((x3_act_kernel<MODE, SPLIT>), dim3(grid), dim3(256), 0, s, hbuf, ldh, out, ldo, A3, M, rows_out, N, act)
+    if (mode == 0 && dact_bf) {
+        if (A3) hipLaunchKernelGGL((x3_act_kernel<0, true, true>), dim3(grid), dim3(256), 0, s, hbuf, ldh, out, ldo, A3, M, rows_out, N, act, dact_bf, ld_dact);
+        else hipLaunchKernelGGL((x3_act_kernel<0, false, true>), dim3(grid), dim3(256), 0, s, hbuf, ldh, out, ldo, A3, M, rows_out, N, act, dact_bf, ld_dact);
+    } else
     if (mode == 0) { if (A3) RVLM_X3_ACT(0, true); else RVLM_X3_ACT(0, false); }
     else { if (A3) RVLM_X3_ACT(1, true); else RVLM_X3_ACT(1, false); }
 #undef RVLM_X3_ACT

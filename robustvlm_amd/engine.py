@@ -37,7 +37,8 @@ class VitEngine:
     handle; the first input gradient is evaluated by the bf16 backward kernels from the x3 forward's saved tensors
     (rvlm_pgd_run_mixed_fwd / rvlm_vit_backward_input_from) - the noise of FARE's first step sits in the forward difference
     phi(x + d0) - phi(x), not in the cotangent's way back (emulation: 0.998 sign agreement), and the x3 backward was more than
-    half of the mixed mode's extra time."""
+    half of the mixed mode's extra time.  'bf16+x3fwd': that split for EVERY iteration of ``pgd_run`` (split-bf16 forwards, bf16
+    backwards) - a rung between 'bf16+x3fwd-first' and 'x3'."""
 
     def __init__(self, cfg, state_dict: dict, precision: str = "bf16", max_batch: int = 128,
                  mean=CLIP_MEAN, std=CLIP_STD, device=None, trainable: bool = False,
@@ -61,10 +62,11 @@ class VitEngine:
         c.image_size, c.patch, c.width, c.layers = cfg.image_size, cfg.patch, cfg.width, cfg.layers
         c.heads, c.out_dim = cfg.heads, cfg.out_dim
         c.act = L.ACT_QUICK_GELU if cfg.act == "quick_gelu" else L.ACT_GELU
-        if precision not in ("bf16", "fp32", "x3", "bf16+fp32-first", "bf16+x3-first", "bf16+x3fwd-first"):
+        if precision not in ("bf16", "fp32", "x3", "bf16+fp32-first", "bf16+x3-first", "bf16+x3fwd-first", "bf16+x3fwd"):
             raise ValueError(f"precision {precision!r} not supported")
-        self.mixed = precision in ("bf16+fp32-first", "bf16+x3-first", "bf16+x3fwd-first")
-        self.handoff = precision == "bf16+x3fwd-first"
+        self.mixed = precision in ("bf16+fp32-first", "bf16+x3-first", "bf16+x3fwd-first", "bf16+x3fwd")
+        self.handoff = precision in ("bf16+x3fwd-first", "bf16+x3fwd")
+        self.n_first = 4096 if precision == "bf16+x3fwd" else 1      # 'bf16+x3fwd': EVERY iteration's forward on the x3 handle
         if self.mixed and (trainable or inference_only):
             raise ValueError(f"precision {precision!r} is an attack-engine option (not trainable / inference_only)")
         if precision == "x3" and trainable:
@@ -187,7 +189,7 @@ class VitEngine:
                     "rvlm_vit_backward_input")
         return g
 
-    def handoff_inputgrad(self, x, delta, ref=None, output_normalize=False, cot=None):
+    def handoff_inputgrad(self, x, delta, ref=None, output_normalize=False, cot=None, fused=True):
         """The first FARE iteration of the mixed modes' handoff, as two calls: forward(x + delta) on the fp32-storage handle
         (activations kept), then d mean_b |emb - ref|^2 / d(x + delta) - or d <cot, emb> / d(x + delta) for a given cotangent -
         on the bf16 handle's backward kernels (rvlm_vit_backward_input_from).  Returns (emb, grad_x)."""
@@ -200,8 +202,12 @@ class VitEngine:
         emb = torch.empty(B, self.cfg.out_dim, device=x.device, dtype=torch.float32)
         g = torch.empty_like(x)
         with torch.cuda.device(x.device):
-            L.check(self.lib.rvlm_vit_forward(self._h32, x.data_ptr(), L.ptr(d), B, int(bool(output_normalize)), 1,
-                                              emb.data_ptr(), L.stream_ptr()), "rvlm_vit_forward")
+            if fused:    # the forward writes the bf16 handle's tensors itself (fp32 flash attention, no probabilities kept)
+                L.check(self.lib.rvlm_vit_forward_for(self._h32, self._h, x.data_ptr(), L.ptr(d), B, int(bool(output_normalize)),
+                                                      emb.data_ptr(), L.stream_ptr()), "rvlm_vit_forward_for")
+            else:        # an ordinary saving forward; the bf16 tensors are exported at the handoff
+                L.check(self.lib.rvlm_vit_forward(self._h32, x.data_ptr(), L.ptr(d), B, int(bool(output_normalize)), 1,
+                                                  emb.data_ptr(), L.stream_ptr()), "rvlm_vit_forward")
             d_emb = _f32c(cot) if cot is not None else ((emb - _f32c(ref)) * (2.0 / B)).contiguous()
             L.check(self.lib.rvlm_vit_backward_input_from(self._h, self._h32, d_emb.data_ptr(), B, g.data_ptr(), L.stream_ptr()),
                     "rvlm_vit_backward_input_from")
@@ -284,7 +290,7 @@ class VitEngine:
         with torch.cuda.device(x.device):
             if self.mixed:
                 fn = self.lib.rvlm_pgd_run_mixed_fwd if self.handoff else self.lib.rvlm_pgd_run_mixed
-                L.check(fn(self._h, self._h32, 1, x.data_ptr(), L.ptr(d0), x.shape[0],
+                L.check(fn(self._h, self._h32, self.n_first, x.data_ptr(), L.ptr(d0), x.shape[0],
                            C.byref(ls), int(norm_kind), float(eps), int(iterations),
                            float(stepsize), float(momentum), 1 if mode == "max" else 0,
                            out.data_ptr(), L.ptr(trace), flags.data_ptr(), L.stream_ptr()),

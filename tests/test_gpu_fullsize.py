@@ -627,6 +627,17 @@ def test_config2_x3_forward_bf16_backward_first_iteration(setup):
         assert same_mixed > 0.90, same_mixed
     finally:
         eng.close()
+    # 'bf16+x3fwd': the same split (split-bf16 forward, bf16 backward) in EVERY iteration
+    eng = R.VitEngine(to_cfg(s["cfg"]), wd, precision="bf16+x3fwd", max_batch=NP)
+    try:
+        model = R.ClipVisionModel(eng).eval()
+        xa = run(model, model(x, False), 10)
+        ball_and_range(xa, x)
+        same_all = float((xa.cpu() == torch.from_numpy(GOLD["pgd_x_adv"])).float().mean())
+        record("config2_x3fwd_all", same_pixels_x3fwd_every_iteration_vs_reference=same_all)
+        assert same_all > same_mixed, (same_all, same_mixed)
+    finally:
+        eng.close()
 
 
 def test_clip_like_x3_vs_reference(setup_clip):

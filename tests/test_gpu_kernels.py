@@ -543,3 +543,38 @@ def test_softmax_rows_fp32(cols, ld):
     torch.cuda.synchronize()
     assert float((dp[:, :cols].double() - want).abs().max()) < 5e-7, float((dp[:, :cols].double() - want).abs().max())
     assert bool((dp[:, cols:] == 555.0).all())
+
+
+@pytest.mark.parametrize("S", [257, 50, 197, 33, 17, 288])
+def test_attn_fwd_f32_flash(S):
+    """The fp32 flash forward of the fp32-storage engines (round 6, csrc/attention_f32.hip: v_mfma_f32_32x32x2_f32, no score
+    matrices) against torch fp64: output, the log-sum-exp rows in the bf16 flash kernels' convention, and the bf16 copies of
+    q | k | v and o it writes for the handoff.  Full key tiles run on the matrix pipe, the remainder keys on the VALU: 257 = 8
+    tiles + 1, 50 = 1 + 18, 17 = none + 17, 288 = 9 + 0."""
+    l = lib()
+    B, H = 3, 2
+    W = 64 * H
+    g = torch.Generator(device=dev()).manual_seed(S)
+    qkv = torch.randn(B * S, 3 * W, generator=g, device=dev())
+    qkv[:, :W] *= 2.0                                   # logits with a spread of a few units
+    o = torch.full((B * S, W), float("nan"), device=dev())
+    Sp = (S + 31) // 32 * 32
+    lse = torch.full((B * H, Sp), 123.0, device=dev())
+    qkv_bf = torch.zeros(B * S, 3 * W, dtype=torch.bfloat16, device=dev())
+    o_bf = torch.zeros(B * S, W, dtype=torch.bfloat16, device=dev())
+    L.check(l.rvlm_k_attn_fwd_f32_flash(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), qkv_bf.data_ptr(), o_bf.data_ptr(), B, H, S, st()))
+    torch.cuda.synchronize()
+    q, k, v = (t.reshape(B, S, H, 64).transpose(1, 2).double() for t in qkv.split(W, dim=1))
+    sc = q @ k.transpose(-1, -2) * 0.125
+    want = (torch.softmax(sc, -1) @ v).transpose(1, 2).reshape(B * S, W)
+    err = float((o.double() - want).abs().max() / want.abs().max())
+    assert err < 2e-6, err
+    want_lse = torch.logsumexp(sc, -1) * 1.4426950408889634          # [B, H, S]
+    assert float((lse.reshape(B, H, Sp)[:, :, :S].double() - want_lse).abs().max()) < 1e-5
+    assert bool((lse.reshape(B, H, Sp)[:, :, S:] == 123.0).all())
+    assert torch.equal(qkv_bf, qkv.to(torch.bfloat16)) and torch.equal(o_bf, o.to(torch.bfloat16))
+    # without the optional outputs
+    o2 = torch.empty_like(o)
+    L.check(l.rvlm_k_attn_fwd_f32_flash(qkv.data_ptr(), o2.data_ptr(), None, None, None, B, H, S, st()))
+    torch.cuda.synchronize()
+    assert torch.equal(o2, o)
