@@ -69,6 +69,68 @@ attn_fwd_f32_flash_kernel(const float* __restrict__ qkv, long ld, float* __restr
         for (int j = 0; j < 32; ++j) qf[j] *= scale_log2;
     }
     __syncthreads();
+    // ---- a last query tile of only 1-4 rows (S = 257: the class token's "+1") does not get an MFMA tile walk - with NT waves on 4
+    // SIMDs its wave is the third on SIMD 0, and a whole walk (NK x 64 MFMAs = NK x 4 096 matrix-pipe cycles) for one valid row of 32
+    // made that SIMD the kernel's critical path.  Its rows run on the VALU instead: lane <-> key for the scores (K rows by the same
+    // conflict-free 16-byte reads), probabilities through S floats of LDS, lane <-> head dim for P V: ~5 k cycles per row.
+    const int nrem = S - (NT - 1) * 32;
+    if (w == NT - 1 && nrem <= 4) {
+        constexpr int NP = (NT + 1) / 2;                    // passes of 64 keys
+        float* Ps = Vs + Sp * 64;                           // [Sp] probabilities of the row in flight (this wave only)
+        for (int qi = 0; qi < nrem; ++qi) {
+            const int qr = (NT - 1) * 32 + qi;
+            const float* qp = base + (long)qr * ld;
+            float qv[64];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) *(float4*)&qv[4 * j] = *(const float4*)(qp + 4 * j);
+            if (base_bf && lane < 8) {
+                const float4 a = *(const float4*)(qp + 8 * lane), c = *(const float4*)(qp + 8 * lane + 4);
+                const bf16x8 t = {(bf16_t)a.x, (bf16_t)a.y, (bf16_t)a.z, (bf16_t)a.w, (bf16_t)c.x, (bf16_t)c.y, (bf16_t)c.z, (bf16_t)c.w};
+                *(bf16x8*)(base_bf + (long)qr * ld_bf + 8 * lane) = t;
+            }
+#pragma unroll
+            for (int j = 0; j < 64; ++j) qv[j] *= scale_log2;
+            float sc[NP], mx = -INFINITY;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const int key = p * 64 + lane;
+                const float* kr = Ks + min(key, Sp - 1) * AF_KLD;
+                float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 16; j += 2) {
+                    const float4 k0 = *(const float4*)(kr + 4 * j), k1 = *(const float4*)(kr + 4 * j + 4);
+                    a0 = fmaf(k0.x, qv[4 * j], a0); a0 = fmaf(k0.y, qv[4 * j + 1], a0); a0 = fmaf(k0.z, qv[4 * j + 2], a0); a0 = fmaf(k0.w, qv[4 * j + 3], a0);
+                    a1 = fmaf(k1.x, qv[4 * j + 4], a1); a1 = fmaf(k1.y, qv[4 * j + 5], a1); a1 = fmaf(k1.z, qv[4 * j + 6], a1); a1 = fmaf(k1.w, qv[4 * j + 7], a1);
+                }
+                sc[p] = key < S ? a0 + a1 : -INFINITY;
+                mx = fmaxf(mx, sc[p]);
+            }
+            mx = wave_max(mx);
+            float lsum = 0.0f;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const float e = __builtin_amdgcn_exp2f(sc[p] - mx);
+                lsum += e;
+                if (p * 64 + lane < Sp) Ps[p * 64 + lane] = e;
+            }
+            lsum = wave_sum(lsum);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (one wave: its LDS writes are ordered in front of its reads)
+            float acc0 = 0.0f, acc1 = 0.0f;
+            const int S4 = (S + 3) & ~3;                            // (rows S .. Sp - 1 of V are zero, their probabilities too)
+            for (int key = 0; key < S4; key += 4) {
+                const float4 p4 = *(const float4*)(Ps + key);
+                const float* vk = Vs + key * 64 + lane;
+                acc0 = fmaf(p4.x, vk[0], acc0); acc1 = fmaf(p4.y, vk[64], acc1);
+                acc0 = fmaf(p4.z, vk[128], acc0); acc1 = fmaf(p4.w, vk[192], acc1);
+            }
+            const float ov = (acc0 + acc1) / lsum;
+            o[((long)b * S + qr) * ldo + h * 64 + lane] = ov;
+            if (o_bf) o_bf[((long)b * S + qr) * ldo_bf + h * 64 + lane] = (bf16_t)ov;
+            if (lse2 && lane == 0) lse2[((long)b * H + h) * lse_ld + qr] = mx + log2f(lsum);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the next row's probabilities overwrite Ps
+        }
+        return;
+    }
     f32x16 oacc[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -170,7 +232,7 @@ bool attn_fwd_f32_flash(const float* qkv, float* o, float* lse2, int lse_ld, bf1
     const int W = H * 64, NT = (S + 31) / 32;
     *rc_out = RVLM_OK;
     if (NT < 1 || NT > 9 || (((size_t)qkv | (size_t)o) & 15)) return false;
-    const size_t lds = (size_t)NT * 32 * (AF_KLD + 64) * sizeof(float);
+    const size_t lds = (size_t)NT * 32 * (AF_KLD + 64 + 1) * sizeof(float);     // K | V | one row of probabilities
     if (lds > 160 * 1024) return false;
     const float sl2 = 0.125f * 1.4426950408889634f;
 #define RVLM_AF_CASE(N)                                                                                                             \

@@ -666,3 +666,35 @@ def test_clip_like_x3_vs_reference(setup_clip):
         assert same > 0.97, same
     finally:
         eng3.close()
+
+
+def test_clip_like_x3_forward_bf16_backward(setup_clip):
+    """The handoff (precision='bf16+x3fwd-first' / 'bf16+x3fwd') on the CLIP-like tower: first-iteration gradient signs against the
+    REFERENCE's own (emulation: 0.9955 with the flash-style backward), ten-step pgd() against the reference's."""
+    s = setup_clip
+    n = s["n"]
+    w = V.init_weights(s["cfg"], seed=3, clip_like=True)
+    wd = {k: v.to(dev()) for k, v in w.items()}
+    out = {}
+    for prec in ("bf16+x3fwd-first", "bf16+x3fwd"):
+        eng = R.VitEngine(to_cfg(s["cfg"]), wd, precision=prec, max_batch=n)
+        try:
+            x, d0 = s["x"][:n].to(dev()), s["d0"][:n].to(dev())
+            model = R.ClipVisionModel(eng).eval()
+            e0 = model(x, False)
+            assert rel(e0.cpu(), torch.from_numpy(GOLDC["pgd_e0"])) < 1e-4
+            xa = R.pgd(model, R.ComputeLossWrapper(e0, None, "mean", "l2", 100.), x, None, "linf", EPS, 10, STEP, False,
+                       perturbation=d0.clone(), mode="max")
+            out[prec] = float((xa.cpu() == torch.from_numpy(GOLDC["pgd_x_adv"])).float().mean())
+            if prec == "bf16+x3fwd-first":
+                ns = int(GOLDC["traj_n"])
+                _, g = eng.handoff_inputgrad(x, d0, ref=e0)
+                sg = GOLDC["traj_grad_sign"][0]
+                sign0 = float(np.mean((np.sign(g[:ns].cpu().numpy()) == sg)[sg != 0]))
+        finally:
+            eng.close()
+    record("clip_like_x3fwd", sign_agree_it0_x3fwd_vs_reference=sign0, same_pixels_x3fwd_first_vs_reference=out["bf16+x3fwd-first"],
+           same_pixels_x3fwd_every_iteration_vs_reference=out["bf16+x3fwd"])
+    assert sign0 > 0.99, sign0
+    assert out["bf16+x3fwd-first"] > 0.85, out
+    assert out["bf16+x3fwd"] > 0.95, out
