@@ -134,6 +134,10 @@ int rvlm_vit_backward_input_from(rvlm_vit* h, rvlm_vit* h_saved, const float* d_
  * bf16 tensors rvlm_vit_backward_input_from(consumer, h, ...) reads are written by the forward itself instead of by export passes. */
 int rvlm_vit_forward_for(rvlm_vit* h, rvlm_vit* consumer, const float* x, const float* delta, int B, int output_normalize,
                          float* out_emb, rvlm_stream_t stream);
+/* Non-saving forwards of an fp32-storage handle on the fp32 flash attention as well (default off: a handle's saving and non-saving
+ * forwards agree bit for bit, which FARE's zero gradient at delta = 0 relies on; switch it on for the handle whose saving forwards
+ * are all rvlm_vit_forward_for, so that its clean embedding and its first-iteration embedding share one arithmetic).  ABI 109. */
+int rvlm_vit_set_flash_inference(rvlm_vit* h, int on);
 
 /* Weight gradients of the outer training step (loss_total.backward(), …clip.py:361): for the last
  * forward run with save_for_backward == 2 on a `trainable` handle, writes (accumulate == 0) or adds
@@ -399,7 +403,7 @@ int rvlm_version(void);   /* = RVLM_VERSION.  101: rvlm_loss_spec.y_target, rvlm
                            * rvlm_vit_backward_params_stages refuses out-of-order stages; 105: rvlm_apgd_controller_rho,
                            * rvlm_vit_set_apgd_rho, rvlm_comm_* / rvlm_allreduce_grads; 106: rvlm_pgd_run_mixed, fp32 mode on v_mfma_f32_32x32x2_f32;
                            * 107: rvlm_l2_random_start; 108: RVLM_PREC_F32X3 (split-bf16 linears over fp32 storage);
-                           * 109: rvlm_vit_backward_input_from, rvlm_vit_forward_for, rvlm_pgd_run_mixed_fwd (fp32-storage forward, bf16 backward) */
+                           * 109: rvlm_vit_backward_input_from, rvlm_vit_forward_for, rvlm_vit_set_flash_inference, rvlm_pgd_run_mixed_fwd (fp32-storage forward, bf16 backward) */
 
 #ifdef __cplusplus
 }

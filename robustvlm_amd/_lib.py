@@ -142,6 +142,7 @@ _SIGS = {
                                          C.c_float, C.c_int, C.c_float, C.c_float, C.c_int, c_f32p, c_f32p, C.c_void_p,
                                          c_stream]),
     "rvlm_vit_backward_input_from": (C.c_int, [C.c_void_p, C.c_void_p, c_f32p, C.c_int, c_f32p, c_stream]),
+    "rvlm_vit_set_flash_inference": (C.c_int, [C.c_void_p, C.c_int]),
     "rvlm_vit_forward_for": (C.c_int, [C.c_void_p, C.c_void_p, c_f32p, c_f32p, C.c_int, C.c_int, c_f32p, c_stream]),
     "rvlm_apgd_run": (C.c_int, [C.c_void_p, c_f32p, c_f32p, C.c_int, C.POINTER(LossSpecC), C.c_float,
                                 C.c_int, C.c_float, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p,

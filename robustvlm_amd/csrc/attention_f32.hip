@@ -3,7 +3,8 @@
 // Why (round 6): the fp32 attention path materialises the score matrices - one batched product, an in-place softmax pass, a second
 // batched product: 2.2 GB of traffic and 21.9 ms per ViT-L/14 forward at B = 128 (scripts/x3_forward_profile.py), a quarter of a
 // split-bf16 forward.  The kept probabilities are what that engine's OWN backward reads; a forward whose input gradient runs on the
-// bf16 handle (the handoff, engine.hip::vit_backward_from) or that has no backward at all (clean embeddings) does not need them.
+// bf16 handle (the handoff, engine.hip::vit_backward_from) does not need them (the clean embedding of such an engine takes this
+// kernel too - rvlm_vit_set_flash_inference - so that it shares one arithmetic with the first iteration's embedding).
 // Here one workgroup owns an (image, head) pair: K and V fp32 in LDS (K rows padded to 68 floats: the A-operand reads are
 // ds_read_b128 down the keys), wave w owns query tile w, S^T = K Q^T in the swapped orientation (one query per lane: row statistics
 // are per-lane scalars and P^T is already the B operand of O^T = V^T P^T, register for register - the contraction index of a

@@ -60,7 +60,12 @@ struct rvlm_vit {
     bool exported_dact = false;          // ... and its act'(fc1)
     bf16_t* cur_dact_out = nullptr;      // the peer's act'(fc1) buffer of the block the forward is in
     bf16_t *cur_qkv_bf = nullptr, *cur_o_bf = nullptr;
-    bool cur_flash = false;              // this forward's attention runs as the flash kernel (save == 0, or a forward for a peer)
+    bool cur_flash = false;              // this forward's attention runs as the flash kernel
+    // Non-saving forwards on the flash kernel too (rvlm_vit_set_flash_inference).  OFF by default: a handle's saving and non-saving
+    // forwards must agree BIT FOR BIT - FARE's loss at delta = 0 is |phi(x) - phi(x)|^2 = 0 with a zero gradient exactly (apgd_train
+    // starts there, train/apgd_train.py:157-160), and 1e-7 of rounding difference between two attention paths turns that into a
+    // random sign pattern.  ON for the fp32-storage handle of a handoff engine, whose saving forwards (run for the peer) are flash.
+    bool flash_inference = false;
     std::vector<void*> h_pre;    // L x [Mp, 4W] T
     void* g_act;         // [Mp, 4W] T
     float *pooled, *emb_raw, *inv_norm;   // [maxB, W], [maxB, D], [maxB]
@@ -475,10 +480,10 @@ static int forward_impl(rvlm_vit* h, const float* x, const float* delta, int B, 
     // xs / qkv / attn_o / lse, pooled, emb_raw, inv_norm): a non-saving pass therefore invalidates the saved forward
     // instead of letting a later backward run on a mixture of two passes.
     h->saved_B = 0;
-    // a forward FOR a peer (handoff) is a saving forward of an fp32-storage handle; non-saving forwards of such handles use the flash
-    // attention too (nothing reads their probabilities)
+    // a forward FOR a peer (handoff) is a saving forward of an fp32-storage handle; it overwrites the peer's bf16 tensors
     rvlm_vit* const peer = (!h->bf16 && save == 1) ? h->peer : nullptr;
-    h->cur_flash = !h->bf16 && (save == 0 || peer != nullptr);
+    if (peer) peer->saved_B = 0;
+    h->cur_flash = !h->bf16 && (peer != nullptr || (save == 0 && h->flash_inference));
     h->exported_to = nullptr; h->exported_dact = false;
     h->cur_qkv_bf = h->cur_o_bf = nullptr; h->cur_dact_out = nullptr;
     {
@@ -1166,6 +1171,12 @@ extern "C" int rvlm_vit_backward_input(rvlm_vit* h, const float* d_emb, int B, f
     if (h->saved_B != B || B <= 0)
         return fail(RVLM_ERR_STATE, "rvlm_vit_backward_input: no saved forward for this batch size");
     return vit_backward(h, d_emb, B, grad_x, (hipStream_t)stream);
+}
+
+extern "C" int rvlm_vit_set_flash_inference(rvlm_vit* h, int on) {
+    RVLM_REQUIRE(h, "rvlm_vit_set_flash_inference: null handle");
+    h->flash_inference = on != 0 && !h->bf16;
+    return RVLM_OK;
 }
 
 extern "C" int rvlm_vit_forward_for(rvlm_vit* h, rvlm_vit* consumer, const float* x, const float* delta, int B, int output_normalize,

@@ -86,6 +86,8 @@ class VitEngine:
                 c.precision = L.PREC_F32 if precision == "bf16+fp32-first" else L.PREC_F32X3
                 L.check(self.lib.rvlm_vit_create(C.byref(c), C.byref(w), L.stream_ptr(), C.byref(self._h32)),
                         "rvlm_vit_create (fp32 handle)")
+                if self.handoff:     # its saving forwards are flash (run for the bf16 handle): the clean embedding too, bit-consistently
+                    L.check(self.lib.rvlm_vit_set_flash_inference(self._h32, 1), "rvlm_vit_set_flash_inference")
         del keep
 
     # ---- weights ------------------------------------------------------------------------------

@@ -597,7 +597,7 @@ def test_fwd_inputgrad_single_call_equals_the_three_calls(loss_name):
     l2v = R.compute_loss(loss_name, e2, y.to(dev()), e0.to(dev()), 100., T.to(dev()))
     (g2,) = torch.autograd.grad(l2v, dd)
     assert torch.equal(e2.detach(), emb) and torch.equal(g2, gx)
-    assert float(l2v) == float(scalar)
+    assert float(l2v.detach()) == float(scalar)
     eng.close()
 
 
@@ -815,6 +815,9 @@ def test_handoff_backward_from_x3_forward(shape, normalize):
         sign_16 = float((torch.sign(gf16.cpu()) == torch.sign(g_fare)).float().mean())
         assert sign_h > 0.985, (sign_h, sign_16)
         assert sign_h > sign_16, (sign_h, sign_16)
+        # a zero perturbation gives a ZERO loss exactly: the clean embedding and the first iteration's share one arithmetic
+        emb_z, g_z = eng.handoff_inputgrad(xd, None, ref=e0, output_normalize=normalize)
+        assert torch.equal(emb_z, e0) and float(g_z.abs().max()) == 0.0
         # the handoff invalidated the bf16 handle's own saved forward (its bf16 tensors were overwritten by the exports)
         with pytest.raises(L.RvlmError):
             eng.backward_input(cot.to(dev()))
