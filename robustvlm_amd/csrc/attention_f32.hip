@@ -226,15 +226,20 @@ attn_fwd_f32_flash_kernel(const float* __restrict__ qkv, long ld, float* __restr
 
 static unsigned long long g_af_attr[17];
 
+// sequence lengths the kernel takes: one wave per query tile (<= 9: K and V of a head must fit the CU's 160 KiB of LDS in fp32)
+bool attn_fwd_f32_flash_covers(int S) {
+    const int NT = (S + 31) / 32;
+    return NT >= 1 && NT <= 9 && (size_t)NT * 32 * (AF_KLD + 64 + 1) * sizeof(float) <= 160 * 1024;
+}
+
 // O = softmax(0.125 Q K^T) V, qkv fp32 [B * S, 3 W] (q | k | v, head h at columns 64 h), o fp32 [B * S, W].  Optional: lse2
 // [B * H, lse_ld], bf16 copies qkv_bf [B * S, 3 W] / o_bf [B * S, W].  false: shape not covered (the caller runs the batched path).
 bool attn_fwd_f32_flash(const float* qkv, float* o, float* lse2, int lse_ld, bf16_t* qkv_bf, bf16_t* o_bf, int B, int H, int S, hipStream_t s,
                         int* rc_out) {
     const int W = H * 64, NT = (S + 31) / 32;
     *rc_out = RVLM_OK;
-    if (NT < 1 || NT > 9 || (((size_t)qkv | (size_t)o) & 15)) return false;
+    if (!attn_fwd_f32_flash_covers(S) || (((size_t)qkv | (size_t)o) & 15)) return false;
     const size_t lds = (size_t)NT * 32 * (AF_KLD + 64 + 1) * sizeof(float);     // K | V | one row of probabilities
-    if (lds > 160 * 1024) return false;
     const float sl2 = 0.125f * 1.4426950408889634f;
 #define RVLM_AF_CASE(N)                                                                                                             \
     case N: {                                                                                                                       \

@@ -481,9 +481,12 @@ static int forward_impl(rvlm_vit* h, const float* x, const float* delta, int B, 
     // instead of letting a later backward run on a mixture of two passes.
     h->saved_B = 0;
     // a forward FOR a peer (handoff) is a saving forward of an fp32-storage handle; it overwrites the peer's bf16 tensors
-    rvlm_vit* const peer = (!h->bf16 && save == 1) ? h->peer : nullptr;
+    // (sequence lengths the flash kernel does not take - S = 577 at 336 px - run the batched attention path as before: the handoff then
+    // exports the bf16 tensors itself and takes the log-sum-exp rows the softmax pass wrote, vit_backward_from)
+    const bool flash_ok = !h->bf16 && attn_fwd_f32_flash_covers(h->S);
+    rvlm_vit* const peer = (flash_ok && save == 1) ? h->peer : nullptr;
     if (peer) peer->saved_B = 0;
-    h->cur_flash = !h->bf16 && (peer != nullptr || (save == 0 && h->flash_inference));
+    h->cur_flash = flash_ok && (peer != nullptr || (save == 0 && h->flash_inference));
     h->exported_to = nullptr; h->exported_dact = false;
     h->cur_qkv_bf = h->cur_o_bf = nullptr; h->cur_dact_out = nullptr;
     {

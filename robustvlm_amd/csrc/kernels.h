@@ -143,6 +143,7 @@ int attn_bwd_bf16(const bf16_t* qkv, long ldqkv, const bf16_t* o, long ldo, cons
                   int B, int H, int S, hipStream_t s);
 // fp32 flash forward (attention_f32.hip): O = softmax(0.125 Q K^T) V without materialised scores, on v_mfma_f32_32x32x2_f32; optional
 // lse2 rows (the bf16 flash kernels' convention) and bf16 copies of q | k | v and o.  false: shape not covered.
+bool attn_fwd_f32_flash_covers(int S);
 bool attn_fwd_f32_flash(const float* qkv, float* o, float* lse2, int lse_ld, bf16_t* qkv_bf, bf16_t* o_bf, int B, int H, int S, hipStream_t s,
                         int* rc_out);
 // class-token attention of the last block (only the class token's query row is live there): o [B, W] (row b = image b),
