@@ -382,7 +382,10 @@ class AdversarialTrainer:
         return logs
 
     def state_dict(self):
-        """open_clip ``visual.state_dict()`` of the fine-tuned tower (what …clip.py:239,470 saves)."""
+        """open_clip ``visual.state_dict()`` of the fine-tuned tower (what …clip.py:239,470 saves).  Checkpoint time is also where
+        the LAST step's deferred ``global_batch`` check is settled (it is otherwise read at the start of the next step: a wrong
+        value passed with an epoch's final partial batch would never be reported)."""
+        self._verify_pending_global_batch()
         return self.params.state_dict()
 
     # -- optimizer state: the file torch.optim.AdamW.state_dict() would write for visual.parameters() ---------------
@@ -442,5 +445,8 @@ class AdversarialTrainer:
         self.engine.load_state_dict(self.params.views)
 
     def close(self):
-        self.engine.close()
-        self.engine_orig.close()
+        try:
+            self._verify_pending_global_batch()      # (the last step's deferred check; raised after the engines are released)
+        finally:
+            self.engine.close()
+            self.engine_orig.close()
