@@ -56,7 +56,8 @@ struct rvlm_vit {
     // own backward is refused for that pass, saved_mode 3), which writes the peer's bf16 qkv / attention output / log-sum-exp rows as
     // it goes; the split-bf16 activation pass writes the peer's act'(fc1).  What was exported is remembered per saved forward.
     rvlm_vit* peer = nullptr;
-    rvlm_vit* exported_to = nullptr;     // the saved forward's bf16 qkv / attention output / lse rows already sit in this handle
+    unsigned long long uid = 0;          // unique per created handle (never reused, unlike an address)
+    unsigned long long exported_to = 0;  // uid of the handle the saved forward's bf16 qkv / attention output / lse rows already sit in
     bool exported_dact = false;          // ... and its act'(fc1)
     bf16_t* cur_dact_out = nullptr;      // the peer's act'(fc1) buffer of the block the forward is in
     bf16_t *cur_qkv_bf = nullptr, *cur_o_bf = nullptr;
@@ -487,7 +488,7 @@ static int forward_impl(rvlm_vit* h, const float* x, const float* delta, int B, 
     rvlm_vit* const peer = (flash_ok && save == 1) ? h->peer : nullptr;
     if (peer) peer->saved_B = 0;
     h->cur_flash = flash_ok && (peer != nullptr || (save == 0 && h->flash_inference));
-    h->exported_to = nullptr; h->exported_dact = false;
+    h->exported_to = 0; h->exported_dact = false;
     h->cur_qkv_bf = h->cur_o_bf = nullptr; h->cur_dact_out = nullptr;
     {
         PROF("patch_im2col", 0, (double)B * 3 * h->img * h->img * (delta ? 8 : 4) + (double)M0 * h->Kpad * sizeof(T));
@@ -559,7 +560,7 @@ static int forward_impl(rvlm_vit* h, const float* x, const float* delta, int B, 
         {
             PROF("attn_fwd", attn_flops, 0);
             h->cur_lse2 = (save && !h->lse2.empty()) ? h->lse2[sl] : nullptr;
-            if (peer) { h->cur_lse2 = peer->lse[l]; h->cur_qkv_bf = (bf16_t*)peer->qkv[l]; h->cur_o_bf = (bf16_t*)peer->attn_o[l]; }
+            if (peer) { h->cur_qkv_bf = (bf16_t*)peer->qkv[l]; h->cur_o_bf = (bf16_t*)peer->attn_o[l]; }   // (the lse rows stay in h->lse2)
             if ((rc = attention_fwd<T>(h, s, h->qkv[sl], h->attn_o[sl], h->lse[sl], B))) return rc;
         }
         {
@@ -604,7 +605,7 @@ static int forward_impl(rvlm_vit* h, const float* x, const float* delta, int B, 
         }
     }
     if (save) { h->saved_B = B; h->saved_norm = normalize != 0; h->saved_mode = save; h->next_param_stage = 0; }
-    if (peer) { h->saved_mode = 3; h->exported_to = peer; }      // (3: for the peer's backward only - no probabilities were kept)
+    if (peer) { h->saved_mode = 3; h->exported_to = peer->uid; }      // (3: for the peer's backward only - no probabilities were kept)
     h->cur_flash = false; h->cur_qkv_bf = h->cur_o_bf = nullptr; h->cur_lse2 = nullptr;
     return RVLM_OK;
 }
@@ -938,24 +939,23 @@ static int vit_backward_from(rvlm_vit* hb, rvlm_vit* hx, const float* d_emb, int
     int rc;
     {
         PROF("handoff_export", 0, (double)M * W * (3 * 6 + 6 + 4 * 6) * L);
-        const bool have_qo = hx->exported_to == hb, have_dact = have_qo && hx->exported_dact;     // written by the forward itself
+        const bool have_qo = hx->exported_to == hb->uid, have_dact = have_qo && hx->exported_dact;     // written by the forward itself
         for (int l = 0; l < L; ++l) {
             if (!have_qo && (rc = x3_export_bf16((const float*)hx->qkv[l], 3 * W, (bf16_t*)hb->qkv[l], 3 * W, M, 3 * W, 0, 0, s))) return rc;
             if (!have_qo && (rc = x3_export_bf16((const float*)hx->attn_o[l], W, (bf16_t*)hb->attn_o[l], W, M, W, 0, 0, s))) return rc;
             if (!have_dact && (rc = x3_export_bf16((const float*)hx->h_pre[l], 4 * W, (bf16_t*)hb->h_pre[l], 4 * W, M, 4 * W, hb->cfg.act, 1, s))) return rc;
         }
     }
-    const bool swap_lse = hx->exported_to != hb;      // (a forward run for hb wrote hb's log-sum-exp rows itself)
     struct Swap {      // hb reads hx's fp32 state in place; restored on every exit path
-        rvlm_vit *a, *b; bool lse;
-        Swap(rvlm_vit* a_, rvlm_vit* b_, bool lse_) : a(a_), b(b_), lse(lse_) { swap(); }
+        rvlm_vit *a, *b;
+        Swap(rvlm_vit* a_, rvlm_vit* b_) : a(a_), b(b_) { swap(); }
         ~Swap() { swap(); }
         void swap() {
             std::swap(a->xs, b->xs); std::swap(a->st_mean, b->st_mean); std::swap(a->st_rstd, b->st_rstd);
             std::swap(a->patch_out, b->patch_out); std::swap(a->emb_raw, b->emb_raw); std::swap(a->inv_norm, b->inv_norm);
-            if (lse) std::swap(a->lse, b->lse2);
+            std::swap(a->lse, b->lse2);
         }
-    } swapped(hb, hx, swap_lse);
+    } swapped(hb, hx);
     const bool tail = hb->cls_tail;
     const bool sn = hb->saved_norm;
     hb->cls_tail = false; hb->saved_norm = hx->saved_norm;
@@ -1004,6 +1004,8 @@ extern "C" int rvlm_vit_create(const rvlm_vit_config* cfg, const rvlm_vit_weight
     RVLM_REQUIRE(cfg->width <= 2048, "rvlm_vit_create: width > 2048 unsupported");
     hipStream_t s = (hipStream_t)stream;
     rvlm_vit* h = new rvlm_vit();
+    static unsigned long long next_uid = 0;
+    h->uid = __atomic_add_fetch(&next_uid, 1, __ATOMIC_RELAXED);
     h->cfg = *cfg;
     h->bf16 = cfg->precision == RVLM_PREC_BF16;
     h->x3 = cfg->precision == RVLM_PREC_F32X3;
