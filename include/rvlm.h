@@ -74,7 +74,10 @@ typedef struct {
     float mean[3];      /* Normalize constants, …clip.py:116 */
     float std[3];
     int32_t trainable;  /* > 0: also keep what the weight-gradient backward needs (rvlm_vit_backward_params);
-                           < 0: inference only (frozen model_orig copy): no per-layer activation storage */
+                           -1: inference only (frozen model_orig copy): no per-layer activation storage;
+                           -2 (ABI 109, fp32-storage precisions): forward PROVIDER of a bf16 handle - its saving forwards are all
+                           rvlm_vit_forward_for / rvlm_pgd_run_mixed_fwd: per-block residual stream and statistics only, no
+                           backward scratch, no probabilities (51 -> 13 GiB at ViT-L/14, B = 128); on a bf16 handle -2 means -1 */
 } rvlm_vit_config;
 
 /* fp32 device pointers in `visual.state_dict()` layout (…clip.py:239,470; Appendix B key list). */

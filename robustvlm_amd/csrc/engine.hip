@@ -86,6 +86,11 @@ struct rvlm_vit {
     // training (cfg.trainable): inputs of every linear layer + embedding tokens + transpose scratch
     bool trainable = false;
     bool inference_only = false;
+    bool provider = false;       // cfg.trainable == -2: an fp32-storage handle whose saving forwards are all run FOR a bf16 handle
+                                 // (rvlm_vit_forward_for / rvlm_pgd_run_mixed_fwd) on the flash attention: the fp32 residual stream, the
+                                 // LayerNorm statistics and the log-sum-exp rows are kept per block; qkv, attention output, fc1
+                                 // pre-activation and probabilities have ONE slot (their bf16 forms are written into the consumer as
+                                 // the forward goes), and there is no backward scratch: 51 -> 13 GiB at ViT-L/14, B = 128
     std::vector<void*> ln1_out, ln2_out, g_act_l;   // L x [Mp,W], [Mp,W], [Mp,4W] T
     float *tokens, *dtok;      // [Mp, W] f32
     void *tA, *tB;             // bf16 mode: transposed operands of the wgrad GEMMs the copy-free form does not take
@@ -120,7 +125,7 @@ struct rvlm_vit {
 namespace rvlm {
 
 static int dev_alloc(rvlm_vit* h, void** p, size_t bytes, bool zero = true) {
-    bytes = (bytes + 255) & ~(size_t)255;
+    bytes = std::max<size_t>((bytes + 255) & ~(size_t)255, 256);
     hipError_t e = hipMalloc(p, bytes);
     if (e != hipSuccess) return fail(RVLM_ERR_HIP, std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e));
     if (zero) {
@@ -290,7 +295,12 @@ int linear_fwd<float>(rvlm_vit* h, hipStream_t s, const void* A, long lda, int M
     g.C = (float*)out; g.scm = ldo; g.scn = 1;
     g.M = M; g.N = N; g.K = K; g.bias = bias; g.residual = residual;
     if (epi == EPI_BF16_ACT) { g.act = h->cfg.act; g.C_pre = (float*)out_pre; }
-    return gemm_f32(g, s);
+    int rc = gemm_f32(g, s);
+    if (rc == RVLM_OK && epi == EPI_BF16_ACT && h->cur_dact_out && out_pre) {      // a forward for a peer on the fp32 tiles: act'(h) for it
+        rc = x3_export_bf16((const float*)out_pre, ldo, h->cur_dact_out, ldo, M, N, h->cfg.act, 1, s);
+        h->exported_dact = true;
+    }
+    return rc;
 }
 // dgrad: out[M,K] = epi(dY[M,N] @ W[N,K])   (w_t = W^T stored [K,N] for the bf16 path)
 template <typename T>
@@ -486,6 +496,9 @@ static int forward_impl(rvlm_vit* h, const float* x, const float* delta, int B, 
     // exports the bf16 tensors itself and takes the log-sum-exp rows the softmax pass wrote, vit_backward_from)
     const bool flash_ok = !h->bf16 && attn_fwd_f32_flash_covers(h->S);
     rvlm_vit* const peer = (flash_ok && save == 1) ? h->peer : nullptr;
+    if (h->provider && save != 0 && !peer)
+        return fail(RVLM_ERR_STATE, "forward: this handle was created as a forward provider (trainable = -2): its saving forwards are run "
+                                    "for a bf16 handle (rvlm_vit_forward_for, rvlm_pgd_run_mixed_fwd)");
     if (peer) peer->saved_B = 0;
     h->cur_flash = flash_ok && (peer != nullptr || (save == 0 && h->flash_inference));
     h->exported_to = 0; h->exported_dact = false;
@@ -940,6 +953,8 @@ static int vit_backward_from(rvlm_vit* hb, rvlm_vit* hx, const float* d_emb, int
     {
         PROF("handoff_export", 0, (double)M * W * (3 * 6 + 6 + 4 * 6) * L);
         const bool have_qo = hx->exported_to == hb->uid, have_dact = have_qo && hx->exported_dact;     // written by the forward itself
+        if (hx->provider && !(have_qo && have_dact))
+            return fail(RVLM_ERR_STATE, "handoff: the forward-provider handle's saved pass was not run for this bf16 handle");
         for (int l = 0; l < L; ++l) {
             if (!have_qo && (rc = x3_export_bf16((const float*)hx->qkv[l], 3 * W, (bf16_t*)hb->qkv[l], 3 * W, M, 3 * W, 0, 0, s))) return rc;
             if (!have_qo && (rc = x3_export_bf16((const float*)hx->attn_o[l], W, (bf16_t*)hb->attn_o[l], W, M, W, 0, 0, s))) return rc;
@@ -1028,7 +1043,10 @@ extern "C" int rvlm_vit_create(const rvlm_vit_config* cfg, const rvlm_vit_weight
         rc = dev_alloc(h, (void**)&h->a3, Mp * 12 * W * 2, false);
         if (rc) { rvlm_vit_destroy(h); return rc; }
     }
-    const bool inference_only = cfg->trainable < 0;   // no backward of any kind: one slot per buffer kind
+    // (a provider needs the flash forward for its sequence length: otherwise the handoff exports from per-block fp32 tensors)
+    const bool provider = cfg->trainable == -2 && !h->bf16 && attn_fwd_f32_flash_covers(S);
+    h->provider = provider;
+    const bool inference_only = cfg->trainable < 0 && !(cfg->trainable == -2 && !h->bf16);   // no backward of any kind: one slot per buffer kind
     h->inference_only = inference_only;
     h->xs.resize(2 * L + 1);
     for (size_t i = 0; i < h->xs.size(); ++i) {
@@ -1041,8 +1059,9 @@ extern "C" int rvlm_vit_create(const rvlm_vit_config* cfg, const rvlm_vit_weight
     h->qkv.resize(L); h->attn_o.resize(L); h->lse.resize(L); h->h_pre.resize(L);
     const size_t Sp = round_up(S, 32);
     for (int l = 0; l < L; ++l) {
-        if (inference_only && l > 0) {
+        if ((inference_only || provider) && l > 0) {
             h->qkv[l] = h->qkv[0]; h->attn_o[l] = h->attn_o[0]; h->lse[l] = h->lse[0]; h->h_pre[l] = h->h_pre[0];
+            if (provider) { h->lse2.resize(L); ALLOC_OR_DIE(h->lse2[l], (size_t)B * h->H * Sp * 4); }
             continue;
         }
         ALLOC_OR_DIE(h->qkv[l], Mp * 3 * W * e);
@@ -1059,20 +1078,21 @@ extern "C" int rvlm_vit_create(const rvlm_vit_config* cfg, const rvlm_vit_weight
     ALLOC_OR_DIE(h->pooled, (size_t)B * W * 4);
     ALLOC_OR_DIE(h->emb_raw, (size_t)B * D * 4);
     ALLOC_OR_DIE(h->inv_norm, (size_t)B * 4);
-    ALLOC_OR_DIE(h->dres, Mp * W * 4);
-    ALLOC_OR_DIE(h->dres_lp, Mp * W * e);
-    ALLOC_OR_DIE(h->d_o, Mp * W * e);
-    ALLOC_OR_DIE(h->dqkv, Mp * 3 * W * e);
-    ALLOC_OR_DIE(h->dh, Mp * 4 * W * e);
-    ALLOC_OR_DIE(h->d_ln, Mp * W * e);
-    ALLOC_OR_DIE(h->d_patch, Mp0 * W * e);
-    ALLOC_OR_DIE(h->dA0, Mp0 * h->Kpad * 4);
+    const size_t bs = provider ? 0 : 1;      // (a provider runs no backward: 256-byte stubs)
+    ALLOC_OR_DIE(h->dres, bs * Mp * W * 4);
+    ALLOC_OR_DIE(h->dres_lp, bs * Mp * W * e);
+    ALLOC_OR_DIE(h->d_o, bs * Mp * W * e);
+    ALLOC_OR_DIE(h->dqkv, bs * Mp * 3 * W * e);
+    ALLOC_OR_DIE(h->dh, bs * Mp * 4 * W * e);
+    ALLOC_OR_DIE(h->d_ln, bs * Mp * W * e);
+    ALLOC_OR_DIE(h->d_patch, bs * Mp0 * W * e);
+    ALLOC_OR_DIE(h->dA0, bs * Mp0 * h->Kpad * 4);
     ALLOC_OR_DIE(h->dsum, (size_t)B * h->H * Sp * 4);
     ALLOC_OR_DIE(h->d_raw, (size_t)B * D * 4);
     ALLOC_OR_DIE(h->d_pooled, (size_t)B * W * 4);
     if (!h->bf16) {
         // [B, H, S, round_up(S, 4)], zero-initialised: the pad columns are never written
-        ALLOC_OR_DIE(h->dscores, (size_t)B * h->H * S * round_up(S, 4) * 4);
+        ALLOC_OR_DIE(h->dscores, bs * (size_t)B * h->H * S * round_up(S, 4) * 4);
     } else { h->dscores = nullptr; }
     h->trainable = cfg->trainable > 0;
     h->tokens = h->dtok = nullptr; h->tA = h->tB = nullptr;

@@ -84,6 +84,8 @@ class VitEngine:
                     "rvlm_vit_create")
             if self.mixed:
                 c.precision = L.PREC_F32 if precision == "bf16+fp32-first" else L.PREC_F32X3
+                if self.handoff:
+                    c.trainable = -2     # forward provider of the bf16 handle: no backward scratch, one slot for qkv / o / fc1 / P
                 L.check(self.lib.rvlm_vit_create(C.byref(c), C.byref(w), L.stream_ptr(), C.byref(self._h32)),
                         "rvlm_vit_create (fp32 handle)")
                 if self.handoff:     # its saving forwards are flash (run for the bf16 handle): the clean embedding too, bit-consistently
@@ -207,7 +209,8 @@ class VitEngine:
             if fused:    # the forward writes the bf16 handle's tensors itself (fp32 flash attention, no probabilities kept)
                 L.check(self.lib.rvlm_vit_forward_for(self._h32, self._h, x.data_ptr(), L.ptr(d), B, int(bool(output_normalize)),
                                                       emb.data_ptr(), L.stream_ptr()), "rvlm_vit_forward_for")
-            else:        # an ordinary saving forward; the bf16 tensors are exported at the handoff
+            else:        # an ordinary saving forward; the bf16 tensors are exported at the handoff (refused by a provider handle:
+                         # the mixed engines of this class create theirs as one - test hook for handles created otherwise)
                 L.check(self.lib.rvlm_vit_forward(self._h32, x.data_ptr(), L.ptr(d), B, int(bool(output_normalize)), 1,
                                                   emb.data_ptr(), L.stream_ptr()), "rvlm_vit_forward")
             d_emb = _f32c(cot) if cot is not None else ((emb - _f32c(ref)) * (2.0 / B)).contiguous()

@@ -771,7 +771,7 @@ def test_x3_falls_back_to_the_fp32_tiles_on_small_shapes():
 
 
 # ---- handoff: fp32-storage forward, bf16 backward (round 6; engine.hip::vit_backward_from) ---------------------------------
-@pytest.mark.parametrize("shape", ["s65", "s257", "s577"])
+@pytest.mark.parametrize("shape", ["s65", "s257", "s577", "tiny"])
 @pytest.mark.parametrize("normalize", [False, True])
 def test_handoff_backward_from_x3_forward(shape, normalize):
     """precision='bf16+x3fwd-first': the input gradient of a forward SAVED ON THE x3 HANDLE evaluated by the bf16 handle's backward
@@ -780,10 +780,11 @@ def test_handoff_backward_from_x3_forward(shape, normalize):
     cotangent it agrees with the fp32 oracle's gradient like the bf16 engine's own backward does; (b) the point of it: on the
     FARE first-iteration gradient - a difference of nearly equal embeddings - it keeps the oracle's signs where the bf16
     engine loses a fifth of them.  s257 runs the S = 257 flash backward (one kernel), s65 the generic pair; s577 (336 px) is beyond
-    the fp32 flash forward: batched attention path + exports at the handoff."""
+    the fp32 flash forward: batched attention path + exports at the handoff; tiny: widths the split-bf16 GEMM does not take (the
+    x3 handle's linears fall back to the fp32 tiles, whose act'(fc1) is exported by a pass of its own)."""
     cfg = {"s65": V.VitConfig(64, 8, 1024, 3, 16, 64), "s257": V.VitConfig(224, 14, 256, 2, 4, 64),
-           "s577": V.VitConfig(336, 14, 256, 1, 4, 64)}[shape]
-    B = 8 if shape == "s65" else 2
+           "s577": V.VitConfig(336, 14, 256, 1, 4, 64), "tiny": V.VIT_TINY2}[shape]
+    B = 8 if shape == "s65" else 3 if shape == "tiny" else 2
     w = V.init_weights(cfg, seed=4)
     ref = V.ClipVisionModelRef(cfg, w).eval()
     g = torch.Generator().manual_seed(7)
