@@ -39,6 +39,10 @@ int rvlm_k_softmax_rows(const float* p, float* s, long rows, int cols, int ld, f
  * domain of 0.125 log2(e) q.k) and bf16 copies qkv_bf / o_bf in the same layouts; S <= 288 */
 int rvlm_k_attn_fwd_f32_flash(const float* qkv, float* o, float* lse2, uint16_t* qkv_bf, uint16_t* o_bf, int B, int H, int S,
                               rvlm_stream_t stream);
+/* fp32 flash backward: dqkv fp32 [B*S, 3*64*H] from qkv, o, d_o (fp32) and the forward's lse2 rows; dsum [B*H, round_up(S, 32)] scratch;
+ * S = 32 NK + 1..4, NK <= 8 */
+int rvlm_k_attn_bwd_f32_flash(const float* qkv, const float* o, const float* d_o, const float* lse2, float* dsum, float* dqkv,
+                              int B, int H, int S, rvlm_stream_t stream);
 int rvlm_k_attn_fwd_bf16(const uint16_t* qkv, uint16_t* o, float* lse2, int B, int H, int S,
                          rvlm_stream_t stream);
 int rvlm_k_attn_bwd_bf16(const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o, const float* lse2,

@@ -171,6 +171,7 @@ _SIGS = {
     "rvlm_k_gemm_f32_set_valu": (C.c_int, [C.c_int]),
     "rvlm_k_softmax_rows": (C.c_int, [c_f32p, c_f32p, C.c_long, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "rvlm_k_attn_fwd_f32_flash": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "rvlm_k_attn_bwd_f32_flash": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "rvlm_k_attn_fwd_bf16": (C.c_int, [C.c_void_p, C.c_void_p, c_f32p, C.c_int, C.c_int, C.c_int,
                                        c_stream]),
     "rvlm_k_attn_bwd_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_f32p, c_f32p,

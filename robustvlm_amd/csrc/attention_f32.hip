@@ -224,6 +224,384 @@ attn_fwd_f32_flash_kernel(const float* __restrict__ qkv, long ld, float* __restr
     }
 }
 
+// =============================================================================================
+// fp32 flash BACKWARD (round 6): the fp32-storage engines' own backward without kept probabilities - P is recomputed from q, k and
+// the forward's log-sum-exp rows, like the bf16 flash kernels do.  Two kernels (K, V, Q, dO of a head in fp32 are 4 x 77 KiB: one
+// workgroup cannot hold them all):
+//   dQ  : K and V in LDS, wave w owns query tile w; per key tile S^T = K Q^T, dP^T = V dO^T (lane <-> query: lse and D are per-lane
+//         scalars), dS^T = P^T (dP^T - D) in registers - already the B operand of dQ^T += K^T dS^T.  96 MFMAs per tile pair.  Also
+//         writes D = rowsum(dO * O) for the second kernel.
+//   dKV : Q and dO in LDS, wave w owns key tile w (K, V rows in registers); per query tile S = Q K^T, dP = dO V^T (lane <-> key,
+//         lse / D per accumulator row), P and dS are the B operands of dV^T += dO^T P and dK^T += Q^T dS.  128 MFMAs per tile pair.
+// The "+1" token (S = 32 NK + 1..4) never gets an MFMA tile: as a key it is folded into the dQ walk / handled by one wave's VALU pass in
+// dKV, as a query the other way round.  Covered: S = 32 NK + r, 1 <= r <= 4, NK <= 8 (S = 257; other lengths keep the batched path).
+// =============================================================================================
+template <int NT>       // NT = NK + 1 padded tiles; NK waves
+__global__ void __launch_bounds__((NT - 1) * 64)
+attn_bwd_f32_dq_kernel(const float* __restrict__ qkv, long ld, const float* __restrict__ o, long ldo, const float* __restrict__ d_o, long lddo,
+                       const float* __restrict__ lse2, int lse_ld, float* __restrict__ dsum, float* __restrict__ dqkv, long lddq, int H, int S,
+                       int W, float scale, float scale_log2) {
+    constexpr int Sp = NT * 32, NK = NT - 1;
+    extern __shared__ __attribute__((aligned(16))) char smem_f[];
+    float* Ks = (float*)smem_f;                 // [Sp][AF_KLD]
+    float* Vs = Ks + Sp * AF_KLD;               // [Sp][AF_KLD]
+    float* Xs = Vs + Sp * AF_KLD;               // VALU path: q row [64] | dO row [64] | dS row [Sp]
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const float* base = qkv + (long)b * S * ld + h * 64;
+    const float* obase = o + (long)b * S * ldo + h * 64;
+    const float* dobase = d_o + (long)b * S * lddo + h * 64;
+    float* dqbase = dqkv + (long)b * S * lddq + h * 64;
+    const float* lrow = lse2 + ((long)b * H + h) * lse_ld;
+    float* drow = dsum + ((long)b * H + h) * lse_ld;
+    for (int i = tid; i < Sp * 16; i += NK * 64) {
+        const int row = i >> 4, c = (i & 15) * 4;
+        float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+        if (row < S) {
+            kv = *(const float4*)(base + (long)row * ld + W + c);
+            vv = *(const float4*)(base + (long)row * ld + 2 * W + c);
+        }
+        *(float4*)(Ks + row * AF_KLD + c) = kv;
+        *(float4*)(Vs + row * AF_KLD + c) = vv;
+    }
+    __syncthreads();
+    // the 1-4 queries beyond the last full tile, by the last wave once its own tile is done (below): lane <-> key for the scores,
+    // lane <-> head dim for dQ (~8 k cycles per row)
+    auto odd_queries = [&]() {
+        constexpr int NP = (NT + 1) / 2;
+        for (int qr = NK * 32; qr < S; ++qr) {
+            const float dov = dobase[(long)qr * lddo + lane];
+            Xs[lane] = base[(long)qr * ld + lane] * scale_log2;
+            Xs[64 + lane] = dov;
+            const float D = wave_sum(dov * obase[(long)qr * ldo + lane]);
+            const float lq = lrow[qr];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 1
+            for (int p = 0; p < NP; ++p) {
+                const int key = p * 64 + lane;
+                const float* kr = Ks + min(key, Sp - 1) * AF_KLD;
+                const float* vr = Vs + min(key, Sp - 1) * AF_KLD;
+                float sc = 0.0f, dp = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const float4 k4 = *(const float4*)(kr + 4 * j), v4 = *(const float4*)(vr + 4 * j);
+                    const float4 q4 = *(const float4*)(Xs + 4 * j), d4 = *(const float4*)(Xs + 64 + 4 * j);
+                    sc = fmaf(k4.x, q4.x, sc); sc = fmaf(k4.y, q4.y, sc); sc = fmaf(k4.z, q4.z, sc); sc = fmaf(k4.w, q4.w, sc);
+                    dp = fmaf(v4.x, d4.x, dp); dp = fmaf(v4.y, d4.y, dp); dp = fmaf(v4.z, d4.z, dp); dp = fmaf(v4.w, d4.w, dp);
+                }
+                if (key < Sp) Xs[128 + key] = key < S ? __builtin_amdgcn_exp2f(sc - lq) * (dp - D) : 0.0f;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            float a0 = 0.0f, a1 = 0.0f;
+            const int S4 = (S + 3) & ~3;
+            for (int key = 0; key < S4; key += 4) {
+                const float4 d4 = *(const float4*)(Xs + 128 + key);
+                const float* kk = Ks + key * AF_KLD + lane;
+                a0 = fmaf(d4.x, kk[0], a0); a1 = fmaf(d4.y, kk[AF_KLD], a1);
+                a0 = fmaf(d4.z, kk[2 * AF_KLD], a0); a1 = fmaf(d4.w, kk[3 * AF_KLD], a1);
+            }
+            dqbase[(long)qr * lddq + lane] = (a0 + a1) * scale;
+            if (lane == 0) drow[qr] = D;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    };
+    const int q = w * 32 + l31;
+    float qf[32], dof[32];
+    float D = 0.0f;
+    {
+        const float* qp = base + (long)q * ld + 32 * hi;
+        const float* dp_ = dobase + (long)q * lddo + 32 * hi;
+        const float* op = obase + (long)q * ldo + 32 * hi;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            *(float4*)&qf[4 * j] = *(const float4*)(qp + 4 * j);
+            *(float4*)&dof[4 * j] = *(const float4*)(dp_ + 4 * j);
+            const float4 o4 = *(const float4*)(op + 4 * j);
+            D = fmaf(dof[4 * j], o4.x, D); D = fmaf(dof[4 * j + 1], o4.y, D); D = fmaf(dof[4 * j + 2], o4.z, D); D = fmaf(dof[4 * j + 3], o4.w, D);
+        }
+#pragma unroll
+        for (int j = 0; j < 32; ++j) qf[j] *= scale_log2;
+        D += __shfl_xor(D, 32, 64);
+        if (hi == 0) drow[q] = D;
+    }
+    const float lq = lrow[q];
+    f32x16 dq[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[dt][r] = 0.0f;
+    for (int kt = 0; kt < NK; ++kt) {
+        f32x16 st, dpt;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { st[r] = 0.0f; dpt[r] = 0.0f; }
+        const float* kr = Ks + (kt * 32 + l31) * AF_KLD + 32 * hi;
+        const float* vr = Vs + (kt * 32 + l31) * AF_KLD + 32 * hi;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4 a = *(const float4*)(kr + 4 * j), c = *(const float4*)(vr + 4 * j);
+            st = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qf[4 * j + 0], st, 0, 0, 0);
+            dpt = __builtin_amdgcn_mfma_f32_32x32x2f32(c.x, dof[4 * j + 0], dpt, 0, 0, 0);
+            st = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qf[4 * j + 1], st, 0, 0, 0);
+            dpt = __builtin_amdgcn_mfma_f32_32x32x2f32(c.y, dof[4 * j + 1], dpt, 0, 0, 0);
+            st = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qf[4 * j + 2], st, 0, 0, 0);
+            dpt = __builtin_amdgcn_mfma_f32_32x32x2f32(c.z, dof[4 * j + 2], dpt, 0, 0, 0);
+            st = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qf[4 * j + 3], st, 0, 0, 0);
+            dpt = __builtin_amdgcn_mfma_f32_32x32x2f32(c.w, dof[4 * j + 3], dpt, 0, 0, 0);
+            if (j & 1) asm volatile("" ::: "memory");      // (keeps hipcc from requesting all 16 operand quads up front: 64 live registers)
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] = __builtin_amdgcn_exp2f(st[r] - lq) * (dpt[r] - D);      // dS^T[key][q]
+        const float* kc = Ks + (kt * 32 + 4 * hi) * AF_KLD + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float* kk = kc + ((r & 3) + 8 * (r >> 2)) * AF_KLD;
+            dq[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(kk[0], st[r], dq[0], 0, 0, 0);
+            dq[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(kk[32], st[r], dq[1], 0, 0, 0);
+            if ((r & 3) == 3) asm volatile("" ::: "memory");
+        }
+    }
+    for (int key = NK * 32; key < S; ++key) {      // the keys beyond the last full tile, on the VALU
+        const float* kr = Ks + key * AF_KLD + 32 * hi;
+        const float* vr = Vs + key * AF_KLD + 32 * hi;
+        float sc = 0.0f, dp = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4 a = *(const float4*)(kr + 4 * j), c = *(const float4*)(vr + 4 * j);
+            sc = fmaf(a.x, qf[4 * j], sc); sc = fmaf(a.y, qf[4 * j + 1], sc); sc = fmaf(a.z, qf[4 * j + 2], sc); sc = fmaf(a.w, qf[4 * j + 3], sc);
+            dp = fmaf(c.x, dof[4 * j], dp); dp = fmaf(c.y, dof[4 * j + 1], dp); dp = fmaf(c.z, dof[4 * j + 2], dp); dp = fmaf(c.w, dof[4 * j + 3], dp);
+        }
+        sc += __shfl_xor(sc, 32, 64);
+        dp += __shfl_xor(dp, 32, 64);
+        const float ds = __builtin_amdgcn_exp2f(sc - lq) * (dp - D);
+        const float* kk = Ks + key * AF_KLD + 4 * hi;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 k4 = *(const float4*)(kk + 32 * dt + 8 * g);
+                dq[dt][4 * g + 0] = fmaf(ds, k4.x, dq[dt][4 * g + 0]); dq[dt][4 * g + 1] = fmaf(ds, k4.y, dq[dt][4 * g + 1]);
+                dq[dt][4 * g + 2] = fmaf(ds, k4.z, dq[dt][4 * g + 2]); dq[dt][4 * g + 3] = fmaf(ds, k4.w, dq[dt][4 * g + 3]);
+            }
+    }
+    float* orow = dqbase + (long)q * lddq + 4 * hi;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *(float4*)(orow + 32 * dt + 8 * g) = make_float4(dq[dt][4 * g] * scale, dq[dt][4 * g + 1] * scale, dq[dt][4 * g + 2] * scale, dq[dt][4 * g + 3] * scale);
+    if (w == NK - 1) odd_queries();
+}
+
+template <int NK>       // NK = S / 32 waves, one key tile each; NT = NK + 1 padded tiles
+__global__ void __launch_bounds__(NK * 64)
+attn_bwd_f32_dkv_kernel(const float* __restrict__ qkv, long ld, const float* __restrict__ d_o, long lddo, const float* __restrict__ lse2,
+                        int lse_ld, const float* __restrict__ dsum, float* __restrict__ dqkv, long lddq, int H, int S, int W, float scale,
+                        float scale_log2) {
+    constexpr int Sp = (NK + 1) * 32;
+    extern __shared__ __attribute__((aligned(16))) char smem_f[];
+    float* Qs = (float*)smem_f;                 // [Sp][AF_KLD]
+    float* Os = Qs + Sp * AF_KLD;               // dO [Sp][AF_KLD]
+    float* Ls = Os + Sp * AF_KLD;               // [Sp] lse rows (+inf beyond S: P = 0)
+    float* Dd = Ls + Sp;                        // [Sp] D
+    float* Xs = Dd + Sp;                        // VALU path: k row [64] | v row [64] | P row [Sp] | dS row [Sp]
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const float* base = qkv + (long)b * S * ld + h * 64;
+    const float* dobase = d_o + (long)b * S * lddo + h * 64;
+    float* dkbase = dqkv + (long)b * S * lddq + W + h * 64;
+    for (int i = tid; i < Sp * 16; i += NK * 64) {
+        const int row = i >> 4, c = (i & 15) * 4;
+        float4 qv = make_float4(0.f, 0.f, 0.f, 0.f), dv = qv;
+        if (row < S) {
+            qv = *(const float4*)(base + (long)row * ld + c);
+            dv = *(const float4*)(dobase + (long)row * lddo + c);
+        }
+        *(float4*)(Qs + row * AF_KLD + c) = qv;
+        *(float4*)(Os + row * AF_KLD + c) = dv;
+    }
+    for (int i = tid; i < Sp; i += NK * 64) {
+        Ls[i] = i < S ? lse2[((long)b * H + h) * lse_ld + i] : INFINITY;
+        Dd[i] = i < S ? dsum[((long)b * H + h) * lse_ld + i] : 0.0f;
+    }
+    const int key = w * 32 + l31;
+    float kf[32], vf[32];
+    {
+        const float* kp = base + (long)key * ld + W + 32 * hi;
+        const float* vp = base + (long)key * ld + 2 * W + 32 * hi;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { *(float4*)&kf[4 * j] = *(const float4*)(kp + 4 * j); *(float4*)&vf[4 * j] = *(const float4*)(vp + 4 * j); }
+#pragma unroll
+        for (int j = 0; j < 32; ++j) kf[j] *= scale_log2;
+    }
+    __syncthreads();
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.0f; dv[dt][r] = 0.0f; }
+    for (int qt = 0; qt < NK; ++qt) {
+        f32x16 sc, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sc[r] = 0.0f; dp[r] = 0.0f; }
+        const float* qr = Qs + (qt * 32 + l31) * AF_KLD + 32 * hi;
+        const float* dr = Os + (qt * 32 + l31) * AF_KLD + 32 * hi;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4 a = *(const float4*)(qr + 4 * j), c = *(const float4*)(dr + 4 * j);
+            sc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, kf[4 * j + 0], sc, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(c.x, vf[4 * j + 0], dp, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, kf[4 * j + 1], sc, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(c.y, vf[4 * j + 1], dp, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, kf[4 * j + 2], sc, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(c.z, vf[4 * j + 2], dp, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, kf[4 * j + 3], sc, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(c.w, vf[4 * j + 3], dp, 0, 0, 0);
+            asm volatile("" ::: "memory");                 // (one operand quad pair in flight: the accumulators and K / V rows fill the file)
+        }
+        // sc[4 g + e] = S[q = 32 qt + 8 g + 4 hi + e][key]: lse / D vary along the accumulator rows
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 l4 = *(const float4*)(Ls + qt * 32 + 8 * g + 4 * hi), d4 = *(const float4*)(Dd + qt * 32 + 8 * g + 4 * hi);
+            const float la[4] = {l4.x, l4.y, l4.z, l4.w}, da[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float p = __builtin_amdgcn_exp2f(sc[4 * g + e] - la[e]);
+                sc[4 * g + e] = p;                                   // P
+                dp[4 * g + e] = p * (dp[4 * g + e] - da[e]);         // dS
+            }
+        }
+        const float* oc = Os + (qt * 32 + 4 * hi) * AF_KLD + l31;
+        const float* qc = Qs + (qt * 32 + 4 * hi) * AF_KLD + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ro = ((r & 3) + 8 * (r >> 2)) * AF_KLD;
+            dv[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(oc[ro], sc[r], dv[0], 0, 0, 0);
+            dk[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(qc[ro], dp[r], dk[0], 0, 0, 0);
+            dv[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(oc[ro + 32], sc[r], dv[1], 0, 0, 0);
+            dk[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(qc[ro + 32], dp[r], dk[1], 0, 0, 0);
+            if (r & 1) asm volatile("" ::: "memory");
+        }
+    }
+    for (int qr = NK * 32; qr < S; ++qr) {      // the queries beyond the last full tile: rank-1 terms on the VALU
+        const float* qp = Qs + qr * AF_KLD + 32 * hi;
+        const float* dp_ = Os + qr * AF_KLD + 32 * hi;
+        float sc = 0.0f, dpv = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4 a = *(const float4*)(qp + 4 * j), c = *(const float4*)(dp_ + 4 * j);
+            sc = fmaf(a.x, kf[4 * j], sc); sc = fmaf(a.y, kf[4 * j + 1], sc); sc = fmaf(a.z, kf[4 * j + 2], sc); sc = fmaf(a.w, kf[4 * j + 3], sc);
+            dpv = fmaf(c.x, vf[4 * j], dpv); dpv = fmaf(c.y, vf[4 * j + 1], dpv); dpv = fmaf(c.z, vf[4 * j + 2], dpv); dpv = fmaf(c.w, vf[4 * j + 3], dpv);
+        }
+        sc += __shfl_xor(sc, 32, 64);
+        dpv += __shfl_xor(dpv, 32, 64);
+        const float p = __builtin_amdgcn_exp2f(sc - Ls[qr]);
+        const float ds = p * (dpv - Dd[qr]);
+        const float* q4p = Qs + qr * AF_KLD + 4 * hi;
+        const float* d4p = Os + qr * AF_KLD + 4 * hi;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 q4 = *(const float4*)(q4p + 32 * dt + 8 * g), o4 = *(const float4*)(d4p + 32 * dt + 8 * g);
+                dk[dt][4 * g + 0] = fmaf(ds, q4.x, dk[dt][4 * g + 0]); dk[dt][4 * g + 1] = fmaf(ds, q4.y, dk[dt][4 * g + 1]);
+                dk[dt][4 * g + 2] = fmaf(ds, q4.z, dk[dt][4 * g + 2]); dk[dt][4 * g + 3] = fmaf(ds, q4.w, dk[dt][4 * g + 3]);
+                dv[dt][4 * g + 0] = fmaf(p, o4.x, dv[dt][4 * g + 0]); dv[dt][4 * g + 1] = fmaf(p, o4.y, dv[dt][4 * g + 1]);
+                dv[dt][4 * g + 2] = fmaf(p, o4.z, dv[dt][4 * g + 2]); dv[dt][4 * g + 3] = fmaf(p, o4.w, dv[dt][4 * g + 3]);
+            }
+    }
+    {
+        float* krow = dkbase + (long)key * lddq + 4 * hi;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                *(float4*)(krow + 32 * dt + 8 * g) = make_float4(dk[dt][4 * g] * scale, dk[dt][4 * g + 1] * scale, dk[dt][4 * g + 2] * scale, dk[dt][4 * g + 3] * scale);
+                *(float4*)(krow + W + 32 * dt + 8 * g) = make_float4(dv[dt][4 * g], dv[dt][4 * g + 1], dv[dt][4 * g + 2], dv[dt][4 * g + 3]);
+            }
+    }
+    if (w == 0) {       // the keys beyond the last full tile: lane <-> query for P / dS, lane <-> head dim for the sums over the queries
+        constexpr int NP = (NK + 2) / 2;
+        for (int kr = NK * 32; kr < S; ++kr) {
+            Xs[lane] = base[(long)kr * ld + W + lane] * scale_log2;
+            Xs[64 + lane] = base[(long)kr * ld + 2 * W + lane];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 1
+            for (int p = 0; p < NP; ++p) {
+                const int qi = p * 64 + lane;
+                const float* qp = Qs + min(qi, Sp - 1) * AF_KLD;
+                const float* dp_ = Os + min(qi, Sp - 1) * AF_KLD;
+                float sc = 0.0f, dpv = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const float4 q4 = *(const float4*)(qp + 4 * j), o4 = *(const float4*)(dp_ + 4 * j);
+                    const float4 k4 = *(const float4*)(Xs + 4 * j), v4 = *(const float4*)(Xs + 64 + 4 * j);
+                    sc = fmaf(q4.x, k4.x, sc); sc = fmaf(q4.y, k4.y, sc); sc = fmaf(q4.z, k4.z, sc); sc = fmaf(q4.w, k4.w, sc);
+                    dpv = fmaf(o4.x, v4.x, dpv); dpv = fmaf(o4.y, v4.y, dpv); dpv = fmaf(o4.z, v4.z, dpv); dpv = fmaf(o4.w, v4.w, dpv);
+                }
+                if (qi < Sp) {
+                    const float pv = __builtin_amdgcn_exp2f(sc - Ls[qi]);          // (rows >= S: lse = +inf -> 0)
+                    Xs[128 + qi] = pv;
+                    Xs[128 + Sp + qi] = pv * (dpv - Dd[qi]);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            float ak0 = 0.0f, ak1 = 0.0f, av0 = 0.0f, av1 = 0.0f;
+            const int S4 = (S + 3) & ~3;
+            for (int qi = 0; qi < S4; qi += 4) {
+                const float4 p4 = *(const float4*)(Xs + 128 + qi), d4 = *(const float4*)(Xs + 128 + Sp + qi);
+                const float* qq = Qs + qi * AF_KLD + lane;
+                const float* oo = Os + qi * AF_KLD + lane;
+                av0 = fmaf(p4.x, oo[0], av0); av1 = fmaf(p4.y, oo[AF_KLD], av1); av0 = fmaf(p4.z, oo[2 * AF_KLD], av0); av1 = fmaf(p4.w, oo[3 * AF_KLD], av1);
+                ak0 = fmaf(d4.x, qq[0], ak0); ak1 = fmaf(d4.y, qq[AF_KLD], ak1); ak0 = fmaf(d4.z, qq[2 * AF_KLD], ak0); ak1 = fmaf(d4.w, qq[3 * AF_KLD], ak1);
+            }
+            dkbase[(long)kr * lddq + lane] = (ak0 + ak1) * scale;
+            dkbase[(long)kr * lddq + W + lane] = av0 + av1;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    }
+}
+
+bool attn_bwd_f32_flash_covers(int S) {
+    const int r = S & 31, NK = S >> 5;
+    return r >= 1 && r <= 4 && NK >= 1 && NK <= 8;
+}
+
+static unsigned long long g_ab_attr[2][10];
+
+// dqkv [B * S, 3 W] = d(q | k | v) of O = softmax(0.125 Q K^T) V for the cotangent d_o, from qkv, o and the forward's lse2 rows
+// ([B * H, lse_ld]); dsum: [B * H, lse_ld] scratch (D = rowsum(dO * O)).  false: sequence length not covered.
+bool attn_bwd_f32_flash(const float* qkv, const float* o, const float* d_o, const float* lse2, int lse_ld, float* dsum, float* dqkv, int B,
+                        int H, int S, hipStream_t s, int* rc_out) {
+    *rc_out = RVLM_OK;
+    if (!attn_bwd_f32_flash_covers(S) || ((((size_t)qkv | (size_t)o | (size_t)d_o | (size_t)dqkv)) & 15)) return false;
+    const int W = H * 64, NK = S >> 5, NT = NK + 1, Sp = NT * 32;
+    const size_t lds_q = (size_t)(2 * Sp * AF_KLD + 128 + Sp) * sizeof(float);
+    const size_t lds_kv = (size_t)(2 * Sp * AF_KLD + 2 * Sp + 128 + 2 * Sp) * sizeof(float);
+    const float scale = 0.125f, sl2 = 0.125f * 1.4426950408889634f;
+#define RVLM_AB_CASE(N)                                                                                                                       \
+    case N: {                                                                                                                                 \
+        hipError_t err = hipSuccess;                                                                                                          \
+        RVLM_ONCE_PER_DEVICE(g_ab_attr[0][N], err = hipFuncSetAttribute((const void*)attn_bwd_f32_dq_kernel<N + 1>,                           \
+                                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q));             \
+        if (err == hipSuccess)                                                                                                                \
+            RVLM_ONCE_PER_DEVICE(g_ab_attr[1][N], err = hipFuncSetAttribute((const void*)attn_bwd_f32_dkv_kernel<N>,                          \
+                                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv));        \
+        if (err != hipSuccess) { *rc_out = fail(RVLM_ERR_HIP, std::string("attn_bwd_f32_flash: ") + hipGetErrorString(err)); return true; }   \
+        hipLaunchKernelGGL((attn_bwd_f32_dq_kernel<N + 1>), dim3(B * H), dim3(N * 64), lds_q, s, qkv, 3L * W, o, (long)W, d_o, (long)W, \
+                           lse2, lse_ld, dsum, dqkv, 3L * W, H, S, W, scale, sl2);                                                            \
+        hipLaunchKernelGGL((attn_bwd_f32_dkv_kernel<N>), dim3(B * H), dim3(N * 64), lds_kv, s, qkv, 3L * W, d_o, (long)W, lse2, lse_ld,      \
+                           (const float*)dsum, dqkv, 3L * W, H, S, W, scale, sl2);                                                            \
+        break;                                                                                                                                \
+    }
+    switch (NK) {
+        RVLM_AB_CASE(1) RVLM_AB_CASE(2) RVLM_AB_CASE(3) RVLM_AB_CASE(4) RVLM_AB_CASE(5) RVLM_AB_CASE(6) RVLM_AB_CASE(7) RVLM_AB_CASE(8)
+        default: return false;
+    }
+#undef RVLM_AB_CASE
+    if (hipGetLastError() != hipSuccess) *rc_out = fail(RVLM_ERR_HIP, "attn_bwd_f32_flash: kernel launch");
+    return true;
+}
+
 static unsigned long long g_af_attr[17];
 
 // sequence lengths the kernel takes: one wave per query tile (<= 9: K and V of a head must fit the CU's 160 KiB of LDS in fp32)

@@ -67,6 +67,10 @@ struct rvlm_vit {
     // starts there, train/apgd_train.py:157-160), and 1e-7 of rounding difference between two attention paths turns that into a
     // random sign pattern.  ON for the fp32-storage handle of a handoff engine, whose saving forwards (run for the peer) are flash.
     bool flash_inference = false;
+    // fp32-storage handle at a sequence length the fp32 flash BACKWARD takes (S = 257): every attention of this handle - saving or not,
+    // forward and backward - runs on the flash kernels (attention_f32.hip); no probabilities are kept or allocated (13 GB at ViT-L/14,
+    // B = 128) and saving / non-saving forwards agree bit for bit by construction.
+    bool own_flash = false;
     std::vector<void*> h_pre;    // L x [Mp, 4W] T
     void* g_act;         // [Mp, 4W] T
     float *pooled, *emb_raw, *inv_norm;   // [maxB, W], [maxB, D], [maxB]
@@ -388,7 +392,8 @@ int attention_fwd<float>(rvlm_vit* h, hipStream_t s, const void* qkv_, void* o, 
     int rc = RVLM_OK;
     if (h->cur_flash) {      // no backward of this handle's own will read P: one fused kernel, no score matrices
         if (attn_fwd_f32_flash(qkv, (float*)o, h->cur_lse2, (int)round_up(S, 32), h->cur_qkv_bf, h->cur_o_bf, B, H, S, s, &rc)) return rc;
-        if (h->peer) return fail(RVLM_ERR_UNSUPPORTED, "forward for a peer handle: sequence length not covered by the fp32 flash kernel");
+        if (h->peer || h->own_flash)      // (no fall-through: there is no probability buffer behind P on these paths)
+            return fail(RVLM_ERR_UNSUPPORTED, "attention forward: sequence length not covered by the fp32 flash kernel");
     }
     rc = attn_scores_f32(h, s, qkv, P, B); if (rc) return rc;
     GemmF32 g;  // O = P V
@@ -408,13 +413,17 @@ int attention_bwd<bf16_t>(rvlm_vit* h, hipStream_t s, const void* qkv, const voi
                          lse, h->dsum, (bf16_t*)dqkv, 3 * h->W, B, h->H, h->S, s);
 }
 template <>
-int attention_bwd<float>(rvlm_vit* h, hipStream_t s, const void* qkv_, const void*, const void* d_o_,
+int attention_bwd<float>(rvlm_vit* h, hipStream_t s, const void* qkv_, const void* o_, const void* d_o_,
                          const float* P, void* dqkv_, int B) {
     const int S = h->S, W = h->W, H = h->H, Sld = (int)round_up(S, 4);
     const float* qkv = (const float*)qkv_;
     const float* d_o = (const float*)d_o_;
     float* dqkv = (float*)dqkv_;
-    int rc;                                                       // (P: kept by the forward)
+    int rc = RVLM_OK;                                             // (P: kept by the forward)
+    if (h->own_flash) {      // probabilities recomputed from the forward's log-sum-exp rows (cur_lse2: the block's)
+        if (attn_bwd_f32_flash(qkv, (const float*)o_, d_o, h->cur_lse2, (int)round_up(S, 32), h->dsum, dqkv, B, H, S, s, &rc)) return rc;
+        return fail(RVLM_ERR_STATE, "attention backward: flash kernels refused a sequence length they cover");
+    }
     const long bs1 = (long)H * S * Sld, bs2 = (long)S * Sld, qs1 = (long)S * 3 * W, os1 = (long)S * W;
     GemmF32 g;  // dP = dO V^T
     g.A = d_o; g.sam = W; g.sak = 1; g.sab1 = os1; g.sab2 = 64;
@@ -500,7 +509,7 @@ static int forward_impl(rvlm_vit* h, const float* x, const float* delta, int B, 
         return fail(RVLM_ERR_STATE, "forward: this handle was created as a forward provider (trainable = -2): its saving forwards are run "
                                     "for a bf16 handle (rvlm_vit_forward_for, rvlm_pgd_run_mixed_fwd)");
     if (peer) peer->saved_B = 0;
-    h->cur_flash = flash_ok && (peer != nullptr || (save == 0 && h->flash_inference));
+    h->cur_flash = flash_ok && (h->own_flash || peer != nullptr || (save == 0 && h->flash_inference));
     h->exported_to = 0; h->exported_dact = false;
     h->cur_qkv_bf = h->cur_o_bf = nullptr; h->cur_dact_out = nullptr;
     {
@@ -618,7 +627,10 @@ static int forward_impl(rvlm_vit* h, const float* x, const float* delta, int B, 
         }
     }
     if (save) { h->saved_B = B; h->saved_norm = normalize != 0; h->saved_mode = save; h->next_param_stage = 0; }
-    if (peer) { h->saved_mode = 3; h->exported_to = peer->uid; }      // (3: for the peer's backward only - no probabilities were kept)
+    if (peer) {      // (saved_mode 3: for the peer's backward only - a provider's single slots / no probabilities kept for a batched backward)
+        if (h->provider || !h->own_flash) h->saved_mode = 3;
+        h->exported_to = peer->uid;
+    }
     h->cur_flash = false; h->cur_qkv_bf = h->cur_o_bf = nullptr; h->cur_lse2 = nullptr;
     return RVLM_OK;
 }
@@ -698,6 +710,7 @@ static int backward_impl(rvlm_vit* h, const float* d_emb, int B, float* grad_x, 
         }
         {
             PROF("attn_bwd", attn_flops, 0);
+            h->cur_lse2 = h->lse2.empty() ? nullptr : h->lse2[l];
             if ((rc = attention_bwd<T>(h, s, h->qkv[l], h->attn_o[l], h->d_o, h->lse[l], h->dqkv, B))) return rc;
         }
         }
@@ -893,6 +906,7 @@ static int backward_params_impl(rvlm_vit* h, const float* d_emb, int B, const rv
                                         (const bf16_t*)h->d_o, W, h->lse_cls, (bf16_t*)h->dqkv, 3 * W, B, h->H, S, s)))
                 return rc;
         } else {
+            h->cur_lse2 = h->lse2.empty() ? nullptr : h->lse2[l];
             if ((rc = attention_bwd<T>(h, s, h->qkv[l], h->attn_o[l], h->d_o, h->lse[l], h->dqkv, B))) return rc;
         }
         // qkv in-proj
@@ -1044,6 +1058,10 @@ extern "C" int rvlm_vit_create(const rvlm_vit_config* cfg, const rvlm_vit_weight
         if (rc) { rvlm_vit_destroy(h); return rc; }
     }
     // (a provider needs the flash forward for its sequence length: otherwise the handoff exports from per-block fp32 tensors)
+    {
+        const char* e = getenv("RVLM_F32_FLASH");      // 0: the batched attention path over kept probabilities (A/B and parity arm)
+        h->own_flash = !h->bf16 && attn_bwd_f32_flash_covers(S) && !(e && atoi(e) == 0);
+    }
     const bool provider = cfg->trainable == -2 && !h->bf16 && attn_fwd_f32_flash_covers(S);
     h->provider = provider;
     const bool inference_only = cfg->trainable < 0 && !(cfg->trainable == -2 && !h->bf16);   // no backward of any kind: one slot per buffer kind
@@ -1066,8 +1084,9 @@ extern "C" int rvlm_vit_create(const rvlm_vit_config* cfg, const rvlm_vit_weight
         }
         ALLOC_OR_DIE(h->qkv[l], Mp * 3 * W * e);
         ALLOC_OR_DIE(h->attn_o[l], Mp * W * e);
-        // bf16: log-sum-exp rows of the flash kernels; fp32: the block's probabilities [B, H, S, round_up(S, 4)], zero pad columns
-        ALLOC_OR_DIE(h->lse[l], h->bf16 ? (size_t)B * h->H * Sp * 4 : (size_t)B * h->H * S * round_up(S, 4) * 4);
+        // bf16: log-sum-exp rows of the flash kernels; fp32: the block's probabilities [B, H, S, round_up(S, 4)], zero pad columns - a
+        // stub where the fp32 flash kernels run both directions (own_flash: nothing is kept)
+        ALLOC_OR_DIE(h->lse[l], h->bf16 ? (size_t)B * h->H * Sp * 4 : h->own_flash ? 256 : (size_t)B * h->H * S * round_up(S, 4) * 4);
         ALLOC_OR_DIE(h->h_pre[l], Mp * 4 * W * e);
         if (!h->bf16 && !inference_only) {      // (2.4 MB per block at ViT-L/14, B = 128)
             h->lse2.resize(L);
@@ -1092,7 +1111,7 @@ extern "C" int rvlm_vit_create(const rvlm_vit_config* cfg, const rvlm_vit_weight
     ALLOC_OR_DIE(h->d_pooled, (size_t)B * W * 4);
     if (!h->bf16) {
         // [B, H, S, round_up(S, 4)], zero-initialised: the pad columns are never written
-        ALLOC_OR_DIE(h->dscores, bs * (size_t)B * h->H * S * round_up(S, 4) * 4);
+        ALLOC_OR_DIE(h->dscores, (h->own_flash ? 0 : bs) * (size_t)B * h->H * S * round_up(S, 4) * 4);
     } else { h->dscores = nullptr; }
     h->trainable = cfg->trainable > 0;
     h->tokens = h->dtok = nullptr; h->tA = h->tB = nullptr;

@@ -146,6 +146,11 @@ int attn_bwd_bf16(const bf16_t* qkv, long ldqkv, const bf16_t* o, long ldo, cons
 bool attn_fwd_f32_flash_covers(int S);
 bool attn_fwd_f32_flash(const float* qkv, float* o, float* lse2, int lse_ld, bf16_t* qkv_bf, bf16_t* o_bf, int B, int H, int S, hipStream_t s,
                         int* rc_out);
+// fp32 flash backward (attention_f32.hip): dqkv from qkv, o, d_o and the forward's lse2 rows - no kept probabilities; dsum: scratch
+// [B * H, lse_ld].  Covered: S = 32 NK + 1..4, NK <= 8 (S = 257).
+bool attn_bwd_f32_flash_covers(int S);
+bool attn_bwd_f32_flash(const float* qkv, const float* o, const float* d_o, const float* lse2, int lse_ld, float* dsum, float* dqkv, int B,
+                        int H, int S, hipStream_t s, int* rc_out);
 // class-token attention of the last block (only the class token's query row is live there): o [B, W] (row b = image b),
 // lse [B*H] natural log; bwd writes dqkv [B*S, 3W] in full (dQ rows of the other tokens are zero)
 int attn_cls_fwd_bf16(const bf16_t* qkv, long ldqkv, bf16_t* o, long ldo, float* lse, int B, int H, int S,

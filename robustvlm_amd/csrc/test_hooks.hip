@@ -286,6 +286,13 @@ extern "C" int rvlm_k_attn_fwd_f32_flash(const float* qkv, float* o, float* lse2
         return fail(RVLM_ERR_UNSUPPORTED, "rvlm_k_attn_fwd_f32_flash: sequence length not covered");
     return rc;
 }
+extern "C" int rvlm_k_attn_bwd_f32_flash(const float* qkv, const float* o, const float* d_o, const float* lse2, float* dsum, float* dqkv,
+                                         int B, int H, int S, rvlm_stream_t stream) {
+    int rc = RVLM_OK;
+    if (!attn_bwd_f32_flash(qkv, o, d_o, lse2, (int)round_up(S, 32), dsum, dqkv, B, H, S, (hipStream_t)stream, &rc))
+        return fail(RVLM_ERR_UNSUPPORTED, "rvlm_k_attn_bwd_f32_flash: sequence length not covered");
+    return rc;
+}
 extern "C" int rvlm_k_attn_fwd_bf16(const uint16_t* qkv, uint16_t* o, float* lse2, int B, int H, int S,
                                     rvlm_stream_t stream) {
     return attn_fwd_bf16((const bf16_t*)qkv, 3L * H * 64, (bf16_t*)o, H * 64L, lse2, B, H, S, (hipStream_t)stream);

@@ -578,3 +578,32 @@ def test_attn_fwd_f32_flash(S):
     L.check(l.rvlm_k_attn_fwd_f32_flash(qkv.data_ptr(), o2.data_ptr(), None, None, None, B, H, S, st()))
     torch.cuda.synchronize()
     assert torch.equal(o2, o)
+
+
+@pytest.mark.parametrize("S", [257, 33, 65, 132])
+def test_attn_bwd_f32_flash(S):
+    """The fp32 flash backward (round 6: dQ kernel + dK / dV kernel on v_mfma_f32_32x32x2_f32, probabilities recomputed from the
+    forward's log-sum-exp rows) against torch autograd in fp64, on the flash forward's own outputs.  S = 32 NK + r: the r "+1" tokens
+    run on the VALU in both roles (as keys and as queries)."""
+    l = lib()
+    B, H = 3, 2
+    W = 64 * H
+    g = torch.Generator(device=dev()).manual_seed(S)
+    qkv = torch.randn(B * S, 3 * W, generator=g, device=dev())
+    qkv[:, :W] *= 2.0
+    d_o = torch.randn(B * S, W, generator=g, device=dev())
+    o = torch.empty(B * S, W, device=dev())
+    Sp = (S + 31) // 32 * 32
+    lse = torch.zeros(B * H, Sp, device=dev())
+    L.check(l.rvlm_k_attn_fwd_f32_flash(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), None, None, B, H, S, st()))
+    dsum = torch.zeros(B * H, Sp, device=dev())
+    dqkv = torch.full((B * S, 3 * W), float("nan"), device=dev())
+    L.check(l.rvlm_k_attn_bwd_f32_flash(qkv.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), dsum.data_ptr(), dqkv.data_ptr(), B, H, S, st()))
+    torch.cuda.synchronize()
+    x = qkv.double().clone().requires_grad_(True)
+    q, k, v = (t.reshape(B, S, H, 64).transpose(1, 2) for t in x.split(W, dim=1))
+    out = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, -1) @ v).transpose(1, 2).reshape(B * S, W)
+    (want,) = torch.autograd.grad((out * d_o.double()).sum(), x)
+    for name, sl in (("dq", slice(0, W)), ("dk", slice(W, 2 * W)), ("dv", slice(2 * W, 3 * W))):
+        err = float((dqkv[:, sl].double() - want[:, sl]).abs().max() / want[:, sl].abs().max())
+        assert err < 5e-6, (name, err)
