@@ -38,11 +38,12 @@ class VitEngine:
     (rvlm_pgd_run_mixed_fwd / rvlm_vit_backward_input_from) - the noise of FARE's first step sits in the forward difference
     phi(x + d0) - phi(x), not in the cotangent's way back (emulation: 0.998 sign agreement), and the x3 backward was more than
     half of the mixed mode's extra time.  'bf16+x3fwd': that split for EVERY iteration of ``pgd_run`` (split-bf16 forwards, bf16
-    backwards) - a rung between 'bf16+x3fwd-first' and 'x3'."""
+    backwards) - a rung between 'bf16+x3fwd-first' and 'x3'; ``faithful_iterations=k`` runs the first k iterations that way
+    (identical pixels with the reference's pgd() on the seeded ViT-L/14: k = 1: 0.927, 10: 0.984; tests/test_gpu_fullsize.py)."""
 
     def __init__(self, cfg, state_dict: dict, precision: str = "bf16", max_batch: int = 128,
                  mean=CLIP_MEAN, std=CLIP_STD, device=None, trainable: bool = False,
-                 inference_only: bool = False):
+                 inference_only: bool = False, faithful_iterations: int | None = None):
         if isinstance(cfg, str):
             cfg = CONFIGS[cfg]
         if not torch.cuda.is_available():
@@ -67,6 +68,10 @@ class VitEngine:
         self.mixed = precision in ("bf16+fp32-first", "bf16+x3-first", "bf16+x3fwd-first", "bf16+x3fwd")
         self.handoff = precision in ("bf16+x3fwd-first", "bf16+x3fwd")
         self.n_first = 4096 if precision == "bf16+x3fwd" else 1      # 'bf16+x3fwd': EVERY iteration's forward on the x3 handle
+        if faithful_iterations is not None:      # the continuum between the '-first' modes and 'bf16+x3fwd': the first k iterations
+            if not self.mixed or int(faithful_iterations) < 0:
+                raise ValueError("faithful_iterations needs a mixed precision and a count >= 0")
+            self.n_first = int(faithful_iterations)
         if self.mixed and (trainable or inference_only):
             raise ValueError(f"precision {precision!r} is an attack-engine option (not trainable / inference_only)")
         if precision == "x3" and trainable:

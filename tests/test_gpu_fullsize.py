@@ -17,6 +17,8 @@ One ViT-L/14 engine pair (bf16 max_batch 256, fp32 max_batch 8) is shared by the
 host threads and costs ~20 s per attack of 4 images (the trajectory test).
 """
 import os
+import time
+
 import numpy as np
 import pytest
 import torch
@@ -698,3 +700,29 @@ def test_clip_like_x3_forward_bf16_backward(setup_clip):
     assert sign0 > 0.99, sign0
     assert out["bf16+x3fwd-first"] > 0.85, out
     assert out["bf16+x3fwd"] > 0.95, out
+
+
+def test_config2_faithful_iterations_curve(setup):
+    """VitEngine(precision='bf16+x3fwd-first', faithful_iterations=k): the first k iterations with a split-bf16 forward (bf16 backward),
+    the rest bf16 - identical pixels with the reference's pgd() as a function of k (k = 1 is the '-first' mode, 10 'bf16+x3fwd')."""
+    s = setup
+    wd = {k: v.to(dev()) for k, v in s["w"].items()}
+    x, d0 = s["x"][:NP].to(dev()), s["d0"][:NP].to(dev())
+    x_or = torch.from_numpy(GOLD["pgd_x_adv"])
+    curve = {}
+    for k in (0, 1, 2, 3, 5, 10):
+        eng = R.VitEngine(to_cfg(s["cfg"]), wd, precision="bf16+x3fwd-first", max_batch=NP, faithful_iterations=k)
+        try:
+            model = R.ClipVisionModel(eng).eval()
+            e0 = model(x, False)
+            torch.cuda.synchronize()
+            t0 = time.time()
+            xa = R.pgd(model, R.ComputeLossWrapper(e0, None, "mean", "l2", 100.), x, None, "linf", EPS, 10, STEP, False,
+                       perturbation=d0.clone(), mode="max")
+            torch.cuda.synchronize()
+            curve[k] = (float((xa.cpu() == x_or).float().mean()), (time.time() - t0) * 1e3)
+        finally:
+            eng.close()
+    record("config2_faithful_iterations_curve", **{f"same_pixels_k{k}": v[0] for k, v in curve.items()},
+           **{f"ms_k{k}": v[1] for k, v in curve.items()})
+    assert curve[1][0] > curve[0][0] + 0.1 and curve[10][0] > curve[3][0] > curve[1][0] - 0.01, curve
