@@ -834,3 +834,27 @@ def test_handoff_backward_from_x3_forward(shape, normalize):
             assert float((xa - xd).abs().max()) <= 4 / 255 + 1e-6
     finally:
         eng.close(); e16.close()
+
+
+def test_fp32_flash_attention_matches_the_batched_path(monkeypatch):
+    """fp32-storage handles at S = 257 run every attention on the fp32 flash kernels (no kept probabilities, round 6);
+    RVLM_F32_FLASH=0 (read at creation) restores the batched score products of rounds 1-5.  Same embeddings and input gradients to
+    fp32 rounding, both precisions; and within one handle a saving and a non-saving forward agree bit for bit either way."""
+    cfg = V.VitConfig(224, 14, 256, 2, 4, 64)
+    w = V.init_weights(cfg, seed=2)
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(2, 3, 224, 224, generator=g).to(dev())
+    cot = torch.randn(2, cfg.out_dim, generator=g).to(dev())
+    for prec in ("fp32", "x3"):
+        res = {}
+        for flash in ("1", "0"):
+            monkeypatch.setenv("RVLM_F32_FLASH", flash)
+            eng = make_engine(cfg, w, prec, max_batch=2)
+            e_s = eng.forward(x, None, False, save=True)
+            gx = eng.backward_input(cot)
+            assert torch.equal(eng.forward(x, None, False, save=False), e_s)
+            res[flash] = (e_s.clone(), gx.clone(), eng.workspace_bytes())
+            eng.close()
+        assert rel_max(res["1"][0].cpu(), res["0"][0].cpu()) < 2e-6, prec
+        assert rel_max(res["1"][1].cpu(), res["0"][1].cpu()) < 2e-5, prec
+        assert res["1"][2] < res["0"][2]          # the probability buffers are gone
