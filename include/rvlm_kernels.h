@@ -90,6 +90,10 @@ int rvlm_k_probe_operand_stream(const uint16_t* A, const uint16_t* Bw, int M, in
 int rvlm_k_attn_occupancy(int S, int* out3);
 int rvlm_k_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y,
                              float* mean, float* rstd, int M, int W, rvlm_stream_t stream);
+/* bf16 dy and bf16 copy of the residual gradient; dres == NULL: the copy is the stream itself (accumulate reads it); accumulate < 0:
+ * only rows that are multiples of -accumulate accumulate, the others are overwritten */
+int rvlm_k_layernorm_bwd_bf16(const uint16_t* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                              float* dres, uint16_t* dres_lp, int accumulate, int M, int W, rvlm_stream_t stream);
 int rvlm_k_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean,
                              const float* rstd, float* dres, int accumulate, int M, int W,
                              rvlm_stream_t stream);

@@ -137,6 +137,10 @@ def forward(cfg, w, x, lin, att, store_bf16):
     """oracle/vit_ref.py::vit_forward with every GEMM routed through Mat (linears: `lin`, attention products: `att`)."""
     W, H = cfg.width, cfg.heads
     dh = W // H
+    res_bf16 = isinstance(store_bf16, str) and store_bf16.endswith("+res")      # the residual GRADIENT stream carried in bf16 too
+    if res_bf16:
+        store_bf16 = store_bf16[:-4]
+    rs = StoreGrad.apply if res_bf16 else (lambda t: t)
     st = StoreGrad.apply if store_bf16 == "grad" else Store.apply if store_bf16 else (lambda t: t)
     act = V.quick_gelu
     B = x.shape[0]
@@ -157,10 +161,10 @@ def forward(cfg, w, x, lin, att, store_bf16):
             s = Mat.apply(q, k.transpose(-1, -2), att) * (1.0 / math.sqrt(dh))
             pr = torch.softmax(s, dim=-1)
             a = st(Mat.apply(st(pr) if att == "bf16" or store_bf16 == "grad" else pr, v, att).transpose(1, 2).reshape(B, N, W))
-        t = t + Mat.apply(a, w[p + "attn.out_proj.weight"].t(), lin) + w[p + "attn.out_proj.bias"]
+        t = rs(t + Mat.apply(a, w[p + "attn.out_proj.weight"].t(), lin) + w[p + "attn.out_proj.bias"])
         h = st(F.layer_norm(t, (W,), w[p + "ln_2.weight"], w[p + "ln_2.bias"], 1e-5))
         h = st(act(Mat.apply(h, w[p + "mlp.c_fc.weight"].t(), lin) + w[p + "mlp.c_fc.bias"]))
-        t = t + Mat.apply(h, w[p + "mlp.c_proj.weight"].t(), lin) + w[p + "mlp.c_proj.bias"]
+        t = rs(t + Mat.apply(h, w[p + "mlp.c_proj.weight"].t(), lin) + w[p + "mlp.c_proj.bias"])
     pooled = F.layer_norm(t[:, 0], (W,), w["ln_post.weight"], w["ln_post.bias"], 1e-5)
     return pooled @ w["proj"]
 
@@ -178,6 +182,8 @@ MODES = {
     "x3fwd-bf16bwd": ("x3/bf16", "f32/bf16", "grad"),
     "f32fwd-bf16bwd": ("f32/bf16", "f32/bf16", "grad"),
     "x3fwd-bf16bwd-flash": ("x3/bf16", "f32/flash", "grad"),   # ... with the backward's attention core as the flash kernel runs it
+    # would a bf16-only residual-GRADIENT stream (LayerNorm backward 16 -> 10 B per element, ~15 ms per pgd() call) cost signs?
+    "f32fwd-bf16bwd-bf16res": ("f32/bf16", "f32/flash", "grad+res"),
     "x3lin-bf16att-bf16bwd": ("x3/bf16", "bf16", "grad"),      # ... and the forward's attention products on bf16 operands too
     "x3lin-x2att-bf16bwd": ("x3/bf16", "x2/bf16", "grad"),
 }

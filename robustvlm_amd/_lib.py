@@ -191,6 +191,8 @@ _SIGS = {
                                            C.c_int, c_stream]),
     "rvlm_k_layernorm_bwd_f32": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int,
                                            C.c_int, C.c_int, c_stream]),
+    "rvlm_k_layernorm_bwd_bf16": (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                            C.c_void_p]),
     "rvlm_k_probe_tr16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_stream]),
     "rvlm_k_wgrad_work_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "rvlm_k_wgrad_set_transposed": (None, [C.c_int]),

@@ -71,6 +71,13 @@ struct rvlm_vit {
     // forward and backward - runs on the flash kernels (attention_f32.hip); no probabilities are kept or allocated (13 GB at ViT-L/14,
     // B = 128) and saving / non-saving forwards agree bit for bit by construction.
     bool own_flash = false;
+    // bf16 handles, attack path (backward_impl): the residual-GRADIENT stream is the bf16 buffer only - the LayerNorm backward reads it
+    // to accumulate and writes it back, 10 instead of 16 B per element and pass (no fp32 copy).  What it costs: an accumulator of 49
+    // terms rounded to 8 bits of mantissa 49 times - measured by the emulation (oracle/split_bf16_emulation.py, arm
+    // f32fwd-bf16bwd-bf16res: first-step sign agreement of a bf16 backward 0.9982 -> 0.9961, CLIP-like 0.9977 -> 0.9945) and by the
+    // full-size tests; the handoff's backward (the faithful first iteration) and the training step keep the fp32 stream.
+    // RVLM_DRES_FP32=1 (read at creation) keeps it everywhere.
+    bool lp_dres = false;
     std::vector<void*> h_pre;    // L x [Mp, 4W] T
     void* g_act;         // [Mp, 4W] T
     float *pooled, *emb_raw, *inv_norm;   // [maxB, W], [maxB, D], [maxB]
@@ -635,12 +642,27 @@ static int forward_impl(rvlm_vit* h, const float* x, const float* delta, int B, 
     return RVLM_OK;
 }
 
+static int ew_blocks(size_t n);
+__global__ void __launch_bounds__(256)
+widen_bf16_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, size_t n8) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        const bf16x8 v = *(const bf16x8*)(src + 8 * i);
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (float)v[e];
+        *(float4*)(dst + 8 * i) = *(const float4*)&o[0];
+        *(float4*)(dst + 8 * i + 4) = *(const float4*)&o[4];
+    }
+}
+
 // ---- backward (input gradient only) --------------------------------------------------------------
 template <typename T>
-static int backward_impl(rvlm_vit* h, const float* d_emb, int B, float* grad_x, hipStream_t s) {
+static int backward_impl(rvlm_vit* h, const float* d_emb, int B, float* grad_x, hipStream_t s, bool fp32_dres = false) {
     const int S = h->S, W = h->W, L = h->L, D = h->D, M = B * S, M0 = B * h->G * h->G;
     const double attn_flops = 8.0 * B * h->H * (double)S * S * 64;
     constexpr bool LP = !std::is_same<T, float>::value;
+    // the fp32 residual-gradient stream, or none (LayerNorm backward then accumulates in the bf16 buffer, rvlm_vit::lp_dres)
+    float* const dres32 = (LP && h->lp_dres && !fp32_dres) ? nullptr : h->dres;
     int rc;
     {
         PROF("head_bwd", 2.0 * B * W * D, 0);
@@ -656,11 +678,11 @@ static int backward_impl(rvlm_vit* h, const float* d_emb, int B, float* grad_x, 
         g.M = B; g.N = W; g.K = D;
         if ((rc = gemm_f32(g, s))) return rc;
         if (!h->cls_tail) {   // with the class-token tail the last block's ln_1 backward overwrites the other rows
-            RVLM_HIP(hipMemsetAsync(h->dres, 0, (size_t)h->Mp * W * 4, s));
+            if (dres32) RVLM_HIP(hipMemsetAsync(dres32, 0, (size_t)h->Mp * W * 4, s));
             if (LP) RVLM_HIP(hipMemsetAsync(h->dres_lp, 0, (size_t)h->Mp * W * sizeof(T), s));
         }
         if ((rc = layernorm_bwd<float, T>(h->d_pooled, W, h->xs[2 * L], (long)S * W, h->lnpost_w,
-                                          h->mean_at(2 * L + 1), h->rstd_at(2 * L + 1), h->dres, (long)S * W,
+                                          h->mean_at(2 * L + 1), h->rstd_at(2 * L + 1), dres32, (long)S * W,
                                           LP ? (T*)h->dres_lp : nullptr, (long)S * W, 0, B, W, s))) return rc;
     }
     const void* dres_A = LP ? (const void*)h->dres_lp : (const void*)h->dres;
@@ -675,7 +697,7 @@ static int backward_impl(rvlm_vit* h, const float* d_emb, int B, float* grad_x, 
                 if ((rc = linear_dgrad<T>(h, s, h->dh, 4 * W, B, 4 * W, W, y.w_fc, W, y.w_fc_t, EPI_BF16, h->d_ln, W,
                                           nullptr))) return rc;
                 if ((rc = layernorm_bwd<T, T>((const T*)h->d_ln, W, h->xs[2 * l + 1], SW, y.ln2_w, h->mean_at(2 + 2 * l),
-                                              h->rstd_at(2 + 2 * l), h->dres, SW, (T*)h->dres_lp, SW, 1, B, W, s)))
+                                              h->rstd_at(2 + 2 * l), dres32, SW, (T*)h->dres_lp, SW, 1, B, W, s)))
                     return rc;
                 if ((rc = linear_dgrad<T>(h, s, dres_A, SW, B, W, W, y.w_out, W, y.w_out_t, EPI_BF16, h->d_o, W,
                                           nullptr, B))) return rc;
@@ -698,9 +720,9 @@ static int backward_impl(rvlm_vit* h, const float* d_emb, int B, float* grad_x, 
                                       nullptr))) return rc;
         }
         {
-            PROF("layernorm_bwd", 0, (double)M * W * (12 + 2 * sizeof(T)));
+            PROF("layernorm_bwd", 0, (double)M * W * ((dres32 ? 12 : 6) + 2 * sizeof(T)));
             if ((rc = layernorm_bwd<T, T>((const T*)h->d_ln, W, h->xs[2 * l + 1], W, y.ln2_w, h->mean_at(2 + 2 * l),
-                                          h->rstd_at(2 + 2 * l), h->dres, W, LP ? (T*)h->dres_lp : nullptr, W, 1,
+                                          h->rstd_at(2 + 2 * l), dres32, W, LP ? (T*)h->dres_lp : nullptr, W, 1,
                                           M, W, s))) return rc;
         }
         {
@@ -723,14 +745,18 @@ static int backward_impl(rvlm_vit* h, const float* d_emb, int B, float* grad_x, 
                                       nullptr))) return rc;
         }
         {
-            PROF("layernorm_bwd", 0, (double)M * W * (12 + 2 * sizeof(T)));
+            PROF("layernorm_bwd", 0, (double)M * W * ((dres32 ? 12 : 6) + 2 * sizeof(T)));
             if ((rc = layernorm_bwd<T, T>((const T*)h->d_ln, W, h->xs[2 * l], W, y.ln1_w, h->mean_at(1 + 2 * l),
-                                          h->rstd_at(1 + 2 * l), h->dres, W, LP ? (T*)h->dres_lp : nullptr, W,
+                                          h->rstd_at(1 + 2 * l), dres32, W, LP ? (T*)h->dres_lp : nullptr, W,
                                           (h->cls_tail && l == L - 1) ? -S : 1, M, W, s))) return rc;
         }
     }
     {
         PROF("embed_lnpre_bwd", 0, (double)M * W * 8);
+        if (!dres32) {      // (the embedding backward reads the residual gradient as fp32: one widening pass per backward, 40 us)
+            hipLaunchKernelGGL(widen_bf16_kernel, dim3(ew_blocks((size_t)M * W / 8)), dim3(256), 0, s, (const bf16_t*)h->dres_lp, h->dres, (size_t)M * W / 8);
+            RVLM_CHECK_LAUNCH();
+        }
         if ((rc = embed_lnpre_bwd<T>(h->dres, W, h->patch_out, W, h->cls, h->pos, h->lnpre_w, h->mean_at(0),
                                      h->rstd_at(0), (T*)h->d_patch, W, B, S, W, s))) return rc;
     }
@@ -988,7 +1014,7 @@ static int vit_backward_from(rvlm_vit* hb, rvlm_vit* hx, const float* d_emb, int
     const bool tail = hb->cls_tail;
     const bool sn = hb->saved_norm;
     hb->cls_tail = false; hb->saved_norm = hx->saved_norm;
-    rc = backward_impl<bf16_t>(hb, d_emb, B, grad_x, s);
+    rc = backward_impl<bf16_t>(hb, d_emb, B, grad_x, s, /*fp32_dres=*/true);
     hb->cls_tail = tail; hb->saved_norm = sn;
     hb->saved_B = 0;        // (hb's own saved forward, if any, lost its bf16 tensors to the exports)
     return rc;
@@ -1058,6 +1084,10 @@ extern "C" int rvlm_vit_create(const rvlm_vit_config* cfg, const rvlm_vit_weight
         if (rc) { rvlm_vit_destroy(h); return rc; }
     }
     // (a provider needs the flash forward for its sequence length: otherwise the handoff exports from per-block fp32 tensors)
+    {
+        const char* e = getenv("RVLM_DRES_FP32");      // 1: the fp32 residual-gradient stream in every backward (rounds 1-5)
+        h->lp_dres = h->bf16 && !(e && atoi(e) != 0);
+    }
     {
         const char* e = getenv("RVLM_F32_FLASH");      // 0: the batched attention path over kept probabilities (A/B and parity arm)
         h->own_flash = !h->bf16 && attn_bwd_f32_flash_covers(S) && !(e && atoi(e) == 0);

@@ -333,6 +333,12 @@ extern "C" int rvlm_k_layernorm_fwd_f32(const float* x, const float* gamma, cons
                                         float* mean, float* rstd, int M, int W, rvlm_stream_t stream) {
     return layernorm_fwd<float>(x, W, gamma, beta, y, W, mean, rstd, M, W, (hipStream_t)stream);
 }
+// bf16 dy / bf16 copy; dres == NULL: the bf16 copy is the residual-gradient stream itself (read to accumulate, written back)
+extern "C" int rvlm_k_layernorm_bwd_bf16(const uint16_t* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                         float* dres, uint16_t* dres_lp, int accumulate, int M, int W, rvlm_stream_t stream) {
+    return layernorm_bwd<bf16_t, bf16_t>((const bf16_t*)dy, W, x, W, gamma, mean, rstd, dres, W, (bf16_t*)dres_lp, W, accumulate, M, W,
+                                         (hipStream_t)stream);
+}
 extern "C" int rvlm_k_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean,
                                         const float* rstd, float* dres, int accumulate, int M, int W,
                                         rvlm_stream_t stream) {

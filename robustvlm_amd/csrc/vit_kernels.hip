@@ -180,23 +180,26 @@ layernorm_bwd_kernel(const TI* __restrict__ dy, long lddy, const float* __restri
     }
     const float c1 = wave_sum(s1) / (float)W;
     const float c2 = wave_sum(s2) / (float)W;
-    float* dr = dres + (long)row * lddres;
+    // dres == null: the low-precision copy IS the residual-gradient stream (read to accumulate, written back)
+    float* dr = dres ? dres + (long)row * lddres : nullptr;
 #pragma unroll
     for (int it = 0; it < LN_MAXV; ++it) {
         const int c = lane * 4 + it * 256;
         if (c < W) {
             float o[4];
-            if (accumulate) load4(dr + c, o); else { o[0] = o[1] = o[2] = o[3] = 0.0f; }
+            if (!accumulate) { o[0] = o[1] = o[2] = o[3] = 0.0f; }
+            else if (dr) load4(dr + c, o);
+            else load4(dres_lp + (long)row * ldlp + c, o);
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] += rs * (g[it][e] - c1 - xh[it][e] * c2);
-            store4(dr + c, o);
+            if (dr) store4(dr + c, o);
             if (dres_lp) store4(dres_lp + (long)row * ldlp + c, o);
         }
     }
 }
 
 // bf16 dy / dres_lp, W = NV * 512: 8 consecutive columns per lane and slab (16-byte bf16 accesses), as in the forward
-template <int NV>
+template <int NV, bool LPONLY = false>
 __global__ void __launch_bounds__(256)
 layernorm_bwd8_kernel(const bf16_t* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx,
                       const float* __restrict__ gamma, const float* __restrict__ mean,
@@ -229,21 +232,28 @@ layernorm_bwd8_kernel(const bf16_t* __restrict__ dy, long lddy, const float* __r
     }
     const float c1 = wave_sum(s1) / (float)(NV * 512);
     const float c2 = wave_sum(s2) / (float)(NV * 512);
-    float* dr = dres + (long)row * lddres + lane * 8;
+    // LPONLY: the bf16 copy IS the residual-gradient stream - read to accumulate, written back: 10 instead of 16 B per element
+    float* dr = LPONLY ? nullptr : dres + (long)row * lddres + lane * 8;
 #pragma unroll
     for (int it = 0; it < NV; ++it) {
         float o[8];
-        if (accumulate) {
-            *(float4*)&o[0] = *(const float4*)(dr + it * 512);
-            *(float4*)&o[4] = *(const float4*)(dr + it * 512 + 4);
-        } else {
+        if (!accumulate) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = 0.0f;
+        } else if (LPONLY) {
+            const bf16x8 a = *(const bf16x8*)(dres_lp + (long)row * ldlp + lane * 8 + it * 512);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (float)a[e];
+        } else {
+            *(float4*)&o[0] = *(const float4*)(dr + it * 512);
+            *(float4*)&o[4] = *(const float4*)(dr + it * 512 + 4);
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] += rs * (g[it][e] - c1 - xh[it][e] * c2);
-        *(float4*)(dr + it * 512) = *(const float4*)&o[0];
-        *(float4*)(dr + it * 512 + 4) = *(const float4*)&o[4];
+        if (!LPONLY) {
+            *(float4*)(dr + it * 512) = *(const float4*)&o[0];
+            *(float4*)(dr + it * 512 + 4) = *(const float4*)&o[4];
+        }
         if (dres_lp) {
             bf16x8 ol;
 #pragma unroll
@@ -262,9 +272,12 @@ bool layernorm_bwd8<bf16_t, bf16_t>(const bf16_t* dy, long lddy, const float* x,
                                     const float* mean, const float* rstd, float* dres, long lddres, bf16_t* dres_lp,
                                     long ldlp, int accumulate, int M, int W, hipStream_t s) {
     if (W % 512 != 0 || W > 2048 || lddy % 8 != 0 || ldx % 4 != 0 || lddres % 4 != 0 || ldlp % 8 != 0) return false;
+    if (!dres && !dres_lp) return false;
     const dim3 grid(cdiv(M, 4)), block(256);
-#define RVLM_LNB8(NVV) hipLaunchKernelGGL((layernorm_bwd8_kernel<NVV>), grid, block, 0, s, dy, lddy, x, ldx, gamma, mean, \
-                                          rstd, dres, lddres, dres_lp, ldlp, accumulate, M)
+#define RVLM_LNB8(NVV) do { if (dres) hipLaunchKernelGGL((layernorm_bwd8_kernel<NVV, false>), grid, block, 0, s, dy, lddy, x, ldx, gamma, mean, \
+                                                          rstd, dres, lddres, dres_lp, ldlp, accumulate, M);                                  \
+                            else hipLaunchKernelGGL((layernorm_bwd8_kernel<NVV, true>), grid, block, 0, s, dy, lddy, x, ldx, gamma, mean,     \
+                                                    rstd, dres, lddres, dres_lp, ldlp, accumulate, M); } while (0)
     switch (W / 512) {
         case 1: RVLM_LNB8(1); break;
         case 2: RVLM_LNB8(2); break;

@@ -607,3 +607,40 @@ def test_attn_bwd_f32_flash(S):
     for name, sl in (("dq", slice(0, W)), ("dk", slice(W, 2 * W)), ("dv", slice(2 * W, 3 * W))):
         err = float((dqkv[:, sl].double() - want[:, sl]).abs().max() / want[:, sl].abs().max())
         assert err < 5e-6, (name, err)
+
+
+@pytest.mark.parametrize("W", [1024, 768, 256])
+def test_layernorm_bwd_bf16_residual_gradient_stream(W):
+    """LayerNorm backward of the bf16 engine, both forms of the residual-gradient stream: fp32 accumulator + bf16 copy (rounds 1-5;
+    the handoff's backward and the training step), and the bf16 buffer ALONE (round 6, the attack path: read to accumulate, written
+    back - 10 instead of 16 B per element).  Against fp64 torch; the class-token form (accumulate = -S: only every S-th row
+    accumulates) in both."""
+    l = lib()
+    M, S = 4 * 37 + 3, 5
+    g = torch.Generator(device="cuda").manual_seed(W)
+    x = torch.randn(M, W, generator=g, device=dev()) * 2 + 0.5
+    gm = 1 + 0.2 * torch.randn(W, generator=g, device=dev())
+    dy = torch.randn(M, W, generator=g, device=dev()).bfloat16()
+    acc0 = torch.randn(M, W, generator=g, device=dev()).bfloat16()
+    mean = x.mean(1).contiguous()
+    rstd = (x.var(1, unbiased=False) + 1e-5).rsqrt().contiguous()
+    xd = x.double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xd, (W,), gm.double(), None, 1e-5)
+    (gx,) = torch.autograd.grad((ref * dy.double()).sum(), xd)
+    rows = torch.arange(M, device=dev())
+    for accumulate in (1, 0, -S):
+        keep = torch.ones(M, dtype=torch.bool, device=dev()) if accumulate == 1 else (rows % S == 0) if accumulate < 0 else torch.zeros(M, dtype=torch.bool, device=dev())
+        want = gx + acc0.double() * keep[:, None]
+        # (a) fp32 stream + bf16 copy
+        dres = acc0.float().clone()
+        lp = torch.zeros(M, W, dtype=torch.bfloat16, device=dev())
+        L.check(l.rvlm_k_layernorm_bwd_bf16(dy.data_ptr(), x.data_ptr(), gm.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dres.data_ptr(),
+                                            lp.data_ptr(), accumulate, M, W, st()))
+        # (b) the bf16 buffer alone
+        lp2 = acc0.clone()
+        L.check(l.rvlm_k_layernorm_bwd_bf16(dy.data_ptr(), x.data_ptr(), gm.data_ptr(), mean.data_ptr(), rstd.data_ptr(), None,
+                                            lp2.data_ptr(), accumulate, M, W, st()))
+        torch.cuda.synchronize()
+        assert rel_max(dres, want) < 1e-5, accumulate
+        assert torch.equal(lp, dres.bfloat16()), accumulate
+        assert torch.equal(lp2, lp), accumulate          # same fp32 arithmetic on the same bf16-representable accumulator: same rounding
