@@ -98,9 +98,12 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32 p) {
 // LDS tile (lanes = consecutive rows: conflict-free ds_write_b32); a row-contiguous operand ([K, N] weights, V, the
 // transposed score matrices) as 16-byte chunks of 4 rows written whole.  vec_a / vec_b = the operand's base, strides and
 // extent allow 16-byte accesses (else scalar, guarded loads: S = 257 score matrices).
+#ifndef RVLM_F32_BK
+#define RVLM_F32_BK 16      // k-tile depth of the fp32 MFMA tiles (A/B knob: 32 = half the barriers, 64 KiB of LDS, two workgroups per CU)
+#endif
 template <int ROWS, bool KC>
 struct F32TileLoader {
-    static constexpr int NV = ROWS * 16 / 4 / 256;   // 16-byte chunks per thread: 2 (ROWS = 128) or 1 (ROWS = 64)
+    static constexpr int NV = ROWS * RVLM_F32_BK / 4 / 256;   // 16-byte chunks per thread (BK = 16: 2 at ROWS = 128, 1 at ROWS = 64)
     float4 v[NV];
     __device__ __forceinline__ void load(const float* __restrict__ base, long s_row, long s_k, int row0, int nrows, int k0,
                                          int K, int tid, bool VEC) {
@@ -152,7 +155,7 @@ struct F32TileLoader {
 // PLAIN: alpha and bias only (the instantiations with the activation / act' / residual epilogue are 5x the code)
 template <int BM, int BN, bool A_KC, bool B_KC, bool PLAIN>
 __global__ void __launch_bounds__(256) gemm_f32_mfma_kernel(GemmF32 p, int vec_a, int vec_b) {
-    constexpr int BK = 16, TM = BM / 64, TN = BN / 64;
+    constexpr int BK = RVLM_F32_BK, TM = BM / 64, TN = BN / 64;
     __shared__ __attribute__((aligned(16))) float As[2][BK][BM];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
     const int bz = blockIdx.z;
