@@ -187,7 +187,7 @@ def pgd_ref(forward, loss_fn, data_clean, targets, norm, eps, iterations, stepsi
             loss = loss_fn(out, targets)                                          # :33
         g = torch.autograd.grad(loss, p)[0].numpy().astype(F32)                   # :38
         if trace is not None:
-            trace.append(dict(loss=float(loss), grad=g.copy()))
+            trace.append(dict(loss=float(loss.detach()), grad=g.copy()))
         if norm in LINF:
             delta, vel = pgd_linf_update_ref(x, g, delta, vel, eps, stepsize, momentum, mode)
         else:
