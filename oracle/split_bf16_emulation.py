@@ -138,9 +138,14 @@ def forward(cfg, w, x, lin, att, store_bf16):
     W, H = cfg.width, cfg.heads
     dh = W // H
     res_bf16 = isinstance(store_bf16, str) and store_bf16.endswith("+res")      # the residual GRADIENT stream carried in bf16 too
+    res_fwd = isinstance(store_bf16, str) and store_bf16.endswith("+resfwd")    # ... and the residual stream ITSELF (forward) as well
     if res_bf16:
         store_bf16 = store_bf16[:-4]
-    rs = StoreGrad.apply if res_bf16 else (lambda t: t)
+    if res_fwd:
+        store_bf16 = store_bf16[:-7]
+    if store_bf16 == "all":
+        store_bf16 = True
+    rs = Store.apply if res_fwd else StoreGrad.apply if res_bf16 else (lambda t: t)
     st = StoreGrad.apply if store_bf16 == "grad" else Store.apply if store_bf16 else (lambda t: t)
     act = V.quick_gelu
     B = x.shape[0]
@@ -184,6 +189,10 @@ MODES = {
     "x3fwd-bf16bwd-flash": ("x3/bf16", "f32/flash", "grad"),   # ... with the backward's attention core as the flash kernel runs it
     # would a bf16-only residual-GRADIENT stream (LayerNorm backward 16 -> 10 B per element, ~15 ms per pgd() call) cost signs?
     "f32fwd-bf16bwd-bf16res": ("f32/bf16", "f32/flash", "grad+res"),
+    # LATER iterations (run with ITER=k: the perturbation after k sign steps of the fp32 arm): what the bf16 engine's fp32 residual
+    # stream is worth there - bf16 as it is, with the bf16 residual-gradient stream (shipped), and with a bf16 residual stream forward
+    "bf16-bf16res": ("bf16", "bf16", "all+res"),
+    "bf16-bf16resfwd": ("bf16", "bf16", "all+resfwd"),
     "x3lin-bf16att-bf16bwd": ("x3/bf16", "bf16", "grad"),      # ... and the forward's attention products on bf16 operands too
     "x3lin-x2att-bf16bwd": ("x3/bf16", "x2/bf16", "grad"),
 }
@@ -206,6 +215,11 @@ def run(tag, clip_like, n=4):
     eps = 4 / 255
     x = torch.rand(256, 3, 224, 224, generator=torch.Generator().manual_seed(0))[:n]
     d0 = ((torch.rand(256, 3, 224, 224, generator=torch.Generator().manual_seed(1)) * 2 - 1) * eps)[:n]
+    for it in range(int(os.environ.get("ITER", "0"))):     # k plain sign steps of the fp32 arm (momentum-free PGD: a pricing study)
+        _, _, g = first_iteration(cfg, w, x, d0, "f32")
+        d0 = (d0 + (1 / 255) * torch.sign(g)).clamp(-eps, eps)
+        d0 = (x + d0).clamp(0, 1) - x
+        tag = tag.split(" @")[0] + f" @ iteration {it + 1}"
     ref = None
     for name in (os.environ.get("ARMS", "").split(",") if os.environ.get("ARMS") else MODES):
         t0 = time.time()
